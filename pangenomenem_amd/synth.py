@@ -1,0 +1,116 @@
+"""Seeded synthetic NEM problems: presence/absence matrices, contiguity graphs
+and initial parameters shaped like what PPanGGOLiN's ``__write_nem_input_files`` emits
+(reference: ppanggolin/ppanggolin.py:821-930).  Pure numpy; input generation only.
+"""
+import numpy as np
+
+# BASELINE.json configs (families N, organisms D, classes K, beta)
+CONFIGS = {
+    "C1": dict(n=2048, d=15, k=3, beta=0.0, graph=False, seed=1),
+    "C2": dict(n=20000, d=500, k=3, beta=0.5, graph=True, seed=2),
+    "C3": dict(n=50000, d=1000, k=3, beta=0.5, graph=True, seed=3),
+    "C4": dict(n=200000, d=5000, k=3, beta=0.5, graph=True, seed=4),
+    "C5": dict(n=20000, d=500, k=None, beta=0.5, graph=True, seed=5, latent=10),
+}
+
+
+def bernoulli_pa_matrix(n, d, seed, mix=(0.30, 0.20, 0.50), p=(0.97, 0.5, 0.03)):
+    """3-latent-class (persistent / shell / cloud) 0/1 matrix, uint8 [n, d]; all-zero rows get
+    one random 1 (a family absent from every selected organism is never written, ppanggolin.py:849)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    z = rng.choice(len(mix), size=n, p=np.asarray(mix) / np.sum(mix))
+    pz = np.asarray(p, np.float64)[z]
+    x = (rng.random((n, d)) < pz[:, None]).astype(np.uint8)
+    empty = np.flatnonzero(x.sum(axis=1) == 0)
+    x[empty, rng.integers(0, d, size=len(empty))] = 1
+    return x, z
+
+
+def grouped_pa_matrix(n, d, seed, groups=10, p_in=0.95, p_out=0.05):
+    """`groups`-latent-class matrix for the K-sweep (C5): class c present with p_in in organism
+    group c and p_out elsewhere, so no class empties for K <= groups."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    z = rng.integers(0, groups, size=n)
+    org_group = (np.arange(d) * groups) // d
+    prob = np.where(org_group[None, :] == z[:, None], p_in, p_out)
+    x = (rng.random((n, d)) < prob).astype(np.uint8)
+    empty = np.flatnonzero(x.sum(axis=1) == 0)
+    x[empty, rng.integers(0, d, size=len(empty))] = 1
+    return x, z
+
+
+def contiguity_graph(n, seed, chord_frac=0.05, wmax=8):
+    """Path i<->i+1 in index order plus n*chord_frac random chords, undirected, every edge listed
+    from both endpoints, integer weights uniform in [1, wmax] (keeps beta*sum(w) far below the
+    reference's exp overflow at 709).  Returns CSR (ptr int32[n+1], idx int32, w float32);
+    neighbour order inside a row = insertion order (the order a .nei line would list them)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    src = [np.arange(n - 1, dtype=np.int64)]
+    dst = [np.arange(1, n, dtype=np.int64)]
+    nch = int(n * chord_frac)
+    if nch > 0 and n > 3:
+        a = rng.integers(0, n, size=nch)
+        b = rng.integers(0, n, size=nch)
+        keep = np.abs(a - b) > 1
+        src.append(a[keep]); dst.append(b[keep])
+    s = np.concatenate(src); t = np.concatenate(dst)
+    # drop duplicate undirected edges, keep first occurrence
+    key = np.minimum(s, t) * n + np.maximum(s, t)
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    s, t = s[first], t[first]
+    w = rng.integers(1, wmax + 1, size=len(s)).astype(np.float32)
+    # both directions, stable by insertion order
+    us = np.concatenate([s, t]); ut = np.concatenate([t, s]); uw = np.concatenate([w, w])
+    order = np.concatenate([np.arange(len(s)) * 2, np.arange(len(s)) * 2 + 1])
+    perm = np.lexsort((order, us))
+    us, ut, uw = us[perm], ut[perm], uw[perm]
+    ptr = np.zeros(n + 1, np.int32)
+    np.add.at(ptr, us + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    return ptr, ut.astype(np.int32), uw.astype(np.float32)
+
+
+def default_init(d, low_disp=0.1):
+    """PPanGGOLiN's default .m (ppanggolin.py:893-901): pi 0.33333/0.33333/rest, mu 1/0.5/0,
+    eps low/0.5/low.  pi_K is computed as ReadParamFile does (float 1 - p0 - p1, nem_exe.c:1022-1034)."""
+    p0 = np.float32(0.33333)
+    prop = np.array([p0, p0, np.float32(np.float32(np.float32(1.0) - p0) - p0)], np.float32)
+    center = np.stack([np.ones(d), np.full(d, 0.5), np.zeros(d)]).astype(np.float32)
+    disp = np.stack([np.full(d, low_disp), np.full(d, 0.5), np.full(d, low_disp)]).astype(np.float32)
+    return prop, center, disp
+
+
+def kclass_init(x, k, eps=0.1):
+    """Deterministic K-class init for the K-sweep: equal pi written with 4 decimals
+    (round(1/K, 4) like ppanggolin.py:907), mu_k = data row floor((k+1/2)N/K) after sorting rows by
+    (popcount, index), eps = 0.1 everywhere."""
+    n, d = x.shape
+    pc = x.sum(axis=1)
+    order = np.lexsort((np.arange(n), pc))
+    rows = [order[int((c + 0.5) * n / k)] for c in range(k)]
+    center = x[rows].astype(np.float32)
+    disp = np.full((k, d), eps, np.float32)
+    pw = np.float32(round(1.0 / k, 4))
+    prop = np.full(k, pw, np.float32)
+    rem = np.float32(1.0)
+    for c in range(k - 1):
+        rem = np.float32(rem - prop[c])
+    prop[k - 1] = rem
+    return prop, center, disp
+
+
+def make_config(name, n=None, d=None, k=None):
+    """Build one BASELINE config (optionally down-scaled): dict(x, nei, k, beta, prop, center, disp)."""
+    cfg = dict(CONFIGS[name])
+    n = n or cfg["n"]; d = d or cfg["d"]
+    if cfg.get("latent"):
+        x, _ = grouped_pa_matrix(n, d, cfg["seed"], groups=cfg["latent"])
+        k = k or 5
+        prop, center, disp = kclass_init(x, k)
+    else:
+        x, _ = bernoulli_pa_matrix(n, d, cfg["seed"])
+        k = 3
+        prop, center, disp = default_init(d)
+    nei = contiguity_graph(n, cfg["seed"]) if cfg["graph"] else None
+    return dict(name=name, x=x, nei=nei, k=k, beta=cfg["beta"], prop=prop, center=center, disp=disp)
