@@ -1,0 +1,163 @@
+/*
+ * nem_mi355x.h -- C ABI of the MI355X-native NEM partitioning engine.
+ *
+ * Two layers, both plain C (pointers and sizes, no torch/C++ types):
+ *
+ *  1. The DROP-IN entry `nem()`: same symbol, signature, argument meaning, file formats and
+ *     return codes as the reference's only FFI entry point
+ *         /root/reference/ppanggolin/NEM/nem_exe.h:23-35   (declaration)
+ *         /root/reference/ppanggolin/NEM/nem_exe.c:239-704 (definition)
+ *         /root/reference/ppanggolin/NEM/nem.pyx:1-14      (the Cython `cpdef` binding PPanGGOLiN uses)
+ *     It reads <Fname>.str/.dat/.nei/.m, runs the EM loop on the GPU, writes <Fname>.uf|.cf, .mf,
+ *     .stderr and (dolog) .log.
+ *
+ *  2. The in-memory engine `nemgpu_*`: the same EM loop without the ASCII files, for callers that
+ *     already hold the presence/absence matrix (benchmarks, tests, the multi-GPU host driver).
+ *     It replaces the in-memory path  ClassifyByNem()  nem_alg.h:10-18 / nem_alg.c:546-584.
+ *
+ * Every entry point fails loudly (non-zero return + message in nemgpu_last_error()) when no HIP
+ * device is usable: there is no CPU fallback in this library.
+ */
+#ifndef NEM_MI355X_H
+#define NEM_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Drop-in entry (reference: nem_exe.h:23-35).
+ *
+ *   Fname          base path; inputs <Fname>.str .dat .nei .m, outputs <Fname>.uf|.cf .mf .stderr .log
+ *   nk             number of classes K (> 0)
+ *   algo           "nem" | "ncem"            ("gem" is not reachable from PPanGGOLiN; rejected)
+ *   beta           MRF weight of the neighbourhood term
+ *   convergence    "none" | "clas"           ("crit" rejected: needs per-iteration criteria)
+ *   convergence_th threshold of the "clas" test (max |c - c_old| < th)
+ *   format         "hard" (.cf) | "fuzzy" (.uf)
+ *   it_max         maximum number of EM iterations (>= 0)
+ *   dolog          non-zero: messages to <Fname>.stderr and an iteration log <Fname>.log
+ *   model_family   "bern" (the only family PPanGGOLiN uses; "norm"/"lapl" rejected)
+ *   proportion     "p_" | "pk"
+ *   dispersion     "s__" | "sk_" | "s_d" | "skd"
+ *   init_mode      2 (INIT_PARAM_FILE, nem_typ.h:218); other modes rejected
+ *
+ * Return value (ExitET, lib_io.h:22-34): 0 ok, 1 empty class (no output files, like the
+ * reference), 2 bad arguments, 3 file error, 4 memory, 5 GPU/system error, 6 internal error.
+ * ------------------------------------------------------------------------------------------ */
+int nem(const char* Fname,
+        const int nk,
+        const char* algo,
+        const float beta,
+        const char* convergence,
+        const float convergence_th,
+        const char* format,
+        const int it_max,
+        const int dolog,
+        const char* model_family,
+        const char* proportion,
+        const char* dispersion,
+        const int init_mode);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. In-memory engine.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nemgpu_engine nemgpu_engine;
+
+/* numeric values follow the reference enums (nem_typ.h:121-128, 191-205, 271-277) */
+enum { NEMGPU_ALGO_NEM = 0, NEMGPU_ALGO_NCEM = 1 };
+enum { NEMGPU_DISP___ = 0, NEMGPU_DISP_K_ = 1, NEMGPU_DISP__D = 2, NEMGPU_DISP_KD = 3 };
+enum { NEMGPU_PROP__ = 0, NEMGPU_PROP_K = 1 };
+enum { NEMGPU_CV_NONE = 0, NEMGPU_CV_CLAS = 1 };
+/* NCEM tie rule (ComputeMAP, nem_alg.c:590-645). The reference draws random() seeded with
+   time(NULL) (nem_exe.c:353,621), which no caller can reproduce; the engine offers
+   FIRST (= TIE_FIRST) and HASH (counter-based: kmaxes[mix32(seed, sweep, site) % (nequal+1)]). */
+enum { NEMGPU_TIE_FIRST = 1, NEMGPU_TIE_HASH = 2 };
+/* status codes = StatusET (nem_typ.h:106-117) */
+enum { NEMGPU_OK = 0, NEMGPU_W_EMPTYCLASS = 2, NEMGPU_E_ARG = 3, NEMGPU_E_MEMORY = 4,
+       NEMGPU_E_FILEIN = 5, NEMGPU_E_FILEOUT = 6, NEMGPU_E_FILE = 7, NEMGPU_E_FUNCARG = 8,
+       NEMGPU_E_DEVICE = 9 };
+
+typedef struct {
+    int   algo;        /* NEMGPU_ALGO_*  */
+    float beta;
+    int   disper;      /* NEMGPU_DISP_*  */
+    int   propor;      /* NEMGPU_PROP_*  */
+    int   cvtest;      /* NEMGPU_CV_*    */
+    float cvthres;
+    int   it_max;
+    int   param_fix;   /* .m flag 2: never re-estimate parameters (nem_alg.c:1806) */
+    int   tie_rule;    /* NEMGPU_TIE_*   */
+    uint32_t tie_seed;
+} nemgpu_config;
+
+typedef struct {
+    int   status;      /* NEMGPU_OK or NEMGPU_W_EMPTYCLASS */
+    int   iters;       /* completed EM iterations */
+    int   converged;
+    int   emptyk;      /* 1..K, 0 if none */
+    int   zero_density_sites;   /* E-step updates that hit cumnum == 0 (nem_alg.c:2603-2613) */
+    int   first_zero_density_site;
+    int   sweep_rounds;         /* total relaxation rounds spent in E-step sweeps */
+    float crit[6];     /* D G U M L Z (ComputeCrit, nem_alg.c:2678-2757) */
+    double loop_seconds;        /* wall time of the EM iteration loop (host clock, synchronised) */
+} nemgpu_result;
+
+const char* nemgpu_last_error(void);
+
+/* Number of usable HIP devices (0 when none). */
+int nemgpu_device_count(void);
+
+/* Create an engine for n_total families x d organisms, k classes on `device`.
+   [site_lo, site_hi) is the family shard this engine owns (0, n_total for a single GPU).
+   `hip_stream` is a hipStream_t to run on, or NULL for an engine-owned stream. */
+int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, int site_hi,
+                  int device, void* hip_stream);
+void nemgpu_destroy(nemgpu_engine* e);
+
+/* Presence/absence rows of the owned shard, one byte per cell (0/1), row-major
+   [(site_hi-site_lo) x d], HOST memory.  Bit-packs, uploads and builds both device layouts. */
+int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host);
+/* Same, family-major bit-packed rows: word w of row i holds organisms 32w..32w+31 (bit b =
+   organism 32w+b), ceil(d/32) words per row, HOST memory. */
+int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host);
+/* Neighbourhood graph of the owned shard in CSR, .nei file order inside a row; neighbour
+   indices are GLOBAL family indices (0-based).  ptr has (site_hi-site_lo)+1 entries.  HOST memory. */
+int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, const float* w);
+/* Initial parameters (the .m file content): prop[k], center[k*d], disp[k*d].  HOST memory. */
+int nemgpu_set_params(nemgpu_engine* e, const float* prop, const float* center, const float* disp);
+int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg);
+
+/* Whole run: INIT_PARAM_FILE start + EM loop + final criteria (single-GPU engines only). */
+int nemgpu_run(nemgpu_engine* e, nemgpu_result* res);
+
+/* Step-level entry points (same kernels; used by tests, bench.py and the multi-GPU host driver). */
+int nemgpu_init_partition(nemgpu_engine* e);              /* ComputePartitionFromPara(Needinit=1) */
+int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res);  /* up to n_iters EM iterations */
+int nemgpu_reset(nemgpu_engine* e);                       /* back to the initial parameters, zero partition */
+int nemgpu_density(nemgpu_engine* e);                     /* E1 only */
+int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds);  /* E2 only (one full Gauss-Seidel sweep) */
+int nemgpu_mstep(nemgpu_engine* e, int* emptyk);          /* M only */
+int nemgpu_criteria(nemgpu_engine* e, float crit6[6]);    /* C1 only */
+
+/* Test hook: load a partition (row-major [n_total x k], HOST) as the current state
+   (argmax labels for ncem engines). */
+int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk);
+
+/* Results (HOST buffers; any pointer may be NULL).  c_nk is row-major [(site_hi-site_lo) x k]. */
+int nemgpu_get_partition(nemgpu_engine* e, float* c_nk);
+int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels);
+int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k);
+int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk);
+/* Kernel timing probe for bench.py: average duration (ms) of the E1 density kernel over the
+   launches since the last call, measured with hipEvents on the engine's stream. */
+int nemgpu_profile_enable(nemgpu_engine* e, int on);
+int nemgpu_profile_read(nemgpu_engine* e, double* density_ms_avg, int* density_launches,
+                        double* algorithmic_bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEM_MI355X_H */

@@ -1,0 +1,246 @@
+// nem_capi.cpp -- the drop-in `nem()` entry point (reference: nem_exe.h:23-35, nem_exe.c:239-704).
+//
+// Same symbol, argument list, file formats and return codes as the reference's only FFI entry;
+// the EM loop runs on the GPU through the nemgpu_* engine.  Text written to <Fname>.stderr keeps
+// the reference's wording where a caller could plausibly grep it.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "nem_internal.hpp"
+
+using namespace nemk;
+
+namespace {
+
+// ExitET, lib_io.h:22-34
+enum { EXIT_OK_ = 0, EXIT_W_RESULT_ = 1, EXIT_E_ARGS_ = 2, EXIT_E_FILE_ = 3, EXIT_E_MEMORY_ = 4, EXIT_E_SYSTEM_ = 5, EXIT_E_BUG_ = 6 };
+
+const char* kVersion = "1.08-a";   // NemVersionStrC, nem_exe.c:233 (banner compatibility)
+
+int get_enum(const char* s, const char* const* tab, int n)   // GetEnum, nem_exe.c:1784-1809
+{
+    if (!s) return -1;
+    for (int i = 0; i < n; i++) if (!strcmp(s, tab[i])) return i;
+    return -1;
+}
+
+struct Log {
+    FILE* fp = nullptr;
+    bool owned = false;
+    void open(const std::string& base, int dolog)
+    {
+        if (dolog) {
+            std::string name = std::string(base).substr(0, 200) + ".stderr";   // LEN_FILENAME, nem_typ.h:50
+            fp = fopen(name.c_str(), "w");
+            owned = fp != nullptr;
+        }
+        if (!fp) { fp = stderr; owned = false; }
+    }
+    void close() { if (owned && fp) fclose(fp); fp = nullptr; }   // the reference also fclose()s stderr; we do not
+    void pr(const char* fmt, ...)
+    {
+        va_list ap; va_start(ap, fmt); vfprintf(fp, fmt, ap); va_end(ap);
+    }
+};
+
+}  // namespace
+
+extern "C" int nem(const char* Fname, const int nk, const char* algo, const float beta, const char* convergence,
+                   const float convergence_th, const char* format, const int it_max, const int dolog,
+                   const char* model_family, const char* proportion, const char* dispersion, const int init_mode)
+{
+    static const char* const AlgoStr[] = {"nem", "ncem", "gem"};            // nem_typ.h:556
+    static const char* const CvStr[] = {"none", "clas", "crit"};            // :560
+    static const char* const FormatStr[] = {"hard", "fuzzy"};               // :561
+    static const char* const FamilyStr[] = {"norm", "lapl", "bern"};        // :575
+    static const char* const DisperStr[] = {"s__", "sk_", "s_d", "skd"};    // :576
+    static const char* const ProporStr[] = {"p_", "pk"};                    // :577
+    static const char* const AlgoDes[] = {"NEM", "NCEM (C-step)", "GEM (Monte-Carlo at E-step)"};
+    static const char* const DisperDes[] = {"S__", "SK_", "S_D", "S_KD"};
+    static const char* const ProporDes[] = {"P_", "Pk"};
+
+    if (!Fname) return EXIT_E_ARGS_;
+    const std::string base = std::string(Fname).substr(0, 200);             // strncpy(..., LEN_FILENAME)
+    Log lg;
+    lg.open(base, dolog);
+    lg.pr(" * * * NEM (spatial data clustering) v%s * * *\n", kVersion);
+    lg.pr(" * * * MI355X-native engine (HIP, gfx950) behind the reference nem() interface * * *\n");
+
+    if (nk <= 0) {                                                          // nem_exe.c:297-302
+        lg.pr("Nb of classes must be > 0 (here %d)\n", nk);
+        lg.close();
+        return NEMGPU_E_ARG;
+    }
+    if (nk > kMaxK) {
+        lg.pr("Nb of classes must be <= %d in this engine (here %d)\n", kMaxK, nk);
+        lg.close();
+        return EXIT_E_ARGS_;
+    }
+
+    NemInputs in;
+    std::string err;
+    int sts;
+    if ((sts = read_str_file(base, in, err)) != NEMGPU_OK) {                // :304-309 (raw StatusET returned)
+        fprintf(stderr, "%s\n", err.c_str());
+        lg.close();
+        return sts;
+    }
+
+    // ---- argument decoding, nem_exe.c:371-435.  The reference records bad strings in `err` and then
+    // overwrites it (:472), so most of them are not fatal there; the same fall-backs apply here.
+    nemgpu_config cfg{};
+    int a = get_enum(algo, AlgoStr, 3);
+    if (a == -1) lg.pr(" Unknown type of algorithm %s\n", algo ? algo : "(null)");
+    if (a == 2) {
+        lg.pr(" Algorithm gem (Monte-Carlo E-step) is not supported by this engine\n");
+        lg.pr("*** NEM error status : bad arguments\n");
+        lg.close();
+        return EXIT_E_ARGS_;
+    }
+    cfg.algo = (a == 1) ? NEMGPU_ALGO_NCEM : NEMGPU_ALGO_NEM;               // Algo == -1 behaves like NEM
+    cfg.beta = beta;
+    int cv = get_enum(convergence, CvStr, 3);
+    cfg.cvtest = NEMGPU_CV_NONE;
+    cfg.cvthres = 1.0f;
+    if (cv == -1) lg.pr(" Unknown convergence test %s\n", convergence ? convergence : "(null)");
+    else if (cv == 2) {
+        lg.pr(" Convergence test crit is not supported by this engine (use clas or none)\n");
+        lg.pr("*** NEM error status : bad arguments\n");
+        lg.close();
+        return EXIT_E_ARGS_;
+    } else if (cv == 1) {
+        if (convergence_th <= 0) lg.pr(" Conv threshold must be > 0 (here %f)\n", convergence_th);   // never satisfied
+        else { cfg.cvtest = NEMGPU_CV_CLAS; cfg.cvthres = convergence_th; }
+    }
+    int fm = get_enum(format, FormatStr, 2);
+    if (fm == -1) lg.pr(" Unknown format %s\n", format ? format : "(null)");
+    const bool hard = (fm == 0);
+    cfg.it_max = it_max;
+    if (it_max < 0) { lg.pr("Nb iterations must be >= 0 (here %d)\n", it_max); cfg.it_max = 0; }
+    int fam = get_enum(model_family, FamilyStr, 3);
+    if (fam != 2) {
+        lg.pr(fam == -1 ? " Unknown family %s\n" : " Family %s is not supported by this engine (only bern)\n",
+              model_family ? model_family : "(null)");
+        lg.pr("*** NEM error status : bad arguments\n");
+        lg.close();
+        return EXIT_E_ARGS_;
+    }
+    int pr = get_enum(proportion, ProporStr, 2);
+    if (pr == -1) lg.pr(" Unknown proportion %s\n", proportion ? proportion : "(null)");
+    cfg.propor = (pr == 1) ? NEMGPU_PROP_K : NEMGPU_PROP__;                 // only PROPOR_K re-estimates (nem_mod.c:456)
+    int dp = get_enum(dispersion, DisperStr, 4);
+    if (dp == -1) lg.pr(" Unknown dispersion %s\n", dispersion ? dispersion : "(null)");
+    cfg.disper = dp;
+    cfg.tie_rule = NEMGPU_TIE_HASH;
+    cfg.tie_seed = (uint32_t)time(nullptr);                                 // NemPara.Seed = time(NULL), :353
+    if (const char* s = getenv("NEM_MI355X_SEED")) cfg.tie_seed = (uint32_t)strtoul(s, nullptr, 10);
+
+    const std::string outname = base + (hard ? ".cf" : ".uf");              // :437-440
+
+    // ---- inputs, nem_exe.c:469-574
+    lg.pr("Reading points ...\n");
+    if ((sts = read_dat_file(base, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
+    if (init_mode != 2) {                                                   // INIT_PARAM_FILE, nem_typ.h:218
+        lg.pr("Initialization mode %d is not supported by this engine (only 2 = parameter file)\n", init_mode);
+        lg.pr("*** NEM error status : bad arguments\n");
+        lg.close();
+        return EXIT_E_ARGS_;
+    }
+    lg.pr("Reading parameter file ...\n");
+    if ((sts = read_param_file(base, nk, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
+    cfg.param_fix = (in.param_mode == 2);
+    if (in.type != 'N') {
+        lg.pr("Reading neighborhood information ...\n");
+        if ((sts = read_nei_file(base, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
+    } else {
+        cfg.beta = 0.0f;                                                    // :572
+        in.nei_ptr.assign(in.n + 1, 0);
+    }
+
+    lg.pr("\nData : ");
+    if (!in.str_comment.empty()) lg.pr("%s\n", in.str_comment.c_str()); else lg.pr("\n");
+    lg.pr("  file names =  %10s   |   nb points   = %10d\n", Fname, in.n);
+    lg.pr("  type       =  %10s   |   dim         = %10d\n", in.type == 'N' ? "NoSpatial" : "Spatial", in.d);
+    if (in.type != 'N') {
+        lg.pr("Neighborhood system :\n  max neighb =  %10d\n", in.max_neighs);
+        lg.pr("%s\n", in.nei_comment.c_str());
+    }
+    lg.pr("\nNEM parameters :\n");
+    lg.pr("Type of algorithm : '%s'\n", AlgoDes[cfg.algo]);
+    lg.pr("  beta       =  %10.2f   |   nk                    = %3d\n", cfg.beta, nk);
+    lg.pr("                %10s   |   model                 = %s, %s %s\n", " ", "Bernoulli",
+          ProporDes[pr == 1 ? 1 : 0], dp >= 0 ? DisperDes[dp] : "?");
+    lg.pr("\n");
+
+    if (dp == -1) {                                                         // InerToDisp default -> STS_E_FUNCARG
+        lg.pr("*** NEM internal error : bad arguments\n");
+        lg.close();
+        return EXIT_E_BUG_;
+    }
+
+    // ---- the EM run on the GPU (ClassifyByNem, :624)
+    nemgpu_engine* e = nullptr;
+    nemgpu_result res{};
+    int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, 0, nullptr);
+    if (rc == NEMGPU_OK) rc = nemgpu_set_matrix_bits(e, in.xbits.data());
+    if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
+    if (rc == NEMGPU_OK) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
+    if (rc == NEMGPU_OK) rc = nemgpu_configure(e, &cfg);
+    if (rc == NEMGPU_OK) {
+        lg.pr("Initializing parameters from given value\n");
+        rc = nemgpu_run(e, &res);
+    }
+    if (rc != NEMGPU_OK) {
+        lg.pr("*** NEM GPU engine error : %s\n", nemgpu_last_error());
+        fprintf(stderr, "nem (MI355X engine): %s\n", nemgpu_last_error());
+        if (e) nemgpu_destroy(e);
+        lg.close();
+        return rc == NEMGPU_E_ARG ? EXIT_E_ARGS_ : (rc == NEMGPU_E_MEMORY ? EXIT_E_MEMORY_ : EXIT_E_SYSTEM_);
+    }
+
+    lg.pr("  Iterations : %4d \n", res.iters);
+    if (res.zero_density_sites > 0) lg.pr("Warning : pt %d density = 0\n", res.first_zero_density_site);
+    if (res.status == NEMGPU_W_EMPTYCLASS) lg.pr("Class %d empty at iteration %d\n", res.emptyk, res.iters);
+    lg.pr("  criterion NEM = %6.3f / Ps-Like = %6.3f / Lmix = %6.3f\n", res.crit[2], res.crit[3], res.crit[4]);
+    if (cfg.cvtest != NEMGPU_CV_NONE && res.status == NEMGPU_OK) {          // nem_alg.c:1863-1875
+        if (res.converged) lg.pr("  NEM converged after %d iterations\n", res.iters);
+        else lg.pr("  NEM did not converge after %d iterations\n", res.iters);
+    }
+    lg.pr("  [engine] EM loop %.6f s, %d sweep relaxation rounds\n", res.loop_seconds, res.sweep_rounds);
+
+    int ret = EXIT_OK_;
+    if (res.status == NEMGPU_OK) {
+        lg.pr("Saving results ...\n");                                      // nem_exe.c:628-630
+        std::vector<float> c((size_t)in.n * nk), prop(nk), center((size_t)nk * in.d), disp((size_t)nk * in.d);
+        nemgpu_get_partition(e, c.data());
+        nemgpu_get_params(e, prop.data(), center.data(), disp.data(), nullptr);
+        int w1 = hard ? write_cf_file(outname, c.data(), in.n, nk, cfg.tie_rule, cfg.tie_seed)
+                      : write_uf_file(outname, c.data(), in.n, nk);
+        int w2 = write_mf_file(base + ".mf", res.crit, cfg.beta, in.d, nk, center.data(), prop.data(), disp.data());
+        if (w1 != NEMGPU_OK) fprintf(stderr, "Could not open file '%s' in write mode\n", outname.c_str());
+        if (w2 != NEMGPU_OK) fprintf(stderr, "Could not open file '%s.mf' in write mode\n", base.c_str());
+        if (dolog) {                                                        // minimal <Fname>.log (never parsed by PPanGGOLiN)
+            FILE* fl = fopen((base + ".log").c_str(), "w");
+            if (fl) {
+                time_t t = time(nullptr);
+                fprintf(fl, "NEM log file  -  %s\n", asctime(localtime(&t)));
+                fprintf(fl, "  MI355X engine: per-iteration criteria are not logged; iterations = %d\n", res.iters);
+                fclose(fl);
+            }
+        }
+        lg.pr("NEM completed, classification in %s\n", outname.c_str());    // :642-645
+        lg.pr(" criteria and parameters in %s%s\n", base.c_str(), ".mf");
+        if (dolog) lg.pr("Log of detailed running in %s.log\n", base.c_str());
+    } else {
+        lg.pr("*** NEM warning status : empty class\n");                    // :660-663
+        ret = EXIT_W_RESULT_;
+    }
+    nemgpu_destroy(e);
+    lg.close();
+    return ret;
+}

@@ -1,0 +1,752 @@
+// nem_engine.hip -- the in-memory NEM engine: device buffers, the EM driver and the nemgpu_* C ABI.
+//
+// Mirrors the reference's in-memory path ClassifyByNem -> ClassifyByNemOneBeta(INIT_PARAM_FILE)
+// -> NemAlgo (/root/reference/ppanggolin/NEM/nem_alg.c:546-584, 1151-1169, 1746-1879) with all
+// numeric work in the kernels of nem_kernels.hip.  There is no CPU compute path here: every
+// entry point returns NEMGPU_E_DEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nem_internal.hpp"
+#include "nem_kernels.hpp"
+
+using namespace nemk;
+
+namespace nemk {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace nemk
+
+#define HIPCHK(call)                                                                            \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess) {                                                              \
+            set_error(std::string(#call) + " failed: " + hipGetErrorString(err__));             \
+            return NEMGPU_E_DEVICE;                                                             \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+constexpr int kRoundCap = 64;     // relaxation rounds per flag window
+constexpr int kRoundBatch = 3;    // rounds enqueued between host checks
+}  // namespace
+
+struct nemgpu_engine {
+    int n_total = 0, d = 0, k = 0, lo = 0, hi = 0, n = 0;
+    int npad = 0, dpad = 0, W = 0, wf = 0, nw64 = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    nemgpu_config cfg{};
+    bool have_matrix = false, have_params = false, has_graph = false;
+
+    uint32_t* xw = nullptr;
+    uint64_t* xt = nullptr;
+    int *nei_ptr = nullptr, *nei_idx = nullptr;
+    float* nei_w = nullptr;
+    int nnz = 0;
+
+    float *prop = nullptr, *center = nullptr, *disp = nullptr;
+    float *prop0 = nullptr, *center0 = nullptr, *disp0 = nullptr;
+    float *nbobs_k = nullptr, *iner = nullptr;
+    float *fz_s0 = nullptr, *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
+    double2* tabT = nullptr;
+    double* tabL0 = nullptr;
+    uint32_t *nz0 = nullptr, *nz1 = nullptr;
+    double* pk = nullptr;
+    float* logpk = nullptr;
+    double* pkfki = nullptr;
+    float* logpkfki = nullptr;
+
+    uint8_t* lab[3] = {nullptr, nullptr, nullptr};   // NCEM partitions (labels), n_total each
+    float* cbuf[3] = {nullptr, nullptr, nullptr};    // fuzzy partitions, n_total*k each
+    int cur = 0;
+    uint64_t* mask = nullptr;
+    int* stats = nullptr;
+    int* flags_dev = nullptr;                         // [FLAG_ITER_STRIDE] + kRoundCap * FLAG_ROUND_STRIDE
+    int* flags_host = nullptr;                        // pinned mirror
+
+    float* c_onehot = nullptr;                        // lazily allocated (criteria / NCEM)
+    float *crit_dik = nullptr, *crit_gik = nullptr, *crit6_dev = nullptr;
+    double *crit_lfi = nullptr, *crit_lzi = nullptr;
+
+    // run state
+    uint32_t sweep_counter = 0;
+    int iters = 0, converged = 0, emptyk = 0, status = NEMGPU_OK;
+    int zero_density = 0, first_zero = -1, sweep_rounds = 0;
+    bool masks_valid = false;
+
+    // profiling of the E1 kernel
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+
+    bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
+    int* iter_flags() const { return flags_dev; }
+    int* round_flags(int r) const { return flags_dev + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
+    size_t flag_words() const { return FLAG_ITER_STRIDE + (size_t)kRoundCap * FLAG_ROUND_STRIDE; }
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+    return NEMGPU_OK;
+}
+
+int ensure_state_buffers(nemgpu_engine* e)
+{
+    if (e->ncem()) {
+        for (int b = 0; b < 3; b++)
+            if (!e->lab[b]) { int r = dev_alloc(&e->lab[b], (size_t)e->n_total); if (r) return r; }
+    } else {
+        for (int b = 0; b < 3; b++)
+            if (!e->cbuf[b]) { int r = dev_alloc(&e->cbuf[b], (size_t)e->n_total * e->k); if (r) return r; }
+        if (!e->fz_s0) {
+            size_t kd = (size_t)e->k * e->d;
+            int r;
+            if ((r = dev_alloc(&e->fz_s0, kd))) return r;
+            if ((r = dev_alloc(&e->fz_in0, kd))) return r;
+            if ((r = dev_alloc(&e->fz_in1, kd))) return r;
+            if ((r = dev_alloc(&e->fz_inh, kd))) return r;
+        }
+    }
+    return NEMGPU_OK;
+}
+
+int do_tables(nemgpu_engine* e)
+{
+    launch_tables(e->k, e->d, e->dpad, e->prop, e->center, e->disp, e->tabT, e->tabL0, e->nz0, e->nz1, e->pk,
+                  e->logpk, e->iter_flags(), e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+int do_density(nemgpu_engine* e)
+{
+    if (e->prof) {
+        if ((int)e->ev.size() < e->ev_used + 2) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            e->ev.push_back(a); e->ev.push_back(b);
+        }
+        HIPCHK(hipEventRecord(e->ev[e->ev_used], e->stream));
+    }
+    launch_density(e->xw, e->n, e->npad, e->dpad, e->k, e->tabT, e->tabL0, e->nz0, e->nz1, e->pk, e->logpk, e->pkfki,
+                   e->logpkfki, e->stream);
+    HIPCHK(hipGetLastError());
+    if (e->prof) {
+        HIPCHK(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
+        e->ev_used += 2;
+    }
+    return NEMGPU_OK;
+}
+
+// One full Gauss-Seidel sweep == relaxation rounds until a round changes nothing.
+// On return the new partition is in buffer (cur+1)%3 and `cur` is NOT advanced (the caller commits).
+int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
+{
+    const bool ncem = e->ncem();
+    const int P = e->cur, Q = (e->cur + 1) % 3, R = (e->cur + 2) % 3;
+    const bool use_nei = e->has_graph && beta != 0.0f;
+    SweepArgs a{};
+    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
+    a.use_nei = use_nei ? 1 : 0;
+    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
+    a.beta = beta;
+    a.pkfki = e->pkfki;
+    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = e->sweep_counter++;
+
+    int r = 0, done_at = -1;
+    while (done_at < 0) {
+        const int r0 = r;
+        const int batch = use_nei ? kRoundBatch : 1;
+        // a window of flag slots is reused every kRoundCap rounds; clear the slots of this batch
+        for (int b = 0; b < batch; b++)
+            HIPCHK(hipMemsetAsync(e->round_flags(r0 + b), 0, FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+        for (int b = 0; b < batch; b++, r++) {
+            const int gb = (r == 0) ? P : ((r - 1) % 2 == 0 ? Q : R);
+            const int ob = (r % 2 == 0) ? Q : R;
+            if (ncem) { a.lab_old = e->lab[P]; a.lab_guess = e->lab[gb]; a.lab_out = e->lab[ob]; }
+            else { a.c_old = e->cbuf[P]; a.c_guess = e->cbuf[gb]; a.c_out = e->cbuf[ob]; }
+            a.flags = e->round_flags(r);
+            a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
+            launch_sweep(a, ncem, e->stream);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
+                              e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (!use_nei) { done_at = 0; break; }
+        for (int q = r0; q < r; q++) {
+            const int* f = e->flags_host + FLAG_ITER_STRIDE + (q % kRoundCap) * FLAG_ROUND_STRIDE;
+            if (f[FLAG_CHANGED] == 0) { done_at = q; break; }
+        }
+    }
+    // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
+    const int* f = e->flags_host + FLAG_ITER_STRIDE + (done_at % kRoundCap) * FLAG_ROUND_STRIDE;
+    if (f[FLAG_NZERO] > 0) {
+        e->zero_density += f[FLAG_NZERO];
+        if (e->first_zero < 0) e->first_zero = e->n_total - f[FLAG_FIRSTZERO];
+    }
+    // result: out buffer of round done_at; when done_at is odd (R) it equals Q bit for bit (see k_sweep)
+    e->sweep_rounds += done_at + 1;
+    if (rounds_out) *rounds_out = done_at + 1;
+    return NEMGPU_OK;
+}
+
+int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf)
+{
+    launch_labels_post(e->n, e->lo, e->k, e->nw64, e->lab[newbuf], oldbuf >= 0 ? e->lab[oldbuf] : nullptr, e->mask,
+                       e->iter_flags(), e->stream);
+    HIPCHK(hipGetLastError());
+    e->masks_valid = true;
+    return NEMGPU_OK;
+}
+
+// EstimPara (nem_mod.c:415-469) on the current partition; leaves FLAG_EMPTYK in the iteration flags.
+int do_mstep(nemgpu_engine* e)
+{
+    if (e->ncem()) {
+        if (!e->masks_valid) { int r = do_labels_post(e, e->cur, -1); if (r) return r; }
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stream);
+        launch_mstep_centers_ncem(e->k, e->d, e->stats, e->center, e->nbobs_k, e->iner, e->stream);
+    } else {
+        launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
+                           e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->center, e->iner, e->stream);
+    }
+    launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
+                      e->iter_flags(), e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+int read_iter_flags(nemgpu_engine* e)
+{
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, FLAG_ITER_STRIDE * sizeof(int), hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return NEMGPU_OK;
+}
+
+int clear_iter_flags(nemgpu_engine* e)
+{
+    HIPCHK(hipMemsetAsync(e->flags_dev, 0, FLAG_ITER_STRIDE * sizeof(int), e->stream));
+    return NEMGPU_OK;
+}
+
+// ComputePartitionFromPara(Needinit = 1), nem_alg.c:1967-1981
+int init_partition(nemgpu_engine* e)
+{
+    int r;
+    if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
+    if ((r = ensure_state_buffers(e))) return r;
+    if ((r = clear_iter_flags(e))) return r;
+    if ((r = do_tables(e))) return r;
+    if ((r = do_density(e))) return r;
+    // ClassifM starts as zeros (calloc, nem_exe.c:524-526): the blind beta = 0 sweep never reads it
+    if ((r = do_sweep(e, 0.0f, nullptr))) return r;
+    e->cur = (e->cur + 1) % 3;
+    if ((r = do_sweep(e, e->cfg.beta, nullptr))) return r;
+    e->cur = (e->cur + 1) % 3;
+    e->masks_valid = false;
+    if (e->ncem()) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+    return NEMGPU_OK;
+}
+
+// NemAlgo's loop body (nem_alg.c:1789-1840), up to n_iters iterations
+int iterate(nemgpu_engine* e, int n_iters)
+{
+    int r;
+    for (int it = 0; it < n_iters && !e->converged && e->status == NEMGPU_OK; it++) {
+        if ((r = clear_iter_flags(e))) return r;
+        if (!e->cfg.param_fix) {                                   // nem_alg.c:1806
+            if ((r = do_mstep(e))) return r;
+            if ((r = do_tables(e))) return r;
+        }
+        if ((r = do_density(e))) return r;
+        int rounds = 0;
+        if ((r = do_sweep(e, e->cfg.beta, &rounds))) return r;     // syncs; iteration flags are in flags_host
+        e->iters++;
+        const int ek = e->flags_host[FLAG_EMPTYK];
+        if (!e->cfg.param_fix && ek != 0) {                        // nem_alg.c:1831-1838: E-step not run
+            e->status = NEMGPU_W_EMPTYCLASS;
+            e->emptyk = ek;
+            break;                                                 // partition stays at buffer `cur`
+        }
+        const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
+        if (e->ncem()) {
+            if ((r = do_labels_post(e, newbuf, oldbuf))) return r;
+        } else if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
+            launch_conv_fuzzy((size_t)e->n * e->k, e->cbuf[newbuf] + (size_t)e->lo * e->k,
+                              e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stream);
+        }
+        e->cur = newbuf;
+        if (e->cfg.cvtest == NEMGPU_CV_CLAS) {                     // HasConverged, nem_alg.c:2075-2089
+            if ((r = read_iter_flags(e))) return r;
+            const int moved = e->flags_host[FLAG_MOVED];
+            if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
+            else e->converged = !moved;
+        }
+    }
+    return NEMGPU_OK;
+}
+
+int ensure_crit_buffers(nemgpu_engine* e)
+{
+    int r;
+    size_t nk = (size_t)e->n * e->k;
+    if (!e->crit_dik) {
+        if ((r = dev_alloc(&e->crit_dik, nk))) return r;
+        if ((r = dev_alloc(&e->crit_gik, nk))) return r;
+        if ((r = dev_alloc(&e->crit_lfi, (size_t)e->n))) return r;
+        if ((r = dev_alloc(&e->crit_lzi, (size_t)e->n))) return r;
+        if ((r = dev_alloc(&e->crit6_dev, 8))) return r;
+    }
+    if (e->ncem() && !e->c_onehot) { if ((r = dev_alloc(&e->c_onehot, (size_t)e->n_total * e->k))) return r; }
+    return NEMGPU_OK;
+}
+
+const float* float_partition(nemgpu_engine* e)
+{
+    if (!e->ncem()) return e->cbuf[e->cur];
+    launch_onehot(e->n_total, e->k, e->lab[e->cur], e->c_onehot, e->stream);
+    return e->c_onehot;
+}
+
+int criteria(nemgpu_engine* e, float crit6[6])
+{
+    int r;
+    if (e->lo != 0 || e->hi != e->n_total) { set_error("criteria need the whole partition on one engine"); return NEMGPU_E_FUNCARG; }
+    if ((r = ensure_crit_buffers(e))) return r;
+    const float* c = float_partition(e);
+    launch_criteria(e->n, e->k, e->npad, e->nei_ptr, e->nei_idx, e->nei_w, e->has_graph ? 1 : 0, e->cfg.beta, c,
+                    e->pkfki, e->logpkfki, e->crit_dik, e->crit_gik, e->crit_lfi, e->crit_lzi, e->crit6_dev,
+                    e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(crit6, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return NEMGPU_OK;
+}
+
+int reset_state(nemgpu_engine* e)
+{
+    if (e->have_params) {
+        HIPCHK(hipMemcpyAsync(e->prop, e->prop0, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->center, e->center0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->disp, e->disp0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
+    e->cur = 0; e->sweep_counter = 0;
+    e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
+    e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
+    return NEMGPU_OK;
+}
+
+void fill_result(nemgpu_engine* e, nemgpu_result* res)
+{
+    if (!res) return;
+    res->status = e->status; res->iters = e->iters; res->converged = e->converged; res->emptyk = e->emptyk;
+    res->zero_density_sites = e->zero_density; res->first_zero_density_site = e->first_zero;
+    res->sweep_rounds = e->sweep_rounds;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char* nemgpu_last_error(void) { return g_last_error.c_str(); }
+
+int nemgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, int site_hi, int device,
+                  void* hip_stream)
+{
+    if (!out) return NEMGPU_E_FUNCARG;
+    *out = nullptr;
+    if (n_total <= 0 || d <= 0 || k <= 0 || k > kMaxKernelK || site_lo < 0 || site_hi > n_total || site_lo >= site_hi) {
+        set_error("nemgpu_create: bad sizes (need n,d > 0, 1 <= k <= 32, 0 <= lo < hi <= n)");
+        return NEMGPU_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no usable HIP device: this library has no CPU fallback");
+        return NEMGPU_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("nemgpu_create: bad device index"); return NEMGPU_E_ARG; }
+    HIPCHK(hipSetDevice(device));
+    nemgpu_engine* e = new nemgpu_engine();
+    e->n_total = n_total; e->d = d; e->k = k; e->lo = site_lo; e->hi = site_hi; e->n = site_hi - site_lo;
+    e->device = device;
+    e->npad = (e->n + 255) / 256 * 256;
+    e->dpad = (d + 63) / 64 * 64;
+    e->W = e->dpad / 32;
+    e->wf = (d + 31) / 32;
+    e->nw64 = (e->n + 63) / 64;
+    e->cfg.algo = NEMGPU_ALGO_NCEM; e->cfg.beta = 0.5f; e->cfg.disper = NEMGPU_DISP_K_; e->cfg.propor = NEMGPU_PROP_K;
+    e->cfg.cvtest = NEMGPU_CV_CLAS; e->cfg.cvthres = 1e-8f; e->cfg.it_max = 100; e->cfg.param_fix = 0;
+    e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
+    if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
+    else {
+        if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+        e->own_stream = true;
+    }
+    int r = NEMGPU_OK;
+    const size_t kd = (size_t)k * d, kdp = (size_t)k * e->dpad;
+    auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
+    A(dev_alloc(&e->xw, (size_t)e->W * e->npad));
+    A(dev_alloc(&e->xt, (size_t)d * e->nw64));
+    A(dev_alloc(&e->prop, (size_t)k)); A(dev_alloc(&e->center, kd)); A(dev_alloc(&e->disp, kd));
+    A(dev_alloc(&e->prop0, (size_t)k)); A(dev_alloc(&e->center0, kd)); A(dev_alloc(&e->disp0, kd));
+    A(dev_alloc(&e->nbobs_k, (size_t)k)); A(dev_alloc(&e->iner, kd));
+    A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
+    A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
+    A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
+    A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
+    A(dev_alloc(&e->mask, (size_t)k * e->nw64));
+    A(dev_alloc(&e->stats, (size_t)k + kd));
+    A(dev_alloc(&e->flags_dev, e->flag_words()));
+    if (r == NEMGPU_OK && hipHostMalloc((void**)&e->flags_host, e->flag_words() * sizeof(int)) != hipSuccess) {
+        set_error("hipHostMalloc failed"); r = NEMGPU_E_DEVICE;
+    }
+    if (r != NEMGPU_OK) { nemgpu_destroy(e); return r; }
+    *out = e;
+    return NEMGPU_OK;
+}
+
+void nemgpu_destroy(nemgpu_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* ptrs[] = {e->xw, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
+                    e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
+                    e->nz1, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
+                    e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
+                    e->crit6_dev, e->crit_lfi, e->crit_lzi};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (e->flags_host) (void)hipHostFree(e->flags_host);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
+{
+    if (!e || !xbits_host) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    uint32_t* xf = nullptr;
+    const size_t words = (size_t)e->n * e->wf;
+    HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
+    hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) {
+        launch_layout(xf, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->stream);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(xf);
+    if (err != hipSuccess) { set_error(std::string("matrix upload failed: ") + hipGetErrorString(err)); return NEMGPU_E_DEVICE; }
+    e->have_matrix = true;
+    return NEMGPU_OK;
+}
+
+int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
+{
+    if (!e || !x_host) return NEMGPU_E_FUNCARG;
+    std::vector<uint32_t> bits((size_t)e->n * e->wf, 0u);
+    for (int i = 0; i < e->n; i++) {
+        const uint8_t* row = x_host + (size_t)i * e->d;
+        uint32_t* out = bits.data() + (size_t)i * e->wf;
+        for (int j = 0; j < e->d; j++) {
+            if (row[j] > 1) { set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
+            out[j >> 5] |= (uint32_t)row[j] << (j & 31);
+        }
+    }
+    return nemgpu_set_matrix_bits(e, bits.data());
+}
+
+int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, const float* w)
+{
+    if (!e || !ptr) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    const int nnz = ptr[e->n] - ptr[0];
+    if (ptr[0] != 0 || nnz < 0) { set_error("graph: ptr[0] must be 0 and ptr non-decreasing"); return NEMGPU_E_ARG; }
+    for (int i = 0; i < e->n; i++) if (ptr[i + 1] < ptr[i]) { set_error("graph: ptr not monotone"); return NEMGPU_E_ARG; }
+    for (int t = 0; t < nnz; t++)
+        if (idx[t] < 0 || idx[t] >= e->n_total) { set_error("graph: neighbour index out of range"); return NEMGPU_E_ARG; }
+    if (e->nei_ptr) { (void)hipFree(e->nei_ptr); (void)hipFree(e->nei_idx); (void)hipFree(e->nei_w); e->nei_ptr = nullptr; e->nei_idx = nullptr; e->nei_w = nullptr; }
+    int r;
+    if ((r = dev_alloc(&e->nei_ptr, (size_t)e->n + 1))) return r;
+    if ((r = dev_alloc(&e->nei_idx, (size_t)nnz))) return r;
+    if ((r = dev_alloc(&e->nei_w, (size_t)nnz))) return r;
+    HIPCHK(hipMemcpy(e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpy(e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    e->nnz = nnz;
+    e->has_graph = nnz > 0;
+    return NEMGPU_OK;
+}
+
+int nemgpu_set_params(nemgpu_engine* e, const float* prop, const float* center, const float* disp)
+{
+    if (!e || !prop || !center || !disp) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t kd = (size_t)e->k * e->d;
+    HIPCHK(hipMemcpy(e->prop0, prop, sizeof(float) * e->k, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+    e->have_params = true;
+    return reset_state(e);
+}
+
+int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
+{
+    if (!e || !cfg) return NEMGPU_E_FUNCARG;
+    if (cfg->algo != NEMGPU_ALGO_NEM && cfg->algo != NEMGPU_ALGO_NCEM) { set_error("algo must be nem or ncem"); return NEMGPU_E_ARG; }
+    if (cfg->disper < 0 || cfg->disper > 3 || cfg->propor < 0 || cfg->propor > 1) { set_error("bad dispersion/proportion model"); return NEMGPU_E_ARG; }
+    if (cfg->cvtest != NEMGPU_CV_NONE && cfg->cvtest != NEMGPU_CV_CLAS) { set_error("convergence must be none or clas"); return NEMGPU_E_ARG; }
+    if (cfg->cvtest == NEMGPU_CV_CLAS && !(cfg->cvthres > 0)) { set_error("convergence threshold must be > 0"); return NEMGPU_E_ARG; }
+    if (cfg->it_max < 0) { set_error("it_max must be >= 0"); return NEMGPU_E_ARG; }
+    if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
+    e->cfg = *cfg;
+    HIPCHK(hipSetDevice(e->device));
+    return reset_state(e);
+}
+
+int nemgpu_reset(nemgpu_engine* e)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    return reset_state(e);
+}
+
+int nemgpu_init_partition(nemgpu_engine* e)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    return init_partition(e);
+}
+
+int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    int r = iterate(e, n_iters);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fill_result(e, res);
+    if (res) res->loop_seconds = secs;
+    return NEMGPU_OK;
+}
+
+int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = reset_state(e))) return r;
+    if ((r = init_partition(e))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    if ((r = iterate(e, e->cfg.it_max))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (e->iters == 0) {                                           // nem_alg.c:1845-1851
+        if ((r = clear_iter_flags(e))) return r;
+        if ((r = do_mstep(e))) return r;
+        if ((r = do_tables(e))) return r;
+        if ((r = do_density(e))) return r;
+    }
+    fill_result(e, res);
+    if (res) {
+        res->loop_seconds = secs;
+        if ((r = criteria(e, res->crit))) return r;                // nem_alg.c:1852
+    }
+    return NEMGPU_OK;
+}
+
+int nemgpu_density(nemgpu_engine* e)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = clear_iter_flags(e))) return r;
+    if ((r = do_tables(e))) return r;
+    if ((r = do_density(e))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return NEMGPU_OK;
+}
+
+int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    if ((r = do_sweep(e, beta, rounds))) return r;
+    e->cur = (e->cur + 1) % 3;
+    e->masks_valid = false;
+    return NEMGPU_OK;
+}
+
+int nemgpu_mstep(nemgpu_engine* e, int* emptyk)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    if ((r = clear_iter_flags(e))) return r;
+    if ((r = do_mstep(e))) return r;
+    if ((r = read_iter_flags(e))) return r;
+    if (emptyk) *emptyk = e->flags_host[FLAG_EMPTYK];
+    return e->flags_host[FLAG_EMPTYK] ? NEMGPU_W_EMPTYCLASS : NEMGPU_OK;
+}
+
+int nemgpu_criteria(nemgpu_engine* e, float crit6[6])
+{
+    if (!e || !crit6) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    return criteria(e, crit6);
+}
+
+int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)
+{
+    // test hook: load a partition (row-major [n_total x k], HOST) as the current state
+    if (!e || !c_nk) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    if (e->ncem()) {
+        std::vector<uint8_t> lab((size_t)e->n_total);
+        for (int i = 0; i < e->n_total; i++) {
+            int best = 0;
+            for (int k = 1; k < e->k; k++) if (c_nk[(size_t)i * e->k + k] > c_nk[(size_t)i * e->k + best]) best = k;
+            lab[i] = (uint8_t)best;
+        }
+        HIPCHK(hipMemcpy(e->lab[e->cur], lab.data(), lab.size(), hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(e->cbuf[e->cur], c_nk, sizeof(float) * (size_t)e->n_total * e->k, hipMemcpyHostToDevice));
+    }
+    e->masks_valid = false;
+    return NEMGPU_OK;
+}
+
+int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels)
+{
+    if (!e || !labels) return NEMGPU_E_FUNCARG;
+    if (!e->ncem() || !e->lab[e->cur]) { set_error("labels exist only for ncem runs"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(labels, e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
+    return NEMGPU_OK;
+}
+
+int nemgpu_get_partition(nemgpu_engine* e, float* c_nk)
+{
+    if (!e || !c_nk) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->ncem()) {
+        if (!e->lab[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
+        std::vector<uint8_t> lab((size_t)e->n);
+        HIPCHK(hipMemcpy(lab.data(), e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < e->n; i++)                             // LabelToClassVector, nem_alg.c:649-664
+            for (int k = 0; k < e->k; k++) c_nk[(size_t)i * e->k + k] = (lab[i] == k) ? 1.0f : 0.0f;
+    } else {
+        if (!e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
+        HIPCHK(hipMemcpy(c_nk, e->cbuf[e->cur] + (size_t)e->lo * e->k, sizeof(float) * (size_t)e->n * e->k,
+                         hipMemcpyDeviceToHost));
+    }
+    return NEMGPU_OK;
+}
+
+int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t kd = (size_t)e->k * e->d;
+    if (prop) HIPCHK(hipMemcpy(prop, e->prop, sizeof(float) * e->k, hipMemcpyDeviceToHost));
+    if (center) HIPCHK(hipMemcpy(center, e->center, sizeof(float) * kd, hipMemcpyDeviceToHost));
+    if (disp) HIPCHK(hipMemcpy(disp, e->disp, sizeof(float) * kd, hipMemcpyDeviceToHost));
+    if (nbobs_k) HIPCHK(hipMemcpy(nbobs_k, e->nbobs_k, sizeof(float) * e->k, hipMemcpyDeviceToHost));
+    return NEMGPU_OK;
+}
+
+int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
+{
+    // device layout is class-major [k][npad]; hand back the reference's row-major [n][k]
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t m = (size_t)e->k * e->npad;
+    if (pkfki_nk) {
+        std::vector<double> t(m);
+        HIPCHK(hipMemcpy(t.data(), e->pkfki, sizeof(double) * m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < e->n; i++) for (int k = 0; k < e->k; k++) pkfki_nk[(size_t)i * e->k + k] = t[(size_t)k * e->npad + i];
+    }
+    if (logpkfki_nk) {
+        std::vector<float> t(m);
+        HIPCHK(hipMemcpy(t.data(), e->logpkfki, sizeof(float) * m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < e->n; i++) for (int k = 0; k < e->k; k++) logpkfki_nk[(size_t)i * e->k + k] = t[(size_t)k * e->npad + i];
+    }
+    return NEMGPU_OK;
+}
+
+int nemgpu_profile_enable(nemgpu_engine* e, int on)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    e->prof = on != 0;
+    e->ev_used = 0;
+    return NEMGPU_OK;
+}
+
+int nemgpu_profile_read(nemgpu_engine* e, double* density_ms_avg, int* density_launches,
+                        double* algorithmic_bytes_per_launch)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double total = 0.0;
+    const int launches = e->ev_used / 2;
+    for (int i = 0; i < launches; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[2 * i], e->ev[2 * i + 1]));
+        total += ms;
+    }
+    if (density_ms_avg) *density_ms_avg = launches ? total / launches : 0.0;
+    if (density_launches) *density_launches = launches;
+    if (algorithmic_bytes_per_launch) {
+        // E1 per launch: the bit-packed matrix once, the (k,d) tables once, pk*fk (f64) and log (f32) out
+        *algorithmic_bytes_per_launch = (double)e->n * e->wf * 4.0 + (double)e->k * e->d * 24.0 +
+                                        (double)e->n * e->k * 12.0;
+    }
+    e->ev_used = 0;
+    return NEMGPU_OK;
+}
+
+}  // extern "C"

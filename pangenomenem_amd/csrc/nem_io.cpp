@@ -1,0 +1,332 @@
+// nem_io.cpp -- the reference's ASCII file formats, host side only.
+//
+// Readers accept what the reference's fscanf-based readers accept for the files PPanGGOLiN
+// writes (ppanggolin/ppanggolin.py:821-930) and return the same StatusET codes; writers emit
+// byte-identical text for identical values (same printf formats as SaveResults,
+// /root/reference/ppanggolin/NEM/nem_exe.c:1596-1781).
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "nem_internal.hpp"
+
+namespace nemk {
+
+namespace {
+
+bool slurp(const std::string& path, std::vector<char>& buf)
+{
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    buf.resize((size_t)(sz > 0 ? sz : 0) + 1);
+    size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
+    fclose(fp);
+    buf[got] = '\0';
+    buf.resize(got + 1);
+    return true;
+}
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Skip the opening comment lines the way ReadOpeningComments does (lib_io.c:32-87): leading
+// lines that START with the marker are comments; their text (marker stripped) is collected.
+const char* skip_opening_comments(const char* p, std::string& comment)
+{
+    comment.clear();
+    while (*p == '#') {
+        const char* eol = strchr(p, '\n');
+        size_t len = eol ? (size_t)(eol - p + 1) : strlen(p);
+        comment.append(p + 1, len - 1);
+        p += len;
+    }
+    return p;
+}
+
+struct Tok {
+    const char* p;
+    explicit Tok(const char* s) : p(s) {}
+    void ws() { while (*p && is_space(*p)) p++; }
+    bool eof() { ws(); return *p == '\0'; }
+    // fscanf("%d"): optional sign + digits; stops at the first non-digit
+    bool next_int(long& v)
+    {
+        ws();
+        if (!*p) return false;
+        char* end = nullptr;
+        errno = 0;
+        v = strtol(p, &end, 10);
+        if (end == p) return false;
+        p = end;
+        return true;
+    }
+    // fscanf("%f" / "%g")
+    bool next_float(float& v)
+    {
+        ws();
+        if (!*p) return false;
+        char* end = nullptr;
+        v = strtof(p, &end);
+        if (end == p) return false;
+        p = end;
+        return true;
+    }
+};
+
+}  // namespace
+
+// ReadStrFile, nem_exe.c:739-830
+int read_str_file(const std::string& base, NemInputs& in, std::string& err)
+{
+    std::vector<char> buf;
+    const std::string path = base + ".str";
+    if (!slurp(path, buf)) { err = "File str " + path + " does not exist"; return NEMGPU_E_FILEIN; }
+    const char* p = skip_opening_comments(buf.data(), in.str_comment);
+    char type[100] = {0};
+    long n1 = 0, n2 = 0, n3 = 0;
+    int got = sscanf(p, "%99s %ld %ld %ld", type, &n1, &n2, &n3);
+    if (got < 3) { err = "Structure file (" + path + ") not enough fields"; return NEMGPU_E_FILE; }
+    for (char* s = type; *s; s++) if (*s > 'a' && *s < 'z') *s = (char)(*s + ('A' - 'a'));   // my_strupr, :1813-1824
+    if (!strcmp(type, "N") || !strcmp(type, "S")) {
+        in.type = type[0];
+        in.n = (int)n1; in.d = (int)n2;
+    } else if (!strcmp(type, "I")) {
+        err = "Data type I (image) is not supported by this engine (PPanGGOLiN always writes S)";
+        return NEMGPU_E_FILE;
+    } else {
+        err = std::string("Data type ") + type + " unknown in file " + path;
+        return NEMGPU_E_FILE;
+    }
+    if (in.n <= 0 || in.d <= 0) { err = "Structure file (" + path + ") needs positive sizes"; return NEMGPU_E_FILE; }
+    return NEMGPU_OK;
+}
+
+// ReadMatrixFile, nem_exe.c:834-898: N*D whitespace-separated numbers.  This engine handles
+// presence/absence data: every value must be 0 or 1 (what ppanggolin.py:850 writes).
+int read_dat_file(const std::string& base, NemInputs& in, std::string& err)
+{
+    std::vector<char> buf;
+    const std::string path = base + ".dat";
+    if (!slurp(path, buf)) { err = "File matrix " + path + " does not exist"; return NEMGPU_E_FILEIN; }
+    const int n = in.n, d = in.d, wf = (d + 31) / 32;
+    in.xbits.assign((size_t)n * wf, 0u);
+    const char* p = buf.data();
+    for (int i = 0; i < n; i++) {
+        uint32_t* row = in.xbits.data() + (size_t)i * wf;
+        for (int j = 0; j < d; j++) {
+            while (is_space(*p)) p++;
+            if (!*p) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "%s : short file (%d/%d lines and %d/%d columns)", path.c_str(),
+                         j == 0 ? i - 1 : i, n, j == 0 ? d : j, d);
+                err = msg;
+                return NEMGPU_E_FILE;
+            }
+            // fast path: a lone '0' or '1'
+            if ((p[0] == '0' || p[0] == '1') && (is_space(p[1]) || p[1] == '\0')) {
+                if (p[0] == '1') row[j >> 5] |= 1u << (j & 31);
+                p++;
+                continue;
+            }
+            char* end = nullptr;
+            float v = strtof(p, &end);
+            if (end == p) { err = path + " : unreadable value"; return NEMGPU_E_FILE; }
+            p = end;
+            if (v == 1.0f) row[j >> 5] |= 1u << (j & 31);
+            else if (v != 0.0f) {
+                err = path + " : only 0/1 presence/absence values are supported by this engine";
+                return NEMGPU_E_FILE;
+            }
+        }
+    }
+    return NEMGPU_OK;
+}
+
+// ReadNeiFile / ReadPtsNeighs for TYPE_SPATIAL, nem_exe.c:1278-1478.
+// Quirks kept: neighbours outside [1,N] are dropped and zero weights are dropped, each list is
+// compacted on its own (so a dropped index shifts the weights), NbNeigh = number of non-zero
+// weights when weighted; a point listed twice keeps its last record.
+int read_nei_file(const std::string& base, NemInputs& in, std::string& err)
+{
+    std::vector<char> buf;
+    const std::string path = base + ".nei";
+    if (!slurp(path, buf)) { err = "File Neigh " + path + " File does not exist"; return NEMGPU_E_FILEIN; }
+    const char* p = skip_opening_comments(buf.data(), in.nei_comment);
+    Tok tk(p);
+    long weighted = 0;
+    tk.next_int(weighted);
+    const int n = in.n;
+    std::vector<std::vector<int32_t>> idx(n);
+    std::vector<std::vector<float>> wts(n);
+    std::vector<int> nb(n, 0);
+    int nmax = 0;
+    int line = 0;
+    while (!tk.eof()) {
+        long ipt = 0, nbv = 0;
+        if (!tk.next_int(ipt)) { err = "Error in neighb. file : unreadable point index"; return NEMGPU_E_FILE; }
+        if (!tk.next_int(nbv)) break;
+        if (ipt < 1 || ipt > n || nbv < 0) { err = "Error in neighb. file : point index out of range"; return NEMGPU_E_FILE; }
+        std::vector<int32_t> iv((size_t)nbv, 0);      // calloc'ed NeighT[nbv] (genmemo.c:30)
+        std::vector<float> wv((size_t)nbv, 0.0f);
+        int nv = 0;
+        for (long t = 0; t < nbv && !tk.eof(); t++) {
+            long j = 0;
+            if (!tk.next_int(j)) {
+                char msg[128]; snprintf(msg, sizeof msg, "Error in neighb. file l.%d : neighbor %ld", line, t);
+                err = msg; return NEMGPU_E_FILE;
+            }
+            if (j >= 1 && j <= n) iv[nv++] = (int32_t)(j - 1);
+        }
+        if (weighted) {
+            nv = 0;
+            for (long t = 0; t < nbv && !tk.eof(); t++) {
+                float w = 0.f;
+                if (!tk.next_float(w)) {
+                    char msg[128]; snprintf(msg, sizeof msg, "Error in neighb. file l.%d : weight %ld", line, t);
+                    err = msg; return NEMGPU_E_FILE;
+                }
+                if (w != 0.0f) wv[nv++] = w;
+            }
+        } else {
+            for (int t = 0; t < nv; t++) wv[t] = 1.0f;
+        }
+        iv.resize(nv); wv.resize(nv);
+        idx[ipt - 1].swap(iv); wts[ipt - 1].swap(wv); nb[ipt - 1] = nv;
+        if (nv > nmax) nmax = nv;
+        line++;
+    }
+    in.max_neighs = nmax;
+    in.nei_ptr.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) in.nei_ptr[i + 1] = in.nei_ptr[i] + nb[i];
+    in.nei_idx.resize(in.nei_ptr[n]);
+    in.nei_w.resize(in.nei_ptr[n]);
+    for (int i = 0; i < n; i++) {
+        std::copy(idx[i].begin(), idx[i].end(), in.nei_idx.begin() + in.nei_ptr[i]);
+        std::copy(wts[i].begin(), wts[i].end(), in.nei_w.begin() + in.nei_ptr[i]);
+    }
+    return NEMGPU_OK;
+}
+
+// ReadParamFile, nem_exe.c:973-1091 (Bernoulli: dispersions taken as written)
+int read_param_file(const std::string& base, int k, NemInputs& in, std::string& err)
+{
+    std::vector<char> buf;
+    const std::string path = base + ".m";
+    if (!slurp(path, buf)) { err = "File param " + path + " does not exist"; return NEMGPU_E_FILEIN; }
+    const int d = in.d;
+    const int need = 1 + (k - 1) + k * d + k * d;
+    Tok tk(buf.data());
+    auto missing = [&](int have) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "The file %s needs at least %d values (%d missing)", path.c_str(), need, need - have);
+        err = msg;
+        return NEMGPU_E_FILEIN;
+    };
+    long flag = 0;
+    if (!tk.next_int(flag)) return missing(0);
+    if (flag == 1) in.param_mode = 1;
+    else if (flag == 2) in.param_mode = 2;
+    else {
+        err = "First line of file " + path + " must be 1 (parameters at beginning) or 2 (fixed parameters throughout the clustering process)";
+        return NEMGPU_E_FILEIN;
+    }
+    int have = 1, sts = NEMGPU_OK;
+    in.prop.assign(k, 0.f); in.center.assign((size_t)k * d, 0.f); in.disp.assign((size_t)k * d, 0.f);
+    float pK = 1;
+    for (int c = 0; c < k - 1; c++) {
+        float v;
+        if (!tk.next_float(v)) return missing(have);
+        have++;
+        in.prop[c] = v;
+        pK = pK - in.prop[c];
+    }
+    in.prop[k - 1] = pK;
+    if (pK <= 0.0) { char msg[64]; snprintf(msg, sizeof msg, "Last class has pK = %5.2f <= 0", pK); err = msg; sts = NEMGPU_E_FILE; }
+    for (size_t t = 0; t < (size_t)k * d; t++) {
+        float v;
+        if (!tk.next_float(v)) return missing(have);
+        have++;
+        in.center[t] = v;
+    }
+    for (size_t t = 0; t < (size_t)k * d; t++) {
+        float v;
+        if (!tk.next_float(v)) return missing(have);
+        have++;
+        in.disp[t] = v;
+        if (v <= 0) {
+            char msg[96];
+            snprintf(msg, sizeof msg, "Dispersion(k=%d, d=%d) = %5.3f <= 0", (int)(t / d) + 1, (int)(t % d) + 1, v);
+            err = msg; sts = NEMGPU_E_FILE;
+        }
+    }
+    if (!tk.eof()) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "The file %s needs do not need more than %d values", path.c_str(), need);
+        err = msg; sts = NEMGPU_E_FILEIN;
+    }
+    return sts;
+}
+
+// SaveResults, fuzzy branch: nem_exe.c:1673-1687
+int write_uf_file(const std::string& path, const float* c, int n, int k)
+{
+    FILE* fp = fopen(path.c_str(), "w");
+    if (!fp) return NEMGPU_E_FILEOUT;
+    for (int i = 0; i < n; i++) {
+        for (int kk = 0; kk < k; kk++) fprintf(fp, " %5.3f ", c[(size_t)i * k + kk]);
+        fputc('\n', fp);
+    }
+    fclose(fp);
+    return NEMGPU_OK;
+}
+
+// SaveResults, hard branch: nem_exe.c:1634-1670 (MAP label + 1 per point, one line)
+int write_cf_file(const std::string& path, const float* c, int n, int k, int tie_rule, uint32_t seed)
+{
+    FILE* fp = fopen(path.c_str(), "w");
+    if (!fp) return NEMGPU_E_FILEOUT;
+    for (int i = 0; i < n; i++) {
+        const float* row = c + (size_t)i * k;
+        int kmax = 0; float u = row[0];
+        for (int kk = 1; kk < k; kk++) if (row[kk] > u) { u = row[kk]; kmax = kk; }
+        if (tie_rule == NEMGPU_TIE_HASH) {
+            int eq[kMaxK]; int ne = 0; eq[0] = kmax;
+            for (int kk = kmax + 1; kk < k; kk++) if (row[kk] == u) eq[++ne] = kk;
+            if (ne > 0) {
+                kmax = eq[mix32_host(seed, 0xFFFFFFFFu, (uint32_t)i) % (uint32_t)(ne + 1)];
+            }
+        }
+        fprintf(fp, "%d ", kmax + 1);
+    }
+    fputc('\n', fp);
+    fclose(fp);
+    return NEMGPU_OK;
+}
+
+// SaveResults, .mf: nem_exe.c:1708-1774 (Bernoulli family)
+int write_mf_file(const std::string& path, const float crit[6], float beta, int d, int k, const float* center,
+                  const float* prop, const float* disp)
+{
+    FILE* fp = fopen(path.c_str(), "w");
+    if (!fp) return NEMGPU_E_FILEOUT;
+    const float errorrate = nanf("");                    // CalcError with Kr == 0, nem_alg.c:2790-2792
+    fprintf(fp, "Criteria U=NEM, D=Hathaway, L=mixture, M=markov ps-like, error\n\n");
+    fprintf(fp, "  %g    %g    %g    %g   %g\n\n", crit[2], crit[0], crit[4], crit[3], errorrate);
+    fprintf(fp, "Beta (%s)\n", "fixed");
+    fprintf(fp, "  %6.4f\n", beta);
+    fprintf(fp, "Mu (%d), Pk, and disp (%d) of the %d classes\n\n", d, d, k);
+    for (int kk = 0; kk < k; kk++) {
+        for (int j = 0; j < d; j++) fprintf(fp, " %10.3g ", center[(size_t)kk * d + j]);
+        fprintf(fp, "  %5.3g  ", prop[kk]);
+        for (int j = 0; j < d; j++) fprintf(fp, " %10g ", disp[(size_t)kk * d + j]);
+        fputc('\n', fp);
+    }
+    fclose(fp);
+    return NEMGPU_OK;
+}
+
+}  // namespace nemk

@@ -1,0 +1,713 @@
+// nem_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the NEM hot path.
+//
+// Reference stages (paths under /root/reference/ppanggolin/NEM/):
+//   E1  ComputePkFkiM + DensBernoulli      nem_alg.c:2234-2289, nem_mod.c:619-690
+//   E2  ComputePartitionNEM / ComputeLocalProba / ComputeMAP   nem_alg.c:2330-2405, 2546-2616, 590-664
+//   M   EstimPara (Bernoulli = Laplace estimator)              nem_mod.c:415-469, 1180-1479, 1646-1704, 922-1174
+//   C1  ComputeCrit                         nem_alg.c:2678-2757
+//
+// Arithmetic contract: every floating-point chain keeps the reference's operand types and
+// order.  The file is compiled with -ffp-contract=off (no FMA contraction), no fast-math,
+// denormals preserved.  Where a sum is order-independent (NCEM: c in {0,1} => integer
+// counts < 2^24) it is computed with popcounts over bit-packed rows instead.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "nem_kernels.hpp"
+
+namespace nemk {
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t mix32(uint32_t seed, uint32_t sweep, uint32_t site)
+{
+    // counter-based stand-in for the reference's time-seeded random() (nem_rnd.c:40-63);
+    // identical to orc_mix32() in oracle/nem_oracle.c
+    uint32_t h = seed * 0x9E3779B1u + sweep * 0x85EBCA77u + site * 0xC2B2AE3Du + 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ inline int wave_reduce_add(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout kernels (one-off, at upload time)
+//   xf  [n][W]      family-major bit rows (host layout)
+//   xw  [W][npad]   word-major: lane i reads word w of family i  -> coalesced E1 reads
+//   xt  [d][nw64]   organism-major bit rows (bit j = local family j) -> popcount M-step
+// ------------------------------------------------------------------------------------------
+__global__ void k_layout_words(const uint32_t* __restrict__ xf, int n, int wf, int W, int npad,
+                               uint32_t* __restrict__ xw)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = blockIdx.y;
+    if (i >= npad) return;
+    uint32_t v = 0;
+    if (i < n && w < wf) v = xf[(size_t)i * wf + w];
+    xw[(size_t)w * npad + i] = v;
+}
+
+// one wave = 64 families x one 32-organism word: 32 ballots transpose the 64x32 bit tile
+__global__ void k_layout_bits(const uint32_t* __restrict__ xw, int npad, int d, int nw64,
+                              uint64_t* __restrict__ xt)
+{
+    int lane = threadIdx.x & 63;
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // 64-family block index
+    int w = blockIdx.y;
+    if (wave >= nw64) return;
+    int i = wave * 64 + lane;
+    uint32_t v = (i < npad) ? xw[(size_t)w * npad + i] : 0u;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        uint64_t m = __ballot((v >> b) & 1u);
+        if (lane == b) mine = m;
+    }
+    int org = w * 32 + lane;
+    if (lane < 32 && org < d) xt[(size_t)org * nw64 + wave] = mine;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-(k,d) density tables.  DensBernoulli's two logs depend on (k,d) only (nem_mod.c:660-661):
+//   t0 = |(int)(0 - mu)| * log((double)(float)((1-eps)/eps)),  t1 = same for x = 1,
+//   l0 = log((double)(float)(1-eps));  eps <= EPSILON => t0 = t1 = l0 = 0 (dk unchanged) and a
+//   "null density" bit when the mismatch is non-zero (nem_mod.c:662-666).
+// Padding organisms (d >= D) get all-zero entries: the chain step is then an exact no-op.
+// ------------------------------------------------------------------------------------------
+__global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
+                         const float* __restrict__ center, const float* __restrict__ disp,
+                         double2* __restrict__ tabT, double* __restrict__ tabL0,
+                         uint32_t* __restrict__ nz0, uint32_t* __restrict__ nz1,
+                         double* __restrict__ pk, float* __restrict__ logpk, int* __restrict__ flags)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;      // over K * dpad (dpad % 64 == 0)
+    int lane = threadIdx.x & 63;
+    if (t >= K * dpad) return;
+    int k = t / dpad, dd = t - k * dpad;
+    double t0 = 0.0, t1 = 0.0, l0 = 0.0;
+    int n0 = 0, n1 = 0;
+    if (dd < D) {
+        float eps = disp[k * D + dd];
+        float mu = center[k * D + dd];
+        int ad0 = abs((int)(0.0f - mu));
+        int ad1 = abs((int)(1.0f - mu));
+        if ((double)eps > kEpsilonD) {
+            double l1 = log((double)((1.0f - eps) / eps));
+            l0 = log((double)(1.0f - eps));
+            t0 = (double)ad0 * l1;
+            t1 = (double)ad1 * l1;
+        } else {
+            n0 = (ad0 != 0);
+            n1 = (ad1 != 0);
+        }
+    }
+    tabT[t] = make_double2(t0, t1);
+    tabL0[t] = l0;
+    uint64_t m0 = __ballot(n0), m1 = __ballot(n1);
+    if (lane == 0) {
+        int w = t >> 5;                                  // word index inside [K][dpad/32]
+        nz0[w] = (uint32_t)m0; nz0[w + 1] = (uint32_t)(m0 >> 32);
+        nz1[w] = (uint32_t)m1; nz1[w + 1] = (uint32_t)(m1 >> 32);
+    }
+    if (dd == 0) {                                       // ComputePkFkiM, nem_alg.c:2262-2271
+        double p = (double)prop[k];
+        pk[k] = p;
+        if (p > kEpsilonD) logpk[k] = (float)log(p);
+        else { logpk[k] = -INFINITY; atomicOr(&flags[FLAG_EMPTY_PROP], 1); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E1: Bernoulli log-density chains.  One lane per (family, class): the chain over organisms is
+// a sequential float accumulator with double intermediates and cannot be re-associated
+// (SURVEY.md §0-2).  grid = (ceil(n/256), K); the class's table slice is staged through LDS in
+// chunks of DCH organisms and read back as wave-uniform broadcasts.
+// ------------------------------------------------------------------------------------------
+constexpr int DCH = 2048;
+
+__global__ __launch_bounds__(256) void k_density(const uint32_t* __restrict__ xw, int n, int npad, int dpad,
+                                                 const double2* __restrict__ tabT,
+                                                 const double* __restrict__ tabL0,
+                                                 const uint32_t* __restrict__ nz0,
+                                                 const uint32_t* __restrict__ nz1,
+                                                 const double* __restrict__ pk,
+                                                 const float* __restrict__ logpk,
+                                                 double* __restrict__ pkfki, float* __restrict__ logpkfki)
+{
+    __shared__ double2 sT[DCH];
+    __shared__ double sL[DCH];
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;        // i < npad by construction
+    const int W = dpad >> 5;
+    float dk = 0.0f;
+    uint32_t nul = 0;
+
+    for (int d0 = 0; d0 < dpad; d0 += DCH) {
+        const int dn = min(DCH, dpad - d0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < dn; t += 256) {
+            sT[t] = tabT[(size_t)k * dpad + d0 + t];
+            sL[t] = tabL0[(size_t)k * dpad + d0 + t];
+        }
+        __syncthreads();
+        const int w0 = d0 >> 5, wn = dn >> 5;
+        uint32_t xnext = xw[(size_t)w0 * npad + i];
+        for (int w = 0; w < wn; w++) {
+            const uint32_t x = xnext;
+            if (w + 1 < wn) xnext = xw[(size_t)(w0 + w + 1) * npad + i];
+            nul |= (x & nz1[k * W + w0 + w]) | (~x & nz0[k * W + w0 + w]);
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const double2 tt = sT[w * 32 + b];
+                const double l0 = sL[w * 32 + b];
+                const double a = ((x >> b) & 1u) ? tt.y : tt.x;
+                dk = (float)(((double)dk + a) - l0);     // nem_mod.c:661
+            }
+        }
+    }
+    if (i < n) {
+        float logfk; double fk;
+        if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
+        else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
+        pkfki[(size_t)k * npad + i] = pk[k] * fk;                // nem_alg.c:2282
+        logpkfki[(size_t)k * npad + i] = logpk[k] + logfk;       // nem_alg.c:2283
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E2: one relaxation round of the Gauss-Seidel site sweep.
+//
+// The reference updates sites in index order, in place (UPDATE_SEQ): site i sees the NEW rows
+// of neighbours j < i and the OLD rows of neighbours j >= i.  That is a lower-triangular
+// system  c = F(c_{<i}, old_{>=i})  with a unique solution.  Each round evaluates every site
+// in parallel against a guess of the new rows; when a round changes nothing the guess IS that
+// solution, bit for bit.  Round r reads guess_r and writes out_r; rounds after the first
+// unchanged one exit immediately (prev_changed == 0).
+// ------------------------------------------------------------------------------------------
+template <int KT, bool NCEM>
+__global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
+{
+    if (a.prev_changed != nullptr && *a.prev_changed == 0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_local) return;
+    const int gi = a.lo + i;
+    const int K = KT > 0 ? KT : a.K;
+    constexpr int KA = KT > 0 ? KT : kMaxKernelK;
+
+    float ctx[KA];
+#pragma unroll
+    for (int k = 0; k < KA; k++) ctx[k] = 0.0f;
+
+    if (a.use_nei) {
+        const int b = a.nei_ptr[i], e = a.nei_ptr[i + 1];
+        for (int t = b; t < e; t++) {                    // SumNeighsOfClass, nem_alg.c:2865-2875
+            const int j = a.nei_idx[t];
+            const float wt = a.nei_w[t];
+            if (NCEM) {
+                const int lab = (j < gi) ? a.lab_guess[j] : a.lab_old[j];
+#pragma unroll
+                for (int k = 0; k < KA; k++)
+                    if (k < K) ctx[k] = ctx[k] + ((lab == k) ? wt : 0.0f);   // w*1 = w ; w*0 adds nothing
+            } else {
+                const float* row = ((j < gi) ? a.c_guess : a.c_old) + (size_t)j * K;
+#pragma unroll
+                for (int k = 0; k < KA; k++)
+                    if (k < K) ctx[k] = ctx[k] + (wt * row[k]);
+            }
+        }
+    }
+
+    double cinum[KA];
+    double cum = 0.0;
+#pragma unroll
+    for (int k = 0; k < KA; k++) {
+        if (k < K) {                                     // nem_alg.c:2581-2584
+            double v = a.pkfki[(size_t)k * a.npad + i];
+            if (a.use_nei) v = v * exp((double)a.beta * (double)ctx[k]);
+            cinum[k] = v;
+            cum = cum + v;
+        }
+    }
+    float cf[KA];
+    if (cum > 0) {                                       // nem_alg.c:2589-2601
+        if (cum > kEpsilonD) {
+            const double invz = 1 / cum;
+#pragma unroll
+            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * cinum[k]);
+        } else {
+            const double invz = 1 / (cum / kEpsilonD);
+#pragma unroll
+            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * (cinum[k] / kEpsilonD));
+        }
+    } else {                                             // nem_alg.c:2603-2607
+        const float u = (float)(1.0 / K);
+#pragma unroll
+        for (int k = 0; k < KA; k++) if (k < K) cf[k] = u;
+        atomicAdd(&a.flags[FLAG_NZERO], 1);
+        atomicMax(&a.flags[FLAG_FIRSTZERO], a.n_total - gi);   // first site = n_total - max
+    }
+
+    bool changed = false;
+    if (NCEM) {                                          // ComputeMAP, nem_alg.c:603-640
+        int kmax = 0; float ukmax = cf[0];
+#pragma unroll
+        for (int k = 1; k < KA; k++) if (k < K && cf[k] > ukmax) { ukmax = cf[k]; kmax = k; }
+        if (a.tie_rule == NEMGPU_TIE_HASH) {
+            int nequal = 0;
+#pragma unroll
+            for (int k = 1; k < KA; k++) if (k < K && k > kmax && cf[k] == ukmax) nequal++;
+            if (nequal > 0) {
+                int pick = (int)(mix32(a.tie_seed, a.sweep_id, (uint32_t)gi) % (uint32_t)(nequal + 1));
+                int seen = 0, chosen = kmax;
+#pragma unroll
+                for (int k = 1; k < KA; k++)
+                    if (k < K && k > kmax && cf[k] == ukmax) { seen++; if (seen == pick) chosen = k; }
+                kmax = chosen;
+            }
+        }
+        changed = (kmax != (int)a.lab_guess[gi]);
+        a.lab_out[gi] = (uint8_t)kmax;
+    } else {
+        const float* g = a.c_guess + (size_t)gi * K;
+        float* o = a.c_out + (size_t)gi * K;
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+            if (k < K) {
+                changed |= (__float_as_uint(cf[k]) != __float_as_uint(g[k]));
+                o[k] = cf[k];
+            }
+        }
+    }
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
+}
+
+void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
+{
+    dim3 grid((a.n_local + 255) / 256), block(256);
+#define NEM_SW(KT_)                                                                  \
+    case KT_:                                                                        \
+        if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true>), grid, block, 0, s, a);   \
+        else hipLaunchKernelGGL((k_sweep<KT_, false>), grid, block, 0, s, a);       \
+        break;
+    switch (a.K) {
+        NEM_SW(1) NEM_SW(2) NEM_SW(3) NEM_SW(4) NEM_SW(5) NEM_SW(6) NEM_SW(7) NEM_SW(8) NEM_SW(9) NEM_SW(10)
+    default:
+        if (ncem) hipLaunchKernelGGL((k_sweep<0, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_sweep<0, false>), grid, block, 0, s, a);
+    }
+#undef NEM_SW
+}
+
+// ------------------------------------------------------------------------------------------
+// NCEM bookkeeping after a sweep: per-class membership bitmasks (for the popcount M-step) and
+// the CVTEST_CLAS flag (HasConverged, nem_alg.c:2075-2089: max|c - cold| is 1 iff a label moved).
+// ------------------------------------------------------------------------------------------
+__global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* __restrict__ lab_new,
+                              const uint8_t* __restrict__ lab_old, uint64_t* __restrict__ mask,
+                              int* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = i >> 6;
+    if (wave >= nw64) return;
+    int lab = 255, moved = 0;
+    if (i < n_local) {
+        lab = lab_new[lo + i];
+        if (lab_old != nullptr) moved = (lab != (int)lab_old[lo + i]);
+    }
+    for (int k = 0; k < K; k++) {
+        uint64_t m = __ballot(lab == k);
+        if (lane == 0) mask[(size_t)k * nw64 + wave] = m;
+    }
+    if (__any(moved) && lane == 0) atomicOr(&flags[FLAG_MOVED], 1);
+}
+
+// M1-M3 for NCEM as integer counts: S1[k][d] = #{i : label_i = k, x_id = 1}, N_k = #{label = k}.
+// grid = d + 1 blocks (the last one counts class sizes); out: stats[0..K) = N_k, stats[K + k*d + j] = S1.
+__global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, const uint64_t* __restrict__ xt,
+                                                      const uint64_t* __restrict__ mask, int* __restrict__ stats)
+{
+    __shared__ int red[4];
+    const int d = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < K; k++) {
+        int acc = 0;
+        for (int j = threadIdx.x; j < nw64; j += 256) {
+            const uint64_t xv = (d < D) ? xt[(size_t)d * nw64 + j] : ~0ull;
+            acc += __popcll(xv & mask[(size_t)k * nw64 + j]);
+        }
+        acc = wave_reduce_add(acc);
+        __syncthreads();
+        if (lane == 0) red[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int v = red[0] + red[1] + red[2] + red[3];
+            if (d < D) stats[K + k * D + d] = v; else stats[k] = v;
+        }
+    }
+}
+
+// centres and inertia from the (globally summed) counts.  With c in {0,1}:
+//   N_K = count (EstimSizes, nem_mod.c:1293-1315);  halfwei = N_K/2;  zeros-side weight S0 = N_K - S1;
+//   ComputeMedian (nem_mod.c:1439-1477) gives mu = 0 if S0 > half, 0.5 if S0 == half, 1 otherwise;
+//   EstimLaplaceIner (nem_mod.c:1669-1686) gives S1, S0 or N_K/2 for mu = 0, 1, 0.5 (all exact).
+__global__ void k_mstep_centers_ncem(int K, int D, const int* __restrict__ stats, float* __restrict__ center,
+                                     float* __restrict__ nbobs_k, float* __restrict__ iner)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= K * D) return;
+    const int k = t / D;
+    const int nk = stats[k];
+    const float nkf = (float)nk;
+    if (t - k * D == 0) nbobs_k[k] = nkf;
+    float in = 0.0f;
+    if ((double)nkf > kEpsilonD) {
+        const float half = nkf / 2;
+        const int s1 = stats[K + t];
+        const float s0f = (float)(nk - s1);
+        float mu;
+        if (s0f > half) { mu = 0.0f; in = (float)s1; }
+        else if (s0f == half) { mu = 0.5f; in = 0.5f * nkf; }
+        else { mu = 1.0f; in = s0f; }
+        center[t] = mu;
+    }
+    iner[t] = in;
+}
+
+// M4/M5: dispersion model + proportions (InerToDisp*, nem_mod.c:965-1174; EstimPara :456-465).
+// MissMode is MISSING_IGNORE for Bernoulli (nem_mod.c:446-448) and N_KD[k][d] == N_K[k] (no NaN).
+// The d- / k-ordered float sums are order-dependent (values exceed 2^24) and stay sequential.
+__global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, int disper, int propor,
+                                                     const float* __restrict__ nbobs_k,
+                                                     const float* __restrict__ iner, float* __restrict__ disp,
+                                                     float* __restrict__ prop, int* __restrict__ flags)
+{
+    __shared__ float s_disp[kMaxKernelK];
+    __shared__ int s_valid[kMaxKernelK];
+    __shared__ float s_vol;
+    const int tid = threadIdx.x;
+    if (disper == NEMGPU_DISP___) {
+        if (tid == 0) {
+            float vol = 0.0f, nobs = 0.0f;
+            for (int k = 0; k < K; k++)
+                if (nbobs_k[k] > 0)
+                    for (int d = 0; d < D; d++) { vol += iner[k * D + d]; nobs += nbobs_k[k]; }
+            s_vol = vol / nobs;
+        }
+        __syncthreads();
+        for (int t = tid; t < K * D; t += 1024) disp[t] = s_vol;
+    } else if (disper == NEMGPU_DISP_K_) {
+        if (tid < K) {
+            const int k = tid;
+            s_valid[k] = 0;
+            if (nbobs_k[k] > 0) {
+                float sn = 0.0f, si = 0.0f;
+                const float nk = nbobs_k[k];
+                for (int d = 0; d < D; d++) { sn += nk; si += iner[k * D + d]; }
+                s_disp[k] = si / sn;
+                s_valid[k] = 1;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < K * D; t += 1024) {
+            const int k = t / D;
+            if (s_valid[k]) disp[t] = s_disp[k];
+        }
+    } else if (disper == NEMGPU_DISP__D) {
+        for (int d = tid; d < D; d += 1024) {
+            float sn = 0.0f, si = 0.0f;
+            for (int k = 0; k < K; k++) { sn += nbobs_k[k]; si += iner[k * D + d]; }
+            const float dd = si / sn;
+            for (int k = 0; k < K; k++) disp[k * D + d] = dd;
+        }
+    } else {
+        for (int t = tid; t < K * D; t += 1024) {
+            const int k = t / D;
+            if ((double)nbobs_k[k] > kEpsilonD) disp[t] = iner[t] / nbobs_k[k];
+        }
+    }
+    if (tid < K) {
+        if (propor == NEMGPU_PROP_K) prop[tid] = nbobs_k[tid] / (float)n_total;
+        else prop[tid] = (float)(1.0 / K);
+    }
+    if (tid == 0) {                                      // EstimLaplaceCenters :1404-1408
+        int ek = 0;
+        for (int k = 0; k < K; k++) if (!((double)nbobs_k[k] > kEpsilonD)) ek = k + 1;
+        flags[FLAG_EMPTYK] = ek;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fuzzy NEM M-step: the reference's sums are i-ordered float accumulators, so each (class,
+// organism) chain stays on one lane; the K*D chains run in parallel.  wave = 64 organisms of
+// one class: c_ik is wave-uniform, the bit word is shared by 32 lanes.
+//   pass A: N_K, zeros-side total S0, inertia candidates for mu = 0, 1, 0.5
+//   pass B: ComputeMedian's prefix scan (zeros in index order, then ones) against halfwei
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+                                                      const float* __restrict__ c, float* __restrict__ nbobs_k,
+                                                      float* __restrict__ s0_out, float* __restrict__ in0_out,
+                                                      float* __restrict__ in1_out, float* __restrict__ inh_out)
+{
+    const int k = blockIdx.y;
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    const int dw = min(d, D - 1) >> 5, db = d & 31;
+    const uint32_t* col = xw + (size_t)dw * npad;
+    float nk = 0.0f, s0 = 0.0f, in0 = 0.0f, in1 = 0.0f, inh = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < n; i++) {
+        const float ci = c[(size_t)i * K + k];
+        const bool one = (col[i] >> db) & 1u;
+        nk += ci;                                                        // nem_mod.c:1308
+        if (!one) s0 += ci;                                              // nem_mod.c:1456 (zeros first)
+        const double cd = (double)ci;
+        if (one) in0 = (float)((double)in0 + cd * 1.0);                  // nem_mod.c:1683, mu = 0
+        else in1 = (float)((double)in1 + cd * 1.0);                      //                 mu = 1
+        inh = (float)((double)inh + cd * 0.5);                           //                 mu = 0.5
+    }
+    if (d < D) {
+        const int t = k * D + d;
+        s0_out[t] = s0; in0_out[t] = in0; in1_out[t] = in1; inh_out[t] = inh;
+        if (d == 0) nbobs_k[k] = nk;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+                                                      const float* __restrict__ c, const float* __restrict__ nbobs_k,
+                                                      const float* __restrict__ s0_in, const float* __restrict__ in0,
+                                                      const float* __restrict__ in1, const float* __restrict__ inh,
+                                                      float* __restrict__ center, float* __restrict__ iner)
+{
+    const int k = blockIdx.y;
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    const int dc = min(d, D - 1);
+    const int dw = dc >> 5, db = dc & 31;
+    const uint32_t* col = xw + (size_t)dw * npad;
+    const float nk = nbobs_k[k];
+    const int t = k * D + dc;
+    if (!((double)nk > kEpsilonD)) {                     // empty class: centre kept, inertia of an all-zero column
+        if (d < D) iner[t] = 0.0f;                       // (c == 0 everywhere for practical purposes)
+        return;
+    }
+    const float half = nk / 2;                           // nem_mod.c:1439
+    const double half_eps = (double)half + kEpsilonD;    // nem_mod.c:1464
+    float cum0 = 0.0f, cum1 = s0_in[t];
+    // phase: 0 scanning, 1 crossed with equality (looking for next c >= EPSILON), 2 resolved
+    int ph0 = 0, ph1 = 0, next0 = 0, next1 = 0, gt0 = 0, gt1 = 0, any1 = 0;
+#pragma unroll 4
+    for (int i = 0; i < n; i++) {
+        const float ci = c[(size_t)i * K + k];
+        const bool one = (col[i] >> db) & 1u;
+        const bool big = !((double)ci < kEpsilonD);
+        if (!one) {
+            if (ph0 == 0) { cum0 += ci; if (!(cum0 < half)) { ph0 = 1; gt0 = ((double)cum0 > half_eps); } }
+            else if (big) next0 = 1;
+        } else {
+            any1 |= big;
+            if (ph1 == 0) { cum1 += ci; if (!(cum1 < half)) { ph1 = 1; gt1 = ((double)cum1 > half_eps); } }
+            else if (big) next1 = 1;
+        }
+    }
+    float mu;
+    if (ph0) {                                           // median position among the zeros
+        if (gt0 || next0) mu = 0.0f;                     // x_med = 0 (or midway to another 0)
+        else if (any1) mu = 0.5f;                        // midway to the first one with weight
+        else mu = 0.0f;                                  // reference runs off the array here (UB)
+    } else {
+        (void)ph1; (void)gt1; (void)next1;
+        mu = 1.0f;                                       // x_med = 1 (or midway to another 1)
+    }
+    if (d < D) {
+        center[t] = mu;
+        iner[t] = (mu == 0.0f) ? in0[t] : (mu == 1.0f ? in1[t] : inh[t]);
+    }
+}
+
+// CVTEST_CLAS for float partitions (nem_alg.c:2077-2088): converged iff no |c - cold| >= thres
+__global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float* __restrict__ cold, float thres,
+                             int* __restrict__ flags)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (t < m) {
+        float dif = c[t] - cold[t];
+        if (dif < 0) dif = -dif;
+        bad = (dif >= thres);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
+}
+
+// labels -> one-hot float rows (LabelToClassVector, nem_alg.c:649-664)
+__global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* __restrict__ c)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * K) return;
+    const int i = (int)(t / K), k = (int)(t - (size_t)i * K);
+    c[t] = (lab[i] == k) ? 1.0f : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// C1: criteria (ComputeCrit, nem_alg.c:2702-2751).  Per-site terms in parallel, then the four
+// i-ordered float accumulators (D, G, L, Z) on four lanes reading LDS-staged terms.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, const int* __restrict__ nei_ptr,
+                                                    const int* __restrict__ nei_idx, const float* __restrict__ nei_w,
+                                                    int use_nei, float beta, const float* __restrict__ c,
+                                                    const double* __restrict__ pkfki,
+                                                    const float* __restrict__ logpkfki, float* __restrict__ dik,
+                                                    float* __restrict__ gik, double* __restrict__ lfi,
+                                                    double* __restrict__ lzi)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double fi = 0.0;
+    float zi = 0.0f;
+    const int b = use_nei ? nei_ptr[i] : 0, e = use_nei ? nei_ptr[i + 1] : 0;
+    for (int k = 0; k < K; k++) {
+        const float cik = c[(size_t)i * K + k];
+        float pik = 0.0f;
+        for (int t = b; t < e; t++) pik = pik + (nei_w[t] * c[(size_t)nei_idx[t] * K + k]);
+        float dv = 0.0f, gv = 0.0f;
+        if (cik > FLT_MIN) {                                              // MINFLOAT, :2727
+            const float lp = logpkfki[(size_t)k * npad + i];
+            dv = (float)((double)cik * ((double)lp - log((double)cik)));  // :2731
+            gv = cik * pik;                                               // :2732
+        }
+        dik[(size_t)i * K + k] = dv;
+        gik[(size_t)i * K + k] = gv;
+        fi = fi + pkfki[(size_t)k * npad + i];                            // :2739
+        zi = (float)((double)zi + exp((double)(beta * pik)));             // :2740
+    }
+    lfi[i] = log(fi);                                                     // :2744
+    lzi[i] = log((double)zi);                                             // :2745
+}
+
+// The four accumulators are i-ordered (k inner) float chains: one lane each, fed from LDS-staged
+// chunks.  Entries with cik <= MINFLOAT are skipped, not added as zeros (nem_alg.c:2727-2736).
+__global__ __launch_bounds__(256) void k_crit_reduce(int n, int K, float beta, const float* __restrict__ c,
+                                                     const float* __restrict__ dik, const float* __restrict__ gik,
+                                                     const double* __restrict__ lfi, const double* __restrict__ lzi,
+                                                     float* __restrict__ crit6)
+{
+    constexpr int CAP = 4096;                            // staged (site, class) entries per chunk
+    __shared__ float sD[CAP], sG[CAP];
+    __shared__ unsigned char sV[CAP];
+    __shared__ double sL[CAP / 2], sZ[CAP / 2];
+    __shared__ float fin[4];
+    const int ch = max(1, min(CAP / K, CAP / 2));        // sites per chunk
+    float acc = 0.0f;                                    // lane 0: D, 64: G, 128: L, 192: Z
+    for (int i0 = 0; i0 < n; i0 += ch) {
+        const int cn = min(ch, n - i0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cn * K; t += 256) {
+            const size_t g = (size_t)i0 * K + t;         // row-major (i, k): i outer, k inner
+            sD[t] = dik[g]; sG[t] = gik[g]; sV[t] = (c[g] > FLT_MIN);
+        }
+        for (int t = threadIdx.x; t < cn; t += 256) { sL[t] = lfi[i0 + t]; sZ[t] = lzi[i0 + t]; }
+        __syncthreads();
+        if (threadIdx.x == 0) { for (int t = 0; t < cn * K; t++) if (sV[t]) acc = acc + sD[t]; }        // :2734
+        else if (threadIdx.x == 64) { for (int t = 0; t < cn * K; t++) if (sV[t]) acc = acc + sG[t]; }  // :2735
+        else if (threadIdx.x == 128) { for (int t = 0; t < cn; t++) acc = (float)((double)acc + sL[t]); } // :2744
+        else if (threadIdx.x == 192) { for (int t = 0; t < cn; t++) acc = (float)((double)acc - sZ[t]); } // :2745
+    }
+    if ((threadIdx.x & 63) == 0) fin[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float D = fin[0], G = fin[1], L = fin[2], Z = fin[3];
+        crit6[0] = D; crit6[1] = G;
+        crit6[2] = (float)((double)D + (0.5 * (double)beta) * (double)G);   // :2750
+        crit6[3] = (D + (beta * G)) + Z;                                    // :2751
+        crit6[4] = L; crit6[5] = Z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
+                   hipStream_t s)
+{
+    hipLaunchKernelGGL(k_layout_words, dim3((npad + 255) / 256, W), dim3(256), 0, s, xf, n, wf, W, npad, xw);
+    hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
+}
+
+void launch_tables(int K, int D, int dpad, const float* prop, const float* center, const float* disp, double2* tabT,
+                   double* tabL0, uint32_t* nz0, uint32_t* nz1, double* pk, float* logpk, int* flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tables, dim3((K * dpad + 255) / 256), dim3(256), 0, s, K, D, dpad, prop, center, disp, tabT,
+                       tabL0, nz0, nz1, pk, logpk, flags);
+}
+
+void launch_density(const uint32_t* xw, int n, int npad, int dpad, int K, const double2* tabT, const double* tabL0,
+                    const uint32_t* nz0, const uint32_t* nz1, const double* pk, const float* logpk, double* pkfki,
+                    float* logpkfki, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_density, dim3(npad / 256, K), dim3(256), 0, s, xw, n, npad, dpad, tabT, tabL0, nz0, nz1, pk,
+                       logpk, pkfki, logpkfki);
+}
+
+void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
+                        uint64_t* mask, int* flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_labels_post, dim3((nw64 * 64 + 255) / 256), dim3(256), 0, s, n_local, lo, K, nw64, lab_new,
+                       lab_old, mask, flags);
+}
+
+void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mstep_counts, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats);
+}
+
+void launch_mstep_centers_ncem(int K, int D, const int* stats, float* center, float* nbobs_k, float* iner,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mstep_centers_ncem, dim3((K * D + 255) / 256), dim3(256), 0, s, K, D, stats, center, nbobs_k,
+                       iner);
+}
+
+void launch_mstep_disp(int K, int D, int n_total, int disper, int propor, const float* nbobs_k, const float* iner,
+                       float* disp, float* prop, int* flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mstep_disp, dim3(1), dim3(1024), 0, s, K, D, n_total, disper, propor, nbobs_k, iner, disp,
+                       prop, flags);
+}
+
+void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
+                        float* in0, float* in1, float* inh, float* center, float* iner, hipStream_t s)
+{
+    dim3 grid((D + 63) / 64, K), block(64);
+    hipLaunchKernelGGL(k_mstep_fuzzy_a, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh);
+    hipLaunchKernelGGL(k_mstep_fuzzy_b, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh, center,
+                       iner);
+}
+
+void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_conv_fuzzy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, c, cold, thres, flags);
+}
+
+void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)
+{
+    size_t m = (size_t)n * K;
+    hipLaunchKernelGGL(k_onehot, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, n, K, lab, c);
+}
+
+void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
+                     float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
+                     double* lfi, double* lzi, float* crit6, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, n, K, npad, nei_ptr, nei_idx, nei_w,
+                       use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi);
+    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, K, beta, c, dik, gik, lfi, lzi, crit6);
+}
+
+}  // namespace nemk

@@ -1,0 +1,55 @@
+// nem_kernels.hpp -- kernel launch interface (device pointers only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/nem_mi355x.h"
+
+namespace nemk {
+
+constexpr int kMaxKernelK = 32;
+constexpr double kEpsilonD = 1e-20;   // EPSILON, reference nem_typ.h:63
+
+// per-round flag slot of an E2 sweep
+enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_ROUND_STRIDE = 4 };
+// per-iteration flag block
+enum { FLAG_MOVED = 0, FLAG_EMPTYK = 1, FLAG_EMPTY_PROP = 2, FLAG_ITER_STRIDE = 4 };
+
+struct SweepArgs {
+    int n_local, lo, n_total, K, npad, use_nei;
+    const int* nei_ptr; const int* nei_idx; const float* nei_w;
+    float beta;
+    const double* pkfki;                       // [K][npad], local families
+    // NCEM state: labels, GLOBAL family indexing
+    const uint8_t* lab_old; const uint8_t* lab_guess; uint8_t* lab_out;
+    // fuzzy state: float rows [n_total][K], GLOBAL family indexing
+    const float* c_old; const float* c_guess; float* c_out;
+    int tie_rule; uint32_t tie_seed; uint32_t sweep_id;
+    int* flags;                                // this round's slot
+    const int* prev_changed;                   // previous round's FLAG_CHANGED (nullptr for round 0)
+};
+
+void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
+                   hipStream_t s);
+void launch_tables(int K, int D, int dpad, const float* prop, const float* center, const float* disp, double2* tabT,
+                   double* tabL0, uint32_t* nz0, uint32_t* nz1, double* pk, float* logpk, int* flags, hipStream_t s);
+void launch_density(const uint32_t* xw, int n, int npad, int dpad, int K, const double2* tabT, const double* tabL0,
+                    const uint32_t* nz0, const uint32_t* nz1, const double* pk, const float* logpk, double* pkfki,
+                    float* logpkfki, hipStream_t s);
+void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
+void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
+                        uint64_t* mask, int* flags, hipStream_t s);
+void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats, hipStream_t s);
+void launch_mstep_centers_ncem(int K, int D, const int* stats, float* center, float* nbobs_k, float* iner,
+                               hipStream_t s);
+void launch_mstep_disp(int K, int D, int n_total, int disper, int propor, const float* nbobs_k, const float* iner,
+                       float* disp, float* prop, int* flags, hipStream_t s);
+void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
+                        float* in0, float* in1, float* inh, float* center, float* iner, hipStream_t s);
+void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, hipStream_t s);
+void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s);
+void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
+                     float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
+                     double* lfi, double* lzi, float* crit6, hipStream_t s);
+
+}  // namespace nemk

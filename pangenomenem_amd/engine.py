@@ -1,0 +1,250 @@
+"""ctypes binding of the in-memory engine (include/nem_mi355x.h, ``nemgpu_*``).
+
+This is plumbing: every number is produced by the HIP kernels in ``lib/libnem_mi355x.so``.
+Loading fails loudly when the library has not been built; creating an engine fails loudly when
+no HIP device is usable (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnem_mi355x.so")
+
+ALGO = {"nem": 0, "ncem": 1}
+DISP = {"s__": 0, "sk_": 1, "s_d": 2, "skd": 3}
+PROP = {"p_": 0, "pk": 1}
+CVT = {"none": 0, "clas": 1}
+TIE = {"first": 1, "hash": 2}
+STATUS_OK, STATUS_W_EMPTYCLASS, STATUS_E_DEVICE = 0, 2, 9
+
+
+class NemGpuError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("algo", C.c_int), ("beta", C.c_float), ("disper", C.c_int), ("propor", C.c_int),
+                ("cvtest", C.c_int), ("cvthres", C.c_float), ("it_max", C.c_int), ("param_fix", C.c_int),
+                ("tie_rule", C.c_int), ("tie_seed", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("converged", C.c_int), ("emptyk", C.c_int),
+                ("zero_density_sites", C.c_int), ("first_zero_density_site", C.c_int),
+                ("sweep_rounds", C.c_int), ("crit", C.c_float * 6), ("loop_seconds", C.c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library.  Raises if it has not been built (python -m pangenomenem_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NemGpuError("%s is missing: build it with `python pangenomenem_amd/build.py` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    lib.nemgpu_last_error.restype = C.c_char_p
+    lib.nemgpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.nemgpu_destroy.argtypes = [vp]
+    lib.nemgpu_destroy.restype = None
+    lib.nemgpu_set_matrix_bytes.argtypes = [vp, vp]
+    lib.nemgpu_set_matrix_bits.argtypes = [vp, vp]
+    lib.nemgpu_set_graph.argtypes = [vp, vp, vp, vp]
+    lib.nemgpu_set_params.argtypes = [vp, vp, vp, vp]
+    lib.nemgpu_configure.argtypes = [vp, C.POINTER(Config)]
+    lib.nemgpu_run.argtypes = [vp, C.POINTER(Result)]
+    lib.nemgpu_init_partition.argtypes = [vp]
+    lib.nemgpu_iterate.argtypes = [vp, C.c_int, C.POINTER(Result)]
+    lib.nemgpu_reset.argtypes = [vp]
+    lib.nemgpu_density.argtypes = [vp]
+    lib.nemgpu_sweep.argtypes = [vp, C.c_float, ip]
+    lib.nemgpu_mstep.argtypes = [vp, ip]
+    lib.nemgpu_criteria.argtypes = [vp, fp]
+    lib.nemgpu_set_partition.argtypes = [vp, vp]
+    lib.nemgpu_get_partition.argtypes = [vp, vp]
+    lib.nemgpu_get_labels.argtypes = [vp, vp]
+    lib.nemgpu_get_params.argtypes = [vp, vp, vp, vp, vp]
+    lib.nemgpu_get_density.argtypes = [vp, vp, vp]
+    lib.nemgpu_profile_enable.argtypes = [vp, C.c_int]
+    lib.nemgpu_profile_read.argtypes = [vp, C.POINTER(C.c_double), ip, C.POINTER(C.c_double)]
+    lib.nem.restype = C.c_int
+    lib.nem.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_float, C.c_char_p, C.c_float, C.c_char_p, C.c_int,
+                        C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().nemgpu_device_count())
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class NemEngine:
+    """One NEM problem resident on one GPU (mirrors the reference's ClassifyByNem state:
+    DataT + SpatialT + StatModelT + NemParaT, nem_typ.h:286-445)."""
+
+    def __init__(self, n, d, k, device=0, stream=None, site_lo=0, site_hi=None):
+        self.lib = load_library()
+        self.n_total, self.d, self.k = int(n), int(d), int(k)
+        self.lo = int(site_lo)
+        self.hi = int(n if site_hi is None else site_hi)
+        self.n = self.hi - self.lo
+        self._h = C.c_void_p()
+        self._chk(self.lib.nemgpu_create(C.byref(self._h), self.n_total, self.d, self.k, self.lo, self.hi,
+                                         int(device), C.c_void_p(stream) if stream else None))
+
+    def _chk(self, rc, allow=(STATUS_OK,)):
+        if rc not in allow:
+            raise NemGpuError("nemgpu call failed (status %d): %s" % (rc, self.lib.nemgpu_last_error().decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.nemgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_matrix(self, x):
+        x = np.ascontiguousarray(x, np.uint8)
+        assert x.shape == (self.n, self.d)
+        self._chk(self.lib.nemgpu_set_matrix_bytes(self._h, _vp(x)))
+
+    def set_matrix_bits(self, bits):
+        bits = np.ascontiguousarray(bits, np.uint32)
+        assert bits.shape == (self.n, (self.d + 31) // 32)
+        self._chk(self.lib.nemgpu_set_matrix_bits(self._h, _vp(bits)))
+
+    def set_graph(self, nei):
+        if nei is None:
+            ptr = np.zeros(self.n + 1, np.int32)
+            idx = np.zeros(1, np.int32)
+            w = np.zeros(1, np.float32)
+        else:
+            ptr, idx, w = (np.ascontiguousarray(nei[0], np.int32), np.ascontiguousarray(nei[1], np.int32),
+                           np.ascontiguousarray(nei[2], np.float32))
+        self._chk(self.lib.nemgpu_set_graph(self._h, _vp(ptr), _vp(idx), _vp(w)))
+
+    def set_params(self, prop, center, disp):
+        prop = np.ascontiguousarray(prop, np.float32)
+        center = np.ascontiguousarray(center, np.float32).reshape(self.k, self.d)
+        disp = np.ascontiguousarray(disp, np.float32).reshape(self.k, self.d)
+        self._chk(self.lib.nemgpu_set_params(self._h, _vp(prop), _vp(center), _vp(disp)))
+
+    def configure(self, algo="ncem", beta=0.5, disper="sk_", propor="pk", cvtest="clas", cvthres=1e-8,
+                  it_max=100, param_fix=False, tie="hash", seed=0):
+        self.cfg = Config(ALGO[algo], beta, DISP[disper], PROP[propor], CVT[cvtest], cvthres, it_max,
+                          int(param_fix), TIE[tie], seed)
+        self._chk(self.lib.nemgpu_configure(self._h, C.byref(self.cfg)))
+
+    # ---- whole run / steps
+    def _result(self, r):
+        return dict(status=r.status, iters=r.iters, converged=bool(r.converged), emptyk=r.emptyk,
+                    n_zero_density=r.zero_density_sites, first_zero_density_site=r.first_zero_density_site,
+                    sweep_rounds=r.sweep_rounds, crit=np.array(list(r.crit), np.float32),
+                    loop_seconds=r.loop_seconds)
+
+    def run(self):
+        r = Result()
+        self._chk(self.lib.nemgpu_run(self._h, C.byref(r)))
+        out = self._result(r)
+        out.update(self.results())
+        return out
+
+    def init_partition(self):
+        self._chk(self.lib.nemgpu_init_partition(self._h))
+
+    def iterate(self, n_iters):
+        r = Result()
+        self._chk(self.lib.nemgpu_iterate(self._h, int(n_iters), C.byref(r)))
+        return self._result(r)
+
+    def reset(self):
+        self._chk(self.lib.nemgpu_reset(self._h))
+
+    def density(self):
+        self._chk(self.lib.nemgpu_density(self._h))
+        pk = np.zeros((self.n, self.k), np.float64)
+        lp = np.zeros((self.n, self.k), np.float32)
+        self._chk(self.lib.nemgpu_get_density(self._h, _vp(pk), _vp(lp)))
+        return pk, lp
+
+    def sweep(self, beta):
+        rounds = C.c_int(0)
+        self._chk(self.lib.nemgpu_sweep(self._h, C.c_float(beta), C.byref(rounds)))
+        return rounds.value
+
+    def mstep(self):
+        ek = C.c_int(0)
+        rc = self._chk(self.lib.nemgpu_mstep(self._h, C.byref(ek)), allow=(STATUS_OK, STATUS_W_EMPTYCLASS))
+        return rc, ek.value
+
+    def criteria(self):
+        out = (C.c_float * 6)()
+        self._chk(self.lib.nemgpu_criteria(self._h, out))
+        return np.array(list(out), np.float32)
+
+    def set_partition(self, c):
+        c = np.ascontiguousarray(c, np.float32)
+        assert c.shape == (self.n_total, self.k)
+        self._chk(self.lib.nemgpu_set_partition(self._h, _vp(c)))
+
+    # ---- outputs
+    def partition(self):
+        c = np.zeros((self.n, self.k), np.float32)
+        self._chk(self.lib.nemgpu_get_partition(self._h, _vp(c)))
+        return c
+
+    def labels(self):
+        lab = np.zeros(self.n, np.uint8)
+        self._chk(self.lib.nemgpu_get_labels(self._h, _vp(lab)))
+        return lab
+
+    def params(self):
+        prop = np.zeros(self.k, np.float32)
+        center = np.zeros((self.k, self.d), np.float32)
+        disp = np.zeros((self.k, self.d), np.float32)
+        nk = np.zeros(self.k, np.float32)
+        self._chk(self.lib.nemgpu_get_params(self._h, _vp(prop), _vp(center), _vp(disp), _vp(nk)))
+        return dict(prop=prop, center=center, disp=disp, nbobs_k=nk)
+
+    def results(self):
+        out = self.params()
+        out["c"] = self.partition()
+        return out
+
+    def profile(self, on=True):
+        self._chk(self.lib.nemgpu_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n, b = C.c_double(0), C.c_int(0), C.c_double(0)
+        self._chk(self.lib.nemgpu_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return dict(density_ms_avg=ms.value, density_launches=n.value, algorithmic_bytes_per_launch=b.value)
+
+
+def solve(x, nei, k, prop, center, disp, device=0, **cfg):
+    """Convenience: build an engine, run the whole EM, return full-precision results."""
+    n, d = x.shape
+    eng = NemEngine(n, d, k, device=device)
+    try:
+        eng.set_matrix(x)
+        eng.set_graph(nei)
+        eng.set_params(prop, center, disp)
+        eng.configure(**cfg)
+        return eng.run()
+    finally:
+        eng.close()

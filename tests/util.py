@@ -1,0 +1,45 @@
+import numpy as np
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    if a.dtype == np.float64:
+        return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    return np.array_equal(a, b)
+
+
+def maxdiff(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(a - b)
+    d = np.where(np.isnan(a) & np.isnan(b), 0.0, d)
+    d = np.where(np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)), 0.0, d)
+    return float(np.nanmax(d)) if d.size else 0.0
+
+
+def ulp_diff64(a, b):
+    """max distance in units in the last place between two float64 arrays (finite entries)."""
+    a = np.ascontiguousarray(a, np.float64).view(np.int64)
+    b = np.ascontiguousarray(b, np.float64).view(np.int64)
+    return int(np.max(np.abs(a - b))) if a.size else 0
+
+
+def random_fuzzy_partition(n, k, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.random((n, k)).astype(np.float32) ** 3
+    c /= c.sum(axis=1, keepdims=True)
+    return c.astype(np.float32)
+
+
+def random_hard_partition(n, k, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lab = rng.integers(0, k, size=n)
+    c = np.zeros((n, k), np.float32)
+    c[np.arange(n), lab] = 1.0
+    return c
