@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the NEM hot path (BASELINE.json metric:
+"EM iterations/sec + families x organisms/sec at K=3; HBM GB/s vs roofline").
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one EM iteration (M-step + E-step + convergence test; one pass of the reference loop
+nem_alg.c:1789-1840) over the whole presence/absence matrix.  The workload is BASELINE.json
+configs[1] per GPU (20 000 families x 500 organisms, K=3, beta=0.5 with a contiguity graph,
+ncem / sk_ / pk exactly as ppanggolin.py:1769-1826 calls nem()).  Inputs are resident in HBM
+before the timed region.  The timed region restarts the EM from the initial parameters every
+`cycle` iterations (cycle = the iterations this workload needs to converge), so the timed steps
+are real pre-convergence iterations; the restart (reset + the two initial sweeps) is inside the
+timed region and is NOT counted as steps.
+
+For N > 1 (one process per GPU, torch.distributed / RCCL): families are sharded in contiguous
+blocks, every rank holds configs[1]-sized shard (weak scaling); per iteration one all-reduce of
+the integer M-step statistics and one all-gather of the labels per relaxation round.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pangenomenem_amd import build as nem_build  # noqa: E402
+from pangenomenem_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--families", type=int, default=20000, help="families per GPU")
+    ap.add_argument("--organisms", type=int, default=500)
+    ap.add_argument("--algo", default="ncem")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="reference iterations timed for the CPU baseline")
+    return ap.parse_args()
+
+
+def cpu_baseline(x, nei, prop, center, disp, beta, algo, iters):
+    """Time the CPU checker on THIS host, 1 core: the compiled reference (oracle/_ref) when it is
+    there, else the plain-C port (oracle/nem_oracle.c).  Bounded sample: the same workload, `iters`
+    iterations with the convergence test off, minus a 0-iteration run (sort index + initial sweeps)."""
+    from oracle import pyoracle
+    n, d = x.shape
+    if pyoracle.have_reference():
+        ref = pyoracle.Reference()
+        t0 = ref.classify(x, nei, 3, prop, center, disp, algo=algo, beta=beta, cvtest="none", it_max=0)["seconds"]
+        t1 = ref.classify(x, nei, 3, prop, center, disp, algo=algo, beta=beta, cvtest="none", it_max=iters)["seconds"]
+        per_it = max(t1 - t0, 1e-9) / iters
+        kind = "reference"
+    else:
+        orc = pyoracle.Oracle()
+        per_it = orc.run(x, nei, 3, prop, center, disp, algo=algo, beta=beta, cvtest="none", it_max=iters,
+                         tie="hash")["loop_seconds"] / iters
+        kind = "port"
+    return dict(value=n * d / per_it, unit="cells/s", cores=1, kind=kind,
+                sample="%d EM iterations of the same %dx%d workload, convergence test off, loop time only "
+                       "(%.3f s/iteration); host has %d cores" % (iters, n, d, per_it, os.cpu_count() or 0),
+                em_iterations_per_sec=1.0 / per_it)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    nem_build.build()
+    n_loc, d, k, beta = args.families, args.organisms, 3, 0.5
+    n_tot = n_loc * world
+
+    if world == 1:
+        from pangenomenem_amd.engine import NemEngine
+        x, _ = synth.bernoulli_pa_matrix(n_tot, d, 2)
+        nei = synth.contiguity_graph(n_tot, 2)
+        prop, center, disp = synth.default_init(d)
+        eng = NemEngine(n_tot, d, k, device=0)
+        eng.set_matrix(x)
+        eng.set_graph(nei)
+        eng.set_params(prop, center, disp)
+        # how many iterations does this workload need?  (reference call: clas, 1e-8, it_max 100)
+        eng.configure(algo=args.algo, beta=beta, disper="sk_", propor="pk", cvtest="clas", cvthres=1e-8, it_max=100)
+        first = eng.run()
+        # restart period of the timed loop: at least 5 iterations (what the reference needs on this
+        # config per SURVEY.md §6) so the restart overhead is amortised the way a real solve amortises it
+        cycle = max(5, int(first["iters"]))
+        eng.configure(algo=args.algo, beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)
+
+        def run_steps(count):
+            done = 0
+            rounds = 0
+            while done < count:
+                m = min(cycle, count - done)
+                eng.reset()
+                eng.init_partition()
+                rounds += eng.iterate(m)["sweep_rounds"]
+                done += m
+            return rounds
+
+        run_steps(args.warmup)
+        eng.profile(True)
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        elapsed = time.perf_counter() - t0          # iterate() synchronises the stream before returning
+        prof = eng.profile_read()
+        eng.profile(False)
+        dt_max = elapsed
+        extra = dict(iters_to_converge=int(first["iters"]))
+    else:
+        from pangenomenem_amd import distributed as nd
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        job = nd.ShardedNem.synthetic(n_loc, d, k, beta, rank, world, local_rank, algo=args.algo)
+        cycle = job.iters_to_converge()
+        job.run_steps(args.warmup, cycle)
+        job.eng.profile(True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job.run_steps(args.steps, cycle)
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        prof = job.eng.profile_read()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        extra = dict(parity_iters_to_converge=cycle)
+        x = nei = None
+
+    if rank == 0:
+        ms_per_step = dt_max * 1e3 / args.steps
+        cells_per_s = n_tot * d * args.steps / dt_max
+        achieved = prof["algorithmic_bytes_per_launch"] / (prof["density_ms_avg"] * 1e-3) / 1e9 \
+            if prof["density_ms_avg"] > 0 else 0.0
+        out = {
+            "metric": "em_family_x_organism_cells_per_sec",
+            "value": cells_per_s,
+            "unit": "cells/s",
+            "em_iterations_per_sec": args.steps / dt_max,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 chains with f64 intermediates (reference arithmetic); int32 popcounts in the M-step",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1] per GPU: %d families x %d organisms, K=3, beta=0.5, contiguity graph "
+                            "(path + 5%% chords, weights 1..8), %s/sk_/pk, default .m init" % (n_loc, d, args.algo),
+                "families_total": n_tot, "organisms": d, "K": k, "beta": beta,
+                "cycle_iterations": cycle,
+                "parallelism": "1 GPU" if world == 1 else "families sharded over %d GPUs; all-reduce(int32 stats) "
+                                                           "per iteration + all-gather(labels) per relaxation round" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_density (E1 Bernoulli log-density chains)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": prof["algorithmic_bytes_per_launch"],
+                "avg_launch_ms": prof["density_ms_avg"],
+                "launches_timed": prof["density_launches"],
+                "whole_iteration_algorithmic_GBps": None,
+            },
+        }
+        # whole-iteration algorithmic traffic (SURVEY.md §8d formula), for context
+        nnz = int(nei[0][-1]) if nei is not None else int(2.1 * n_tot)
+        bytes_iter = 2 * ((d + 31) // 32) * 4 * n_tot + 12 * n_tot * k + (8 * nnz + 4 * k * nnz + 4 * (n_tot + 1)) \
+            + 16 * k * d
+        out["roofline"]["whole_iteration_algorithmic_GBps"] = bytes_iter * args.steps / dt_max / 1e9
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(x, nei, prop, center, disp, beta, args.algo, args.cpu_iters)
+                out["speedup_vs_cpu_baseline"] = cells_per_s / out["cpu_baseline"]["value"]
+            except Exception as exc:   # the checker is optional on the box; the GPU number stands on its own
+                out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 1, "kind": "unavailable",
+                                       "sample": "failed: %r" % (exc,)}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

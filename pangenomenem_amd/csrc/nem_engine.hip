@@ -34,7 +34,7 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 namespace {
 constexpr int kRoundCap = 64;     // relaxation rounds per flag window
-constexpr int kRoundBatch = 3;    // rounds enqueued between host checks
+constexpr int kRoundBatch = 2;    // rounds enqueued between host checks (round 0 + its verification)
 }  // namespace
 
 struct nemgpu_engine {
@@ -57,7 +57,10 @@ struct nemgpu_engine {
     float *fz_s0 = nullptr, *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
     double2* tabT = nullptr;
     double* tabL0 = nullptr;
-    uint32_t *nz0 = nullptr, *nz1 = nullptr;
+    uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
+    double2* uni = nullptr;
+    int* nonuni = nullptr;
+    int table_epoch = 0;
     double* pk = nullptr;
     float* logpk = nullptr;
     double* pkfki = nullptr;
@@ -80,6 +83,7 @@ struct nemgpu_engine {
     int iters = 0, converged = 0, emptyk = 0, status = NEMGPU_OK;
     int zero_density = 0, first_zero = -1, sweep_rounds = 0;
     bool masks_valid = false;
+    bool flags_clean = false;     // MOVED + round window are zero (set by k_density, consumed by a sweep)
 
     // profiling of the E1 kernel
     bool prof = false;
@@ -124,10 +128,21 @@ int ensure_state_buffers(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
+TableArgs table_args(nemgpu_engine* e)
+{
+    TableArgs t;
+    t.K = e->k; t.D = e->d; t.dpad = e->dpad;
+    t.prop = e->prop; t.center = e->center; t.disp = e->disp;
+    t.tabT = e->tabT; t.tabL0 = e->tabL0; t.nz0 = e->nz0; t.nz1 = e->nz1;
+    t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni; t.epoch = e->table_epoch;
+    t.pk = e->pk; t.logpk = e->logpk; t.flags = e->iter_flags();
+    return t;
+}
+
 int do_tables(nemgpu_engine* e)
 {
-    launch_tables(e->k, e->d, e->dpad, e->prop, e->center, e->disp, e->tabT, e->tabL0, e->nz0, e->nz1, e->pk,
-                  e->logpk, e->iter_flags(), e->stream);
+    e->table_epoch++;                                   // stamps this generation of tables (k_tables / k_density)
+    launch_tables(table_args(e), e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -143,9 +158,10 @@ int do_density(nemgpu_engine* e)
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    launch_density(e->xw, e->n, e->npad, e->dpad, e->k, e->tabT, e->tabL0, e->nz0, e->nz1, e->pk, e->logpk, e->pkfki,
-                   e->logpkfki, e->stream);
+    launch_density(table_args(e), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->flags_dev + FLAG_MOVED,
+                   1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
     HIPCHK(hipGetLastError());
+    e->flags_clean = true;
     if (e->prof) {
         HIPCHK(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;
@@ -154,45 +170,86 @@ int do_density(nemgpu_engine* e)
 }
 
 // One full Gauss-Seidel sweep == relaxation rounds until a round changes nothing.
-// On return the new partition is in buffer (cur+1)%3 and `cur` is NOT advanced (the caller commits).
-int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
+// sweep_enqueue() launches the first batch of rounds without waiting; sweep_complete() reads the
+// flags back (one D2H copy + sync), launches more rounds if the batch did not reach the fixed
+// point, and reports whether it had to.  The new partition ends up in buffer (cur+1)%3 and `cur`
+// is NOT advanced (the caller commits).
+struct SweepCtx {
+    SweepArgs a{};
+    bool use_nei = false;
+    int r = 0;           // rounds launched so far
+    int checked = 0;     // rounds whose flags the host has examined
+};
+
+int clear_sweep_flags(nemgpu_engine* e)
+{
+    HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
+    e->flags_clean = true;
+    return NEMGPU_OK;
+}
+
+int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
 {
     const bool ncem = e->ncem();
     const int P = e->cur, Q = (e->cur + 1) % 3, R = (e->cur + 2) % 3;
-    const bool use_nei = e->has_graph && beta != 0.0f;
-    SweepArgs a{};
+    const int r0 = c.r;
+    for (int b = 0; b < count; b++, c.r++) {
+        const int r = c.r;
+        const int gb = (r == 0) ? P : ((r - 1) % 2 == 0 ? Q : R);
+        const int ob = (r % 2 == 0) ? Q : R;
+        if (ncem) { c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[gb]; c.a.lab_out = e->lab[ob]; }
+        else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
+        c.a.flags = e->round_flags(r);
+        c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
+        launch_sweep(c.a, ncem, e->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c)
+{
+    c = SweepCtx();
+    c.use_nei = e->has_graph && beta != 0.0f;
+    SweepArgs& a = c.a;
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
-    a.use_nei = use_nei ? 1 : 0;
+    a.use_nei = c.use_nei ? 1 : 0;
     a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
     a.beta = beta;
     a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = e->sweep_counter++;
+    if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
+    e->flags_clean = false;
+    return sweep_launch_rounds(e, c, c.use_nei ? kRoundBatch : 1);
+}
 
-    int r = 0, done_at = -1;
-    while (done_at < 0) {
-        const int r0 = r;
-        const int batch = use_nei ? kRoundBatch : 1;
-        // a window of flag slots is reused every kRoundCap rounds; clear the slots of this batch
-        for (int b = 0; b < batch; b++)
-            HIPCHK(hipMemsetAsync(e->round_flags(r0 + b), 0, FLAG_ROUND_STRIDE * sizeof(int), e->stream));
-        for (int b = 0; b < batch; b++, r++) {
-            const int gb = (r == 0) ? P : ((r - 1) % 2 == 0 ? Q : R);
-            const int ob = (r % 2 == 0) ? Q : R;
-            if (ncem) { a.lab_old = e->lab[P]; a.lab_guess = e->lab[gb]; a.lab_out = e->lab[ob]; }
-            else { a.c_old = e->cbuf[P]; a.c_guess = e->cbuf[gb]; a.c_out = e->cbuf[ob]; }
-            a.flags = e->round_flags(r);
-            a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
-            launch_sweep(a, ncem, e->stream);
-        }
-        HIPCHK(hipGetLastError());
+// `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
+// batch read a partition that was not final yet and must be redone by the caller).
+int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
+{
+    int done_at = -1;
+    if (extra) *extra = false;
+    for (;;) {
         HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
                               e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        if (!use_nei) { done_at = 0; break; }
-        for (int q = r0; q < r; q++) {
+        if (!c.use_nei) { done_at = 0; break; }
+        for (int q = c.checked; q < c.r; q++) {
             const int* f = e->flags_host + FLAG_ITER_STRIDE + (q % kRoundCap) * FLAG_ROUND_STRIDE;
             if (f[FLAG_CHANGED] == 0) { done_at = q; break; }
         }
+        c.checked = c.r;
+        if (done_at >= 0) break;
+        if (extra) *extra = true;
+        if (c.r % kRoundCap == 0 || c.r % kRoundCap + kRoundBatch > kRoundCap) {
+            // the flag window is about to wrap: every earlier round has been examined, start a clean window
+            // (keeps the parity of r, which selects the ping-pong buffers)
+            HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_ITER_STRIDE, 0, kRoundCap * FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+            while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
+            c.checked = c.r;
+        }
+        int rr = sweep_launch_rounds(e, c, kRoundBatch);
+        if (rr) return rr;
     }
     // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
     const int* f = e->flags_host + FLAG_ITER_STRIDE + (done_at % kRoundCap) * FLAG_ROUND_STRIDE;
@@ -200,10 +257,18 @@ int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
         e->zero_density += f[FLAG_NZERO];
         if (e->first_zero < 0) e->first_zero = e->n_total - f[FLAG_FIRSTZERO];
     }
-    // result: out buffer of round done_at; when done_at is odd (R) it equals Q bit for bit (see k_sweep)
+    // result: the out buffer of round done_at; when that is R it equals Q bit for bit (see k_sweep)
     e->sweep_rounds += done_at + 1;
     if (rounds_out) *rounds_out = done_at + 1;
     return NEMGPU_OK;
+}
+
+int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
+{
+    SweepCtx c;
+    int r = sweep_enqueue(e, beta, c);
+    if (r) return r;
+    return sweep_complete(e, c, rounds_out, nullptr);
 }
 
 int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf)
@@ -240,23 +305,20 @@ int read_iter_flags(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-int clear_iter_flags(nemgpu_engine* e)
-{
-    HIPCHK(hipMemsetAsync(e->flags_dev, 0, FLAG_ITER_STRIDE * sizeof(int), e->stream));
-    return NEMGPU_OK;
-}
-
 // ComputePartitionFromPara(Needinit = 1), nem_alg.c:1967-1981
 int init_partition(nemgpu_engine* e)
 {
     int r;
     if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
     if ((r = ensure_state_buffers(e))) return r;
-    if ((r = clear_iter_flags(e))) return r;
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
     // ClassifM starts as zeros (calloc, nem_exe.c:524-526): the blind beta = 0 sweep never reads it
-    if ((r = do_sweep(e, 0.0f, nullptr))) return r;
+    {   // one round, no neighbour reads: nothing to verify, no host sync needed
+        SweepCtx c;
+        if ((r = sweep_enqueue(e, 0.0f, c))) return r;
+        e->sweep_rounds += 1;
+    }
     e->cur = (e->cur + 1) % 3;
     if ((r = do_sweep(e, e->cfg.beta, nullptr))) return r;
     e->cur = (e->cur + 1) % 3;
@@ -265,36 +327,50 @@ int init_partition(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-// NemAlgo's loop body (nem_alg.c:1789-1840), up to n_iters iterations
+// NemAlgo's loop body (nem_alg.c:1789-1840), up to n_iters iterations.  One host sync per
+// iteration: the convergence bookkeeping is enqueued right behind the first batch of relaxation
+// rounds and redone only if the sweep needed more rounds than that batch.
+int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf)
+{
+    if (e->ncem()) return do_labels_post(e, newbuf, oldbuf);
+    if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
+        launch_conv_fuzzy((size_t)e->n * e->k, e->cbuf[newbuf] + (size_t)e->lo * e->k,
+                          e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stream);
+        HIPCHK(hipGetLastError());
+    }
+    return NEMGPU_OK;
+}
+
 int iterate(nemgpu_engine* e, int n_iters)
 {
     int r;
     for (int it = 0; it < n_iters && !e->converged && e->status == NEMGPU_OK; it++) {
-        if ((r = clear_iter_flags(e))) return r;
         if (!e->cfg.param_fix) {                                   // nem_alg.c:1806
             if ((r = do_mstep(e))) return r;
             if ((r = do_tables(e))) return r;
         }
         if ((r = do_density(e))) return r;
-        int rounds = 0;
-        if ((r = do_sweep(e, e->cfg.beta, &rounds))) return r;     // syncs; iteration flags are in flags_host
+        const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
+        SweepCtx c;
+        if ((r = sweep_enqueue(e, e->cfg.beta, c))) return r;
+        if ((r = post_sweep(e, newbuf, oldbuf))) return r;         // speculative: assumes the batch converges
+        bool extra = false;
+        if ((r = sweep_complete(e, c, nullptr, &extra))) return r; // syncs; all flags are in flags_host
         e->iters++;
         const int ek = e->flags_host[FLAG_EMPTYK];
         if (!e->cfg.param_fix && ek != 0) {                        // nem_alg.c:1831-1838: E-step not run
             e->status = NEMGPU_W_EMPTYCLASS;
             e->emptyk = ek;
+            e->masks_valid = false;
             break;                                                 // partition stays at buffer `cur`
         }
-        const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
-        if (e->ncem()) {
-            if ((r = do_labels_post(e, newbuf, oldbuf))) return r;
-        } else if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
-            launch_conv_fuzzy((size_t)e->n * e->k, e->cbuf[newbuf] + (size_t)e->lo * e->k,
-                              e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stream);
+        if (extra) {                                               // redo the bookkeeping on the final partition
+            HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_MOVED, 0, sizeof(int), e->stream));
+            if ((r = post_sweep(e, newbuf, oldbuf))) return r;
+            if ((r = read_iter_flags(e))) return r;
         }
         e->cur = newbuf;
         if (e->cfg.cvtest == NEMGPU_CV_CLAS) {                     // HasConverged, nem_alg.c:2075-2089
-            if ((r = read_iter_flags(e))) return r;
             const int moved = e->flags_host[FLAG_MOVED];
             if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
             else e->converged = !moved;
@@ -420,6 +496,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     A(dev_alloc(&e->nbobs_k, (size_t)k)); A(dev_alloc(&e->iner, kd));
     A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
     A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
+    A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
+    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k));
     A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
     A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
     A(dev_alloc(&e->mask, (size_t)k * e->nw64));
@@ -440,7 +518,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->xw, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
                     e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
-                    e->nz1, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
+                    e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
                     e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
                     e->crit6_dev, e->crit_lfi, e->crit_lzi};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -576,8 +654,7 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
     HIPCHK(hipStreamSynchronize(e->stream));
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (e->iters == 0) {                                           // nem_alg.c:1845-1851
-        if ((r = clear_iter_flags(e))) return r;
-        if ((r = do_mstep(e))) return r;
+            if ((r = do_mstep(e))) return r;
         if ((r = do_tables(e))) return r;
         if ((r = do_density(e))) return r;
     }
@@ -594,7 +671,6 @@ int nemgpu_density(nemgpu_engine* e)
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     int r;
-    if ((r = clear_iter_flags(e))) return r;
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -619,7 +695,6 @@ int nemgpu_mstep(nemgpu_engine* e, int* emptyk)
     HIPCHK(hipSetDevice(e->device));
     int r;
     if ((r = ensure_state_buffers(e))) return r;
-    if ((r = clear_iter_flags(e))) return r;
     if ((r = do_mstep(e))) return r;
     if ((r = read_iter_flags(e))) return r;
     if (emptyk) *emptyk = e->flags_host[FLAG_EMPTYK];

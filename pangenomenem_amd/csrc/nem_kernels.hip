@@ -87,6 +87,8 @@ __global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
                          const float* __restrict__ center, const float* __restrict__ disp,
                          double2* __restrict__ tabT, double* __restrict__ tabL0,
                          uint32_t* __restrict__ nz0, uint32_t* __restrict__ nz1,
+                         uint32_t* __restrict__ am0, uint32_t* __restrict__ am1,
+                         double2* __restrict__ uni, int* __restrict__ nonuni, int epoch,
                          double* __restrict__ pk, float* __restrict__ logpk, int* __restrict__ flags)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;      // over K * dpad (dpad % 64 == 0)
@@ -94,29 +96,38 @@ __global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
     if (t >= K * dpad) return;
     int k = t / dpad, dd = t - k * dpad;
     double t0 = 0.0, t1 = 0.0, l0 = 0.0;
-    int n0 = 0, n1 = 0;
+    int n0 = 0, n1 = 0, a0 = 0, a1 = 0;
     if (dd < D) {
         float eps = disp[k * D + dd];
         float mu = center[k * D + dd];
         int ad0 = abs((int)(0.0f - mu));
         int ad1 = abs((int)(1.0f - mu));
+        a0 = (ad0 != 0); a1 = (ad1 != 0);
+        bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(disp[k * D]));
         if ((double)eps > kEpsilonD) {
             double l1 = log((double)((1.0f - eps) / eps));
             l0 = log((double)(1.0f - eps));
             t0 = (double)ad0 * l1;
             t1 = (double)ad1 * l1;
+            if (dd == 0) uni[k] = make_double2(l1, l0);
+            if (!isfinite(l1) || !isfinite(l0)) general = true;   // 0 * inf / NaN must propagate as in the reference
         } else {
-            n0 = (ad0 != 0);
-            n1 = (ad1 != 0);
+            n0 = a0; n1 = a1;
+            general = true;
         }
+        // class k may use the uniform-dispersion chain only if every organism agrees (epoch-stamped,
+        // so the word never needs clearing)
+        if (general) nonuni[k] = epoch;
     }
     tabT[t] = make_double2(t0, t1);
     tabL0[t] = l0;
-    uint64_t m0 = __ballot(n0), m1 = __ballot(n1);
+    uint64_t m0 = __ballot(n0), m1 = __ballot(n1), b0 = __ballot(a0), b1 = __ballot(a1);
     if (lane == 0) {
         int w = t >> 5;                                  // word index inside [K][dpad/32]
         nz0[w] = (uint32_t)m0; nz0[w + 1] = (uint32_t)(m0 >> 32);
         nz1[w] = (uint32_t)m1; nz1[w + 1] = (uint32_t)(m1 >> 32);
+        am0[w] = (uint32_t)b0; am0[w + 1] = (uint32_t)(b0 >> 32);
+        am1[w] = (uint32_t)b1; am1[w + 1] = (uint32_t)(b1 >> 32);
     }
     if (dd == 0) {                                       // ComputePkFkiM, nem_alg.c:2262-2271
         double p = (double)prop[k];
@@ -134,52 +145,85 @@ __global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
 // ------------------------------------------------------------------------------------------
 constexpr int DCH = 2048;
 
-__global__ __launch_bounds__(256) void k_density(const uint32_t* __restrict__ xw, int n, int npad, int dpad,
-                                                 const double2* __restrict__ tabT,
-                                                 const double* __restrict__ tabL0,
-                                                 const uint32_t* __restrict__ nz0,
-                                                 const uint32_t* __restrict__ nz1,
-                                                 const double* __restrict__ pk,
-                                                 const float* __restrict__ logpk,
-                                                 double* __restrict__ pkfki, float* __restrict__ logpkfki)
+struct DensityArgs {
+    const uint32_t* xw; int n, npad, dpad, D;
+    const double2* tabT; const double* tabL0; const uint32_t* nz0; const uint32_t* nz1;
+    const uint32_t* am0; const uint32_t* am1; const double2* uni; const int* nonuni; int epoch;
+    const double* pk; const float* logpk;
+    double* pkfki; float* logpkfki;
+    int* zero_flags; int n_zero_flags;
+};
+
+__global__ __launch_bounds__(256) void k_density(DensityArgs a)
 {
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
     const int k = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;        // i < npad by construction
+    const int npad = a.npad, dpad = a.dpad;
     const int W = dpad >> 5;
     float dk = 0.0f;
     uint32_t nul = 0;
+    // the sweep that follows this launch starts from clean flags (MOVED + the relaxation-round window)
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int t = threadIdx.x; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
 
-    for (int d0 = 0; d0 < dpad; d0 += DCH) {
-        const int dn = min(DCH, dpad - d0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < dn; t += 256) {
-            sT[t] = tabT[(size_t)k * dpad + d0 + t];
-            sL[t] = tabL0[(size_t)k * dpad + d0 + t];
-        }
-        __syncthreads();
-        const int w0 = d0 >> 5, wn = dn >> 5;
-        uint32_t xnext = xw[(size_t)w0 * npad + i];
-        for (int w = 0; w < wn; w++) {
+    if (a.nonuni[k] != a.epoch) {
+        // ---- uniform dispersion in this class (sk_, s__, the default .m): the step constants are two
+        // wave-uniform doubles; which organisms mismatch comes from two bit masks per word.
+        const double l1 = a.uni[k].x, l0 = a.uni[k].y;
+        const int wlast = (a.D - 1) >> 5;                // padding organisms must not take a step here
+        uint32_t xnext = a.xw[i];
+        for (int w = 0; w <= wlast; w++) {
             const uint32_t x = xnext;
-            if (w + 1 < wn) xnext = xw[(size_t)(w0 + w + 1) * npad + i];
-            nul |= (x & nz1[k * W + w0 + w]) | (~x & nz0[k * W + w0 + w]);
+            if (w < wlast) xnext = a.xw[(size_t)(w + 1) * npad + i];
+            const uint32_t m = (x & a.am1[k * W + w]) | (~x & a.am0[k * W + w]);
+            const int nb = (w < wlast) ? 32 : (a.D - (wlast << 5));
+            if (nb == 32) {
+#pragma unroll
+                for (int b = 0; b < 32; b++) {
+                    const double add = ((m >> b) & 1u) ? l1 : 0.0;
+                    dk = (float)(((double)dk + add) - l0);       // nem_mod.c:661
+                }
+            } else {
+                for (int b = 0; b < nb; b++) {
+                    const double add = ((m >> b) & 1u) ? l1 : 0.0;
+                    dk = (float)(((double)dk + add) - l0);
+                }
+            }
+        }
+    } else {
+        // ---- general case (skd, s_d, hand-written .m files): per-(k,d) constants staged through LDS
+        for (int d0 = 0; d0 < dpad; d0 += DCH) {
+            const int dn = min(DCH, dpad - d0);
+            __syncthreads();
+            for (int t = threadIdx.x; t < dn; t += 256) {
+                sT[t] = a.tabT[(size_t)k * dpad + d0 + t];
+                sL[t] = a.tabL0[(size_t)k * dpad + d0 + t];
+            }
+            __syncthreads();
+            const int w0 = d0 >> 5, wn = dn >> 5;
+            uint32_t xnext = a.xw[(size_t)w0 * npad + i];
+            for (int w = 0; w < wn; w++) {
+                const uint32_t x = xnext;
+                if (w + 1 < wn) xnext = a.xw[(size_t)(w0 + w + 1) * npad + i];
+                nul |= (x & a.nz1[k * W + w0 + w]) | (~x & a.nz0[k * W + w0 + w]);
 #pragma unroll 8
-            for (int b = 0; b < 32; b++) {
-                const double2 tt = sT[w * 32 + b];
-                const double l0 = sL[w * 32 + b];
-                const double a = ((x >> b) & 1u) ? tt.y : tt.x;
-                dk = (float)(((double)dk + a) - l0);     // nem_mod.c:661
+                for (int b = 0; b < 32; b++) {
+                    const double2 tt = sT[w * 32 + b];
+                    const double l0 = sL[w * 32 + b];
+                    const double add = ((x >> b) & 1u) ? tt.y : tt.x;
+                    dk = (float)(((double)dk + add) - l0);       // nem_mod.c:661
+                }
             }
         }
     }
-    if (i < n) {
+    if (i < a.n) {
         float logfk; double fk;
         if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
         else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
-        pkfki[(size_t)k * npad + i] = pk[k] * fk;                // nem_alg.c:2282
-        logpkfki[(size_t)k * npad + i] = logpk[k] + logfk;       // nem_alg.c:2283
+        a.pkfki[(size_t)k * npad + i] = a.pk[k] * fk;            // nem_alg.c:2282
+        a.logpkfki[(size_t)k * npad + i] = a.logpk[k] + logfk;   // nem_alg.c:2283
     }
 }
 
@@ -216,7 +260,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
                 const int lab = (j < gi) ? a.lab_guess[j] : a.lab_old[j];
 #pragma unroll
                 for (int k = 0; k < KA; k++)
-                    if (k < K) ctx[k] = ctx[k] + ((lab == k) ? wt : 0.0f);   // w*1 = w ; w*0 adds nothing
+                    if (k < K) ctx[k] = ctx[k] + ((lab == k) ? wt : -0.0f);  // w*1 = w ; w*0 is an additive identity
             } else {
                 const float* row = ((j < gi) ? a.c_guess : a.c_old) + (size_t)j * K;
 #pragma unroll
@@ -386,35 +430,69 @@ __global__ void k_mstep_centers_ncem(int K, int D, const int* __restrict__ stats
 // M4/M5: dispersion model + proportions (InerToDisp*, nem_mod.c:965-1174; EstimPara :456-465).
 // MissMode is MISSING_IGNORE for Bernoulli (nem_mod.c:446-448) and N_KD[k][d] == N_K[k] (no NaN).
 // The d- / k-ordered float sums are order-dependent (values exceed 2^24) and stay sequential.
+__device__ inline void seq_sum_pair(const float4* __restrict__ v4, int n4, float nk, float& sn, float& si)
+{
+    // d-ordered float accumulators (InerToDispK_, nem_mod.c:1054-1058); padding entries are -0.0f / handled by caller
+#pragma unroll 4
+    for (int t = 0; t < n4; t++) {
+        const float4 v = v4[t];
+        si = (((si + v.x) + v.y) + v.z) + v.w;
+        sn = (((sn + nk) + nk) + nk) + nk;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, int disper, int propor,
                                                      const float* __restrict__ nbobs_k,
                                                      const float* __restrict__ iner, float* __restrict__ disp,
                                                      float* __restrict__ prop, int* __restrict__ flags)
 {
+    constexpr int CAP = 12288;                           // staged inertia values (48 KB)
+    __shared__ float4 s_in4[CAP / 4];
     __shared__ float s_disp[kMaxKernelK];
     __shared__ int s_valid[kMaxKernelK];
     __shared__ float s_vol;
+    float* s_in = reinterpret_cast<float*>(s_in4);
     const int tid = threadIdx.x;
-    if (disper == NEMGPU_DISP___) {
-        if (tid == 0) {
-            float vol = 0.0f, nobs = 0.0f;
-            for (int k = 0; k < K; k++)
-                if (nbobs_k[k] > 0)
-                    for (int d = 0; d < D; d++) { vol += iner[k * D + d]; nobs += nbobs_k[k]; }
-            s_vol = vol / nobs;
-        }
-        __syncthreads();
-        for (int t = tid; t < K * D; t += 1024) disp[t] = s_vol;
-    } else if (disper == NEMGPU_DISP_K_) {
-        if (tid < K) {
-            const int k = tid;
-            s_valid[k] = 0;
-            if (nbobs_k[k] > 0) {
-                float sn = 0.0f, si = 0.0f;
+    if (disper == NEMGPU_DISP_K_) {
+        // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains.  Classes run on
+        // different waves; a class's D values are staged in LDS (D4 = D rounded down to 4, tail scalar).
+        const int dq = D & ~3;
+        const int per = max(1, min(K, CAP / max(D, 1)));          // classes staged per pass
+        if (per >= 1 && D <= CAP) {
+            for (int k0 = 0; k0 < K; k0 += per) {
+                const int kn = min(per, K - k0);
+                __syncthreads();
+                for (int t = tid; t < kn * D; t += 1024) {
+                    const int kk = t / D, d = t - kk * D;
+                    s_in[kk * ((D + 3) & ~3) + d] = iner[(k0 + kk) * D + d];
+                }
+                __syncthreads();
+                const int wv = tid >> 6;
+                if ((tid & 63) == 0) {
+                    for (int kk = wv; kk < kn; kk += 16) {
+                        const int k = k0 + kk;
+                        const float nk = nbobs_k[k];
+                        s_valid[k] = (nk > 0);
+                        if (nk > 0) {
+                            float sn = 0.0f, si = 0.0f;
+                            const float* base = s_in + kk * ((D + 3) & ~3);
+                            seq_sum_pair(reinterpret_cast<const float4*>(base), dq >> 2, nk, sn, si);
+                            for (int d = dq; d < D; d++) { sn += nk; si += base[d]; }
+                            s_disp[k] = si / sn;
+                        }
+                    }
+                }
+            }
+        } else {                                                   // very wide matrices: straight from global
+            if (tid < K) {
+                const int k = tid;
                 const float nk = nbobs_k[k];
-                for (int d = 0; d < D; d++) { sn += nk; si += iner[k * D + d]; }
-                s_disp[k] = si / sn;
-                s_valid[k] = 1;
+                s_valid[k] = (nk > 0);
+                if (nk > 0) {
+                    float sn = 0.0f, si = 0.0f;
+                    for (int d = 0; d < D; d++) { sn += nk; si += iner[k * D + d]; }
+                    s_disp[k] = si / sn;
+                }
             }
         }
         __syncthreads();
@@ -422,6 +500,21 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
             const int k = t / D;
             if (s_valid[k]) disp[t] = s_disp[k];
         }
+    } else if (disper == NEMGPU_DISP___) {
+        // one (k, d)-ordered chain over all non-empty classes (InerToDisp__, nem_mod.c:988-1007)
+        if (tid == 0) {
+            float vol = 0.0f, nobs = 0.0f;
+            for (int k = 0; k < K; k++) {
+                const float nk = nbobs_k[k];
+                if (nk > 0) {
+#pragma unroll 8
+                    for (int d = 0; d < D; d++) { vol += iner[k * D + d]; nobs += nk; }
+                }
+            }
+            s_vol = vol / nobs;
+        }
+        __syncthreads();
+        for (int t = tid; t < K * D; t += 1024) disp[t] = s_vol;
     } else if (disper == NEMGPU_DISP__D) {
         for (int d = tid; d < D; d += 1024) {
             float sn = 0.0f, si = 0.0f;
@@ -576,7 +669,9 @@ __global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, cons
         const float cik = c[(size_t)i * K + k];
         float pik = 0.0f;
         for (int t = b; t < e; t++) pik = pik + (nei_w[t] * c[(size_t)nei_idx[t] * K + k]);
-        float dv = 0.0f, gv = 0.0f;
+        // entries with cik <= MINFLOAT take no part in D/G (:2727): store -0.0f, the exact additive
+        // identity of IEEE addition (x + -0 == x for every x, including +0, -0, inf and NaN)
+        float dv = -0.0f, gv = -0.0f;
         if (cik > FLT_MIN) {                                              // MINFLOAT, :2727
             const float lp = logpkfki[(size_t)k * npad + i];
             dv = (float)((double)cik * ((double)lp - log((double)cik)));  // :2731
@@ -592,32 +687,44 @@ __global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, cons
 }
 
 // The four accumulators are i-ordered (k inner) float chains: one lane each, fed from LDS-staged
-// chunks.  Entries with cik <= MINFLOAT are skipped, not added as zeros (nem_alg.c:2727-2736).
-__global__ __launch_bounds__(256) void k_crit_reduce(int n, int K, float beta, const float* __restrict__ c,
-                                                     const float* __restrict__ dik, const float* __restrict__ gik,
-                                                     const double* __restrict__ lfi, const double* __restrict__ lzi,
-                                                     float* __restrict__ crit6)
+// chunks.  Entries with cik <= MINFLOAT were stored as -0.0f by k_crit_terms, so adding every entry
+// reproduces the reference's conditional adds (nem_alg.c:2727-2736) bit for bit.
+__global__ __launch_bounds__(256) void k_crit_reduce(int n, int K, float beta, const float* __restrict__ dik,
+                                                     const float* __restrict__ gik, const double* __restrict__ lfi,
+                                                     const double* __restrict__ lzi, float* __restrict__ crit6)
 {
     constexpr int CAP = 4096;                            // staged (site, class) entries per chunk
-    __shared__ float sD[CAP], sG[CAP];
-    __shared__ unsigned char sV[CAP];
+    __shared__ float4 sD4[CAP / 4], sG4[CAP / 4];
     __shared__ double sL[CAP / 2], sZ[CAP / 2];
     __shared__ float fin[4];
+    float* sD = reinterpret_cast<float*>(sD4);
+    float* sG = reinterpret_cast<float*>(sG4);
     const int ch = max(1, min(CAP / K, CAP / 2));        // sites per chunk
     float acc = 0.0f;                                    // lane 0: D, 64: G, 128: L, 192: Z
     for (int i0 = 0; i0 < n; i0 += ch) {
         const int cn = min(ch, n - i0);
+        const int m = cn * K;
         __syncthreads();
-        for (int t = threadIdx.x; t < cn * K; t += 256) {
+        for (int t = threadIdx.x; t < ((m + 3) & ~3); t += 256) {
             const size_t g = (size_t)i0 * K + t;         // row-major (i, k): i outer, k inner
-            sD[t] = dik[g]; sG[t] = gik[g]; sV[t] = (c[g] > FLT_MIN);
+            sD[t] = t < m ? dik[g] : -0.0f;
+            sG[t] = t < m ? gik[g] : -0.0f;
         }
         for (int t = threadIdx.x; t < cn; t += 256) { sL[t] = lfi[i0 + t]; sZ[t] = lzi[i0 + t]; }
         __syncthreads();
-        if (threadIdx.x == 0) { for (int t = 0; t < cn * K; t++) if (sV[t]) acc = acc + sD[t]; }        // :2734
-        else if (threadIdx.x == 64) { for (int t = 0; t < cn * K; t++) if (sV[t]) acc = acc + sG[t]; }  // :2735
-        else if (threadIdx.x == 128) { for (int t = 0; t < cn; t++) acc = (float)((double)acc + sL[t]); } // :2744
-        else if (threadIdx.x == 192) { for (int t = 0; t < cn; t++) acc = (float)((double)acc - sZ[t]); } // :2745
+        if (threadIdx.x == 0) {                                                            // :2734
+#pragma unroll 4
+            for (int t = 0; t < (m + 3) / 4; t++) { const float4 v = sD4[t]; acc = (((acc + v.x) + v.y) + v.z) + v.w; }
+        } else if (threadIdx.x == 64) {                                                    // :2735
+#pragma unroll 4
+            for (int t = 0; t < (m + 3) / 4; t++) { const float4 v = sG4[t]; acc = (((acc + v.x) + v.y) + v.z) + v.w; }
+        } else if (threadIdx.x == 128) {                                                   // :2744
+#pragma unroll 8
+            for (int t = 0; t < cn; t++) acc = (float)((double)acc + sL[t]);
+        } else if (threadIdx.x == 192) {                                                   // :2745
+#pragma unroll 8
+            for (int t = 0; t < cn; t++) acc = (float)((double)acc - sZ[t]);
+        }
     }
     if ((threadIdx.x & 63) == 0) fin[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -640,19 +747,22 @@ void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, in
     hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
 }
 
-void launch_tables(int K, int D, int dpad, const float* prop, const float* center, const float* disp, double2* tabT,
-                   double* tabL0, uint32_t* nz0, uint32_t* nz1, double* pk, float* logpk, int* flags, hipStream_t s)
+void launch_tables(const TableArgs& t, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tables, dim3((K * dpad + 255) / 256), dim3(256), 0, s, K, D, dpad, prop, center, disp, tabT,
-                       tabL0, nz0, nz1, pk, logpk, flags);
+    hipLaunchKernelGGL(k_tables, dim3((t.K * t.dpad + 255) / 256), dim3(256), 0, s, t.K, t.D, t.dpad, t.prop, t.center,
+                       t.disp, t.tabT, t.tabL0, t.nz0, t.nz1, t.am0, t.am1, t.uni, t.nonuni, t.epoch, t.pk, t.logpk,
+                       t.flags);
 }
 
-void launch_density(const uint32_t* xw, int n, int npad, int dpad, int K, const double2* tabT, const double* tabL0,
-                    const uint32_t* nz0, const uint32_t* nz1, const double* pk, const float* logpk, double* pkfki,
-                    float* logpkfki, hipStream_t s)
+void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+                    int* zero_flags, int n_zero_flags, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_density, dim3(npad / 256, K), dim3(256), 0, s, xw, n, npad, dpad, tabT, tabL0, nz0, nz1, pk,
-                       logpk, pkfki, logpkfki);
+    DensityArgs a;
+    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D;
+    a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
+    a.uni = t.uni; a.nonuni = t.nonuni; a.epoch = t.epoch; a.pk = t.pk; a.logpk = t.logpk;
+    a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
+    hipLaunchKernelGGL(k_density, dim3(npad / 256, t.K), dim3(256), 0, s, a);
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
@@ -707,7 +817,7 @@ void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_
 {
     hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, n, K, npad, nei_ptr, nei_idx, nei_w,
                        use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi);
-    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, K, beta, c, dik, gik, lfi, lzi, crit6);
+    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, K, beta, dik, gik, lfi, lzi, crit6);
 }
 
 }  // namespace nemk

@@ -12,8 +12,10 @@ constexpr double kEpsilonD = 1e-20;   // EPSILON, reference nem_typ.h:63
 
 // per-round flag slot of an E2 sweep
 enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_ROUND_STRIDE = 4 };
-// per-iteration flag block
-enum { FLAG_MOVED = 0, FLAG_EMPTYK = 1, FLAG_EMPTY_PROP = 2, FLAG_ITER_STRIDE = 4 };
+// per-iteration flag block.  FLAG_EMPTYK is overwritten by every k_mstep_disp; FLAG_MOVED and the
+// relaxation-round window that follows this block are zeroed by k_density, which precedes every
+// sweep of the EM loop (so no memset launches are needed).
+enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 4 };
 
 struct SweepArgs {
     int n_local, lo, n_total, K, npad, use_nei;
@@ -31,11 +33,17 @@ struct SweepArgs {
 
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
                    hipStream_t s);
-void launch_tables(int K, int D, int dpad, const float* prop, const float* center, const float* disp, double2* tabT,
-                   double* tabL0, uint32_t* nz0, uint32_t* nz1, double* pk, float* logpk, int* flags, hipStream_t s);
-void launch_density(const uint32_t* xw, int n, int npad, int dpad, int K, const double2* tabT, const double* tabL0,
-                    const uint32_t* nz0, const uint32_t* nz1, const double* pk, const float* logpk, double* pkfki,
-                    float* logpkfki, hipStream_t s);
+// per-(class, organism) density constants, produced by k_tables and consumed by k_density
+struct TableArgs {
+    int K, D, dpad;
+    const float* prop; const float* center; const float* disp;
+    double2* tabT; double* tabL0; uint32_t* nz0; uint32_t* nz1;   // general path
+    uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni; int epoch;   // uniform-dispersion path
+    double* pk; float* logpk; int* flags;
+};
+void launch_tables(const TableArgs& t, hipStream_t s);
+void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+                    int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
                         uint64_t* mask, int* flags, hipStream_t s);
