@@ -151,6 +151,25 @@ int nemgpu_get_partition(nemgpu_engine* e, float* c_nk);
 int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels);
 int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k);
 int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk);
+/* ------------------------------------------------------------------------------------------
+ * 3. File layer (host only; what nem() uses on either side of the engine).  Readers follow
+ *    ReadStrFile / ReadMatrixFile / ReadPtsNeighs / ReadParamFile (nem_exe.c:739-1091, 1278-1478),
+ *    writers follow SaveResults (nem_exe.c:1596-1781).  Return values are StatusET codes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nemio_inputs nemio_inputs;
+/* Parse <Fname>.str/.dat/.nei/.m for nk classes. */
+int nemio_read(const char* Fname, int nk, nemio_inputs** out);
+void nemio_free(nemio_inputs* in);
+/* sizes: n families, d organisms, nnz neighbour entries, max_neighs, param_mode (1 init / 2 fixed), type 'S'|'N' */
+int nemio_sizes(const nemio_inputs* in, int* n, int* d, int* nnz, int* max_neighs, int* param_mode, int* type);
+/* copy out: xbits [n * ceil(d/32)], nei_ptr [n+1], nei_idx/nei_w [nnz], prop [k], center/disp [k*d]; NULL skips */
+int nemio_copy(const nemio_inputs* in, uint32_t* xbits, int32_t* nei_ptr, int32_t* nei_idx, float* nei_w,
+               float* prop, float* center, float* disp);
+int nemio_write_uf(const char* path, const float* c_nk, int n, int k);
+int nemio_write_cf(const char* path, const float* c_nk, int n, int k, int tie_rule, uint32_t seed);
+int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, int k, const float* center,
+                   const float* prop, const float* disp);
+
 /* Kernel timing probe for bench.py: average duration (ms) of the E1 density kernel over the
    launches since the last call, measured with hipEvents on the engine's stream. */
 int nemgpu_profile_enable(nemgpu_engine* e, int on);

@@ -244,3 +244,75 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     lg.close();
     return ret;
 }
+
+// ============================================================================================
+// file layer C ABI (host only)
+// ============================================================================================
+struct nemio_inputs {
+    NemInputs in;
+    int k = 0;
+};
+
+extern "C" {
+
+int nemio_read(const char* Fname, int nk, nemio_inputs** out)
+{
+    if (!Fname || !out || nk <= 0) return NEMGPU_E_FUNCARG;
+    *out = nullptr;
+    nemio_inputs* h = new nemio_inputs();
+    h->k = nk;
+    const std::string base = std::string(Fname).substr(0, 200);
+    std::string err;
+    int sts = read_str_file(base, h->in, err);
+    if (sts == NEMGPU_OK) sts = read_dat_file(base, h->in, err);
+    if (sts == NEMGPU_OK) sts = read_param_file(base, nk, h->in, err);
+    if (sts == NEMGPU_OK) {
+        if (h->in.type != 'N') sts = read_nei_file(base, h->in, err);
+        else h->in.nei_ptr.assign(h->in.n + 1, 0);
+    }
+    if (sts != NEMGPU_OK) { set_error(err); delete h; return sts; }
+    *out = h;
+    return NEMGPU_OK;
+}
+
+void nemio_free(nemio_inputs* in) { delete in; }
+
+int nemio_sizes(const nemio_inputs* h, int* n, int* d, int* nnz, int* max_neighs, int* param_mode, int* type)
+{
+    if (!h) return NEMGPU_E_FUNCARG;
+    if (n) *n = h->in.n;
+    if (d) *d = h->in.d;
+    if (nnz) *nnz = (int)h->in.nei_idx.size();
+    if (max_neighs) *max_neighs = h->in.max_neighs;
+    if (param_mode) *param_mode = h->in.param_mode;
+    if (type) *type = h->in.type;
+    return NEMGPU_OK;
+}
+
+int nemio_copy(const nemio_inputs* h, uint32_t* xbits, int32_t* nei_ptr, int32_t* nei_idx, float* nei_w, float* prop,
+               float* center, float* disp)
+{
+    if (!h) return NEMGPU_E_FUNCARG;
+    const NemInputs& in = h->in;
+    if (xbits) memcpy(xbits, in.xbits.data(), in.xbits.size() * sizeof(uint32_t));
+    if (nei_ptr) memcpy(nei_ptr, in.nei_ptr.data(), in.nei_ptr.size() * sizeof(int32_t));
+    if (nei_idx && !in.nei_idx.empty()) memcpy(nei_idx, in.nei_idx.data(), in.nei_idx.size() * sizeof(int32_t));
+    if (nei_w && !in.nei_w.empty()) memcpy(nei_w, in.nei_w.data(), in.nei_w.size() * sizeof(float));
+    if (prop) memcpy(prop, in.prop.data(), in.prop.size() * sizeof(float));
+    if (center) memcpy(center, in.center.data(), in.center.size() * sizeof(float));
+    if (disp) memcpy(disp, in.disp.data(), in.disp.size() * sizeof(float));
+    return NEMGPU_OK;
+}
+
+int nemio_write_uf(const char* path, const float* c, int n, int k) { return write_uf_file(path, c, n, k); }
+int nemio_write_cf(const char* path, const float* c, int n, int k, int tie_rule, uint32_t seed)
+{
+    return write_cf_file(path, c, n, k, tie_rule, seed);
+}
+int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, int k, const float* center,
+                   const float* prop, const float* disp)
+{
+    return write_mf_file(path, crit6, beta, d, k, center, prop, disp);
+}
+
+}  // extern "C"

@@ -73,6 +73,14 @@ def load_library():
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
     lib.nemgpu_profile_enable.argtypes = [vp, C.c_int]
     lib.nemgpu_profile_read.argtypes = [vp, C.POINTER(C.c_double), ip, C.POINTER(C.c_double)]
+    lib.nemio_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.nemio_free.argtypes = [vp]
+    lib.nemio_free.restype = None
+    lib.nemio_sizes.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    lib.nemio_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nemio_write_uf.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    lib.nemio_write_cf.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_uint32]
+    lib.nemio_write_mf.argtypes = [C.c_char_p, fp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     lib.nem.restype = C.c_int
     lib.nem.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_float, C.c_char_p, C.c_float, C.c_char_p, C.c_int,
                         C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
@@ -248,3 +256,45 @@ def solve(x, nei, k, prop, center, disp, device=0, **cfg):
         return eng.run()
     finally:
         eng.close()
+
+
+# ---- file layer (host only) -------------------------------------------------------------------
+def read_inputs(fname, nk):
+    """Parse <fname>.str/.dat/.nei/.m with the library's readers.  Returns a dict of numpy arrays."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.nemio_read(fname.encode() if isinstance(fname, str) else fname, int(nk), C.byref(h))
+    if rc != 0:
+        raise NemGpuError("nemio_read failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
+    try:
+        n, d, nnz, mx, pm, ty = (C.c_int() for _ in range(6))
+        lib.nemio_sizes(h, C.byref(n), C.byref(d), C.byref(nnz), C.byref(mx), C.byref(pm), C.byref(ty))
+        n, d, nnz = n.value, d.value, nnz.value
+        wf = (d + 31) // 32
+        xbits = np.zeros((n, wf), np.uint32)
+        ptr = np.zeros(n + 1, np.int32)
+        idx = np.zeros(max(nnz, 1), np.int32)
+        w = np.zeros(max(nnz, 1), np.float32)
+        prop = np.zeros(nk, np.float32)
+        center = np.zeros((nk, d), np.float32)
+        disp = np.zeros((nk, d), np.float32)
+        lib.nemio_copy(h, _vp(xbits), _vp(ptr), _vp(idx), _vp(w), _vp(prop), _vp(center), _vp(disp))
+        x = ((xbits[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(n, wf * 32)[:, :d]
+        return dict(n=n, d=d, x=x.astype(np.uint8), xbits=xbits, nei=(ptr, idx[:nnz], w[:nnz]), max_neighs=mx.value,
+                    param_mode=pm.value, type=chr(ty.value), prop=prop, center=center, disp=disp)
+    finally:
+        lib.nemio_free(h)
+
+
+def write_uf(path, c):
+    c = np.ascontiguousarray(c, np.float32)
+    return load_library().nemio_write_uf(path.encode(), _vp(c), c.shape[0], c.shape[1])
+
+
+def write_mf(path, crit6, beta, center, prop, disp):
+    center = np.ascontiguousarray(center, np.float32)
+    disp = np.ascontiguousarray(disp, np.float32)
+    prop = np.ascontiguousarray(prop, np.float32)
+    k, d = center.shape
+    crit = (C.c_float * 6)(*[float(v) for v in crit6])
+    return load_library().nemio_write_mf(path.encode(), crit, C.c_float(beta), d, k, _vp(center), _vp(prop), _vp(disp))

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs only where /root/reference exists (this container).  It compiles the reference C sources
+where they lie (oracle/Makefile, target `ref` -> oracle/_ref/libnem_ref.so) and records, for a
+set of small seeded problems,
+  * the inputs (bit-packed matrix, CSR graph, initial parameters, call arguments),
+  * the reference's full-precision results from ClassifyByNem (oracle/ref_harness.c:ref_classify):
+    posteriors, centres, dispersions, proportions, class sizes, criteria, iteration count, status,
+  * for the file-level cases, the text of the reference's own `.uf` and `.mf` written by nem()
+    (nem_exe.c:239) from the five ASCII input files.
+A fixture is data only: inputs and expected outputs.  No reference source text is stored.
+
+    python tests/golden/make_golden.py
+"""
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle  # noqa: E402
+from pangenomenem_amd import nemfiles, synth  # noqa: E402
+
+SEED_LIBC = 12345
+
+
+def case_list():
+    cases = []
+
+    def add(name, x, nei, k, prop, center, disp, files=False, **cfg):
+        base = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", cvtest="clas", cvthres=1e-8, it_max=100,
+                    param_fix=False)
+        base.update(cfg)
+        cases.append(dict(name=name, x=x, nei=nei, k=k, prop=prop, center=center, disp=disp, files=files, cfg=base))
+
+    # BASELINE configs[0]: 15 organisms x ~2k families, K=3, beta=0, no MRF
+    x, _ = synth.bernoulli_pa_matrix(2048, 15, 1)
+    nei = synth.contiguity_graph(2048, 1)
+    p, c, d = synth.default_init(15)
+    add("c1_beta0_ncem_sk", x, None, 3, p, c, d, files=True, beta=0.0)
+    add("c1_path_ncem_sk", x, nei, 3, p, c, d, files=True, beta=0.5)
+    add("c1_path_nem_sk", x, nei, 3, p, c, d, files=True, algo="nem", it_max=25)
+    add("c1_path_nem_skd", x, nei, 3, p, c, d, algo="nem", disper="skd", it_max=25)
+    add("c1_path_nem_s__", x, nei, 3, p, c, d, algo="nem", disper="s__", it_max=25)
+    add("c1_path_nem_s_d", x, nei, 3, p, c, d, algo="nem", disper="s_d", it_max=25)
+    add("c1_path_ncem_pequal", x, nei, 3, p, c, d, propor="p_")
+    add("c1_path_ncem_fixed", x, nei, 3, p, c, d, param_fix=True, it_max=5)
+    add("c1_path_ncem_itmax0", x, nei, 3, p, c, d, it_max=0)
+    add("c1_path_nem_nocv", x, nei, 3, p, c, d, algo="nem", cvtest="none", it_max=7)
+
+    # wider matrix, heavier graph weights, free dispersion (eps = 0 appears under skd + ncem)
+    x2, _ = synth.bernoulli_pa_matrix(1200, 70, 7)
+    nei2 = synth.contiguity_graph(1200, 7, chord_frac=0.2)
+    p2, c2, d2 = synth.default_init(70)
+    add("w70_ncem_skd", x2, nei2, 3, p2, c2, d2, disper="skd")
+    add("w70_nem_skd_beta1", x2, nei2, 3, p2, c2, d2, algo="nem", disper="skd", beta=1.0, it_max=20)
+
+    # K sweep with a K-class .m (BASELINE configs[4], down-scaled)
+    xg, _ = synth.grouped_pa_matrix(1500, 60, 5, groups=10)
+    neig = synth.contiguity_graph(1500, 5)
+    for k in (2, 5, 10):
+        pk, ck, dk = synth.kclass_init(xg, k)
+        add("k%d_ncem_skd" % k, xg, neig, k, pk, ck, dk, disper="skd")
+        add("k%d_nem_skd" % k, xg, neig, k, pk, ck, dk, algo="nem", disper="skd", it_max=12)
+
+    # D >= 1100: exp(-dk) underflows double for every class -> uniform posteriors
+    xu, _ = synth.bernoulli_pa_matrix(200, 1150, 9)
+    pu, cu, du = synth.default_init(1150)
+    add("underflow_d1150_nem", xu, None, 3, pu, cu, du, algo="nem", beta=0.0, it_max=3)
+
+    # empty class: everything looks persistent -> the shell/cloud classes lose their members
+    xe = np.ones((300, 20), np.uint8)
+    xe[::7, 3] = 0
+    pe, ce, de = synth.default_init(20)
+    add("empty_class", xe, synth.contiguity_graph(300, 3), 3, pe, ce, de)
+
+    # exact ties: two identical classes -> every site ties; the reference breaks them with random()
+    xt, _ = synth.bernoulli_pa_matrix(400, 12, 4)
+    pt = np.array([0.5, 0.5], np.float32)
+    ct = np.tile(np.full(12, 1.0, np.float32), (2, 1))
+    dt = np.full((2, 12), 0.3, np.float32)
+    add("ties_two_equal_classes", xt, synth.contiguity_graph(400, 4), 2, pt, ct, dt, it_max=3)
+    return cases
+
+
+def main():
+    pyoracle.build(ref=True)
+    ref = pyoracle.Reference()
+    manifest = []
+    for case in case_list():
+        name, x, nei, k, cfg = case["name"], case["x"], case["nei"], case["k"], case["cfg"]
+        n, d = x.shape
+        out = os.path.join(HERE, name)
+        if os.path.isdir(out):
+            shutil.rmtree(out)
+        os.makedirs(out)
+        r = ref.classify(x, nei, k, case["prop"], case["center"], case["disp"], algo=cfg["algo"], beta=cfg["beta"],
+                         disper=cfg["disper"], propor=cfg["propor"], cvtest=cfg["cvtest"], cvthres=cfg["cvthres"],
+                         it_max=cfg["it_max"], param_fix=cfg["param_fix"], seed=SEED_LIBC)
+        ptr, idx, w = nei if nei is not None else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        np.savez_compressed(os.path.join(out, "inputs.npz"), xbits=np.packbits(x, axis=1, bitorder="little"), n=n, d=d,
+                            k=k, has_graph=nei is not None, nei_ptr=ptr, nei_idx=idx, nei_w=w, prop=case["prop"],
+                            center=case["center"], disp=case["disp"])
+        np.savez_compressed(os.path.join(out, "expected.npz"), c=r["c"], prop=r["prop"], center=r["center"],
+                            disp=r["disp"], nbobs_k=r["nbobs_k"], crit=r["crit"], iters=r["iters"],
+                            status=r["status"], converged=r["converged"], zero_density=r["zero_density"])
+        meta = dict(name=name, n=n, d=d, k=k, cfg=cfg, libc_seed=SEED_LIBC, status=int(r["status"]),
+                    iters=int(r["iters"]), converged=bool(r["converged"]), files=case["files"])
+        if case["files"]:
+            tmp = tempfile.mkdtemp(prefix="nemgold_")
+            base = nemfiles.write_nem_inputs(tmp, x, nei, case["prop"], case["center"], case["disp"],
+                                             flag=2 if cfg["param_fix"] else 1)
+            rc = ref.nem(base, k, algo=cfg["algo"].encode(), beta=cfg["beta"], convergence=cfg["cvtest"].encode(),
+                         convergence_th=cfg["cvthres"], format=b"fuzzy", it_max=cfg["it_max"], dolog=1,
+                         proportion=cfg["propor"].encode(), dispersion=cfg["disper"].encode(), init_mode=2)
+            meta["nem_rc"] = int(rc)
+            for ext in ("uf", "mf"):
+                with open(base + "." + ext, "rb") as f, open(os.path.join(out, "ref_%s.txt.gz" % ext), "wb") as raw:
+                    with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as g:
+                        g.write(f.read())
+            shutil.rmtree(tmp)
+        with open(os.path.join(out, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        manifest.append(meta)
+        print("%-28s n=%5d d=%5d k=%2d status=%d iters=%3d converged=%s" % (name, n, d, k, r["status"], r["iters"],
+                                                                          r["converged"]))
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""CPU-side checks of the C-ABI library: it builds for gfx950, loads, exports every symbol that
+include/*.h declares, fails loudly without a GPU, and its host-only file layer reproduces the
+reference's text formats (no kernel is launched in this file)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.golden_util import case_names, load_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pangenomenem_amd import build, engine
+    build.build()
+    return engine.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nem_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(nemgpu_[a-z0-9_]+|nemio_[a-z0-9_]+|nem)\s*\(", text))
+    return sorted(names)
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert "nem" in names and "nemgpu_run" in names and len(names) > 25
+    for name in names:
+        assert hasattr(lib, name), "symbol %s declared in include/nem_mi355x.h is not exported" % name
+
+
+def test_reference_signature_of_nem(lib):
+    """13 arguments, same order and C types as nem_exe.h:23-35."""
+    text = open(os.path.join(ROOT, "include", "nem_mi355x.h")).read()
+    m = re.search(r"int nem\((.*?)\);", text, flags=re.S)
+    args = [a.strip() for a in m.group(1).split(",")]
+    assert [a.split()[-1] for a in args] == ["Fname", "nk", "algo", "beta", "convergence", "convergence_th", "format",
+                                            "it_max", "dolog", "model_family", "proportion", "dispersion", "init_mode"]
+    assert [" ".join(a.split()[:-1]) for a in args] == ["const char*", "const int", "const char*", "const float",
+                                                        "const char*", "const float", "const char*", "const int",
+                                                        "const int", "const char*", "const char*", "const char*",
+                                                        "const int"]
+
+
+def test_python_module_keeps_reference_keywords():
+    """nem.pyx:2-14 keyword names, as ppanggolin.py:1814-1826 passes them."""
+    import inspect
+    import nem as nem_module
+    from pangenomenem_amd.nem import nem
+    assert nem_module.nem is nem
+    assert list(inspect.signature(nem).parameters) == ["Fname", "nk", "algo", "beta", "convergence", "convergence_th",
+                                                       "format", "it_max", "dolog", "model_family", "proportion",
+                                                       "dispersion", "init_mode"]
+
+
+def test_no_gpu_means_loud_failure(lib):
+    from pangenomenem_amd import engine
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(engine.NemGpuError) as ei:
+        engine.NemEngine(100, 10, 3)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/: the
+    package must not import, include, link or dlopen anything from it."""
+    pkg = os.path.join(ROOT, "pangenomenem_amd")
+    bad = re.compile(r"^\s*(from|import)\s+oracle\b|pyoracle|libnem_oracle|libnem_ref|#\s*include\s+\"[^\"]*oracle",
+                     re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(text), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("name", case_names(files_only=True))
+def test_writers_reproduce_reference_text(lib, tmp_path, name):
+    """SaveResults' formats: given the reference's full-precision arrays, our writers emit the
+    reference's .uf and .mf byte for byte."""
+    from pangenomenem_amd import engine
+    case = load_case(name)
+    exp = case["expected"]
+    uf = str(tmp_path / "out.uf")
+    mf = str(tmp_path / "out.mf")
+    assert engine.write_uf(uf, exp["c"]) == 0
+    assert engine.write_mf(mf, exp["crit"], case["cfg"]["beta"], exp["center"], exp["prop"], exp["disp"]) == 0
+    assert open(uf, "rb").read() == case["ref_uf"]
+    assert open(mf, "rb").read() == case["ref_mf"]
+
+
+@pytest.mark.parametrize("name", ["c1_path_ncem_sk", "k5_ncem_skd", "w70_ncem_skd"])
+def test_readers_parse_ppanggolin_style_files(lib, tmp_path, name):
+    from pangenomenem_amd import engine, nemfiles
+    case = load_case(name)
+    base = nemfiles.write_nem_inputs(str(tmp_path), case["x"], case["nei"], case["prop"], case["center"], case["disp"])
+    got = engine.read_inputs(base, case["k"])
+    assert got["n"], got["d"] == case["x"].shape
+    assert np.array_equal(got["x"], case["x"])
+    ptr, idx, w = case["nei"]
+    assert np.array_equal(got["nei"][0], ptr) and np.array_equal(got["nei"][1], idx)
+    assert np.array_equal(got["nei"][2], w)
+    assert got["param_mode"] == 1 and got["type"] == "S"
+    assert np.array_equal(got["center"], case["center"])
+    assert np.array_equal(got["disp"], case["disp"])
+    np.testing.assert_array_equal(got["prop"], case["prop"])
+
+
+def test_reader_quirks_and_errors(lib, tmp_path):
+    from pangenomenem_amd import engine
+    base = str(tmp_path / "q")
+    open(base + ".str", "w").write("# a comment line\n# another\ns 4 3\n")
+    open(base + ".dat", "w").write("1 0 1\n0\t0\t1\n1.0 1 0\n0 0 0\n")
+    # point 2 lists an out-of-range neighbour (dropped) and a zero weight (dropped): the two lists are
+    # compacted independently (ReadPtsNeighs, nem_exe.c:1408-1462)
+    open(base + ".nei", "w").write("# hdr\n1\n1 2 2 3 1.5 2\n2 3 1 9 3 4 0 2.5\n3 0\n4 1 1 0.25\n")
+    open(base + ".m", "w").write("2 0.2 0.3 1 1 1 0.5 0.5 0.5 0 0 0 0.1 0.1 0.1 0.5 0.5 0.5 0.1 0.1 0.1")
+    got = engine.read_inputs(base, 3)
+    assert (got["n"], got["d"], got["param_mode"]) == (4, 3, 2)
+    assert got["x"].tolist() == [[1, 0, 1], [0, 0, 1], [1, 1, 0], [0, 0, 0]]
+    ptr, idx, w = got["nei"]
+    assert ptr.tolist() == [0, 2, 4, 4, 5]
+    assert idx.tolist() == [1, 2, 0, 2, 0] and w.tolist() == [1.5, 2.0, 4.0, 2.5, 0.25]
+    assert got["prop"].tolist() == [np.float32(0.2), np.float32(0.3),
+                                    np.float32(np.float32(np.float32(1) - np.float32(0.2)) - np.float32(0.3))]
+    # short .dat -> STS_E_FILE (7); missing .m values -> STS_E_FILEIN (5); bad flag -> 5
+    open(base + ".dat", "w").write("1 0 1\n0 0\n")
+    with pytest.raises(engine.NemGpuError, match="status 7"):
+        engine.read_inputs(base, 3)
+    open(base + ".dat", "w").write("1 0 1\n0 0 1\n1 1 0\n0 0 0\n")
+    open(base + ".m", "w").write("1 0.2 0.3 1 1 1")
+    with pytest.raises(engine.NemGpuError, match="status 5"):
+        engine.read_inputs(base, 3)
+    open(base + ".dat", "w").write("1 0 2\n0 0 1\n1 1 0\n0 0 0\n")
+    with pytest.raises(engine.NemGpuError, match="0/1"):
+        engine.read_inputs(base, 3)

@@ -1,0 +1,64 @@
+"""Pins the oracle to the compiled, unmodified reference (oracle/_ref) on inputs beyond the committed
+fixtures.  Runs where /root/reference (or a prebuilt oracle/_ref) exists; skipped elsewhere."""
+import numpy as np
+import pytest
+
+from pangenomenem_amd import synth
+from tests.util import bits_equal, random_fuzzy_partition, random_hard_partition
+
+CASES = [
+    (900, 33, 0.5, "ncem", "sk_", "pk", 40),
+    (900, 33, 0.5, "nem", "skd", "pk", 15),
+    (700, 130, 1.5, "nem", "sk_", "p_", 15),
+    (1300, 8, 0.2, "ncem", "s_d", "pk", 40),
+    (500, 257, 0.5, "nem", "s__", "pk", 10),
+]
+
+
+@pytest.mark.parametrize("n,d,beta,algo,disper,propor,it_max", CASES)
+def test_full_loop_bit_exact(oracle, reference, n, d, beta, algo, disper, propor, it_max):
+    x, _ = synth.bernoulli_pa_matrix(n, d, n + d)
+    nei = synth.contiguity_graph(n, n + d, chord_frac=0.1)
+    prop, center, disp = synth.default_init(d)
+    a = oracle.run(x, nei, 3, prop, center, disp, algo=algo, beta=beta, disper=disper, propor=propor, it_max=it_max,
+                   tie="libc", seed=777)
+    b = reference.classify(x, nei, 3, prop, center, disp, algo=algo, beta=beta, disper=disper, propor=propor,
+                           it_max=it_max, seed=777)
+    assert a["status"] == b["status"] and a["iters"] == b["iters"] and a["converged"] == b["converged"]
+    for key in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+        assert bits_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("hard", [True, False])
+@pytest.mark.parametrize("disper", ["s__", "sk_", "s_d", "skd"])
+def test_mstep_bit_exact(oracle, reference, hard, disper):
+    n, d, k = 2500, 48, 4
+    x, _ = synth.grouped_pa_matrix(n, d, 3, groups=4)
+    c = random_hard_partition(n, k, 1) if hard else random_fuzzy_partition(n, k, 1)
+    prop = np.full(k, 0.25, np.float32)
+    center = np.full((k, d), 0.5, np.float32)
+    disp = np.full((k, d), 0.3, np.float32)
+    a = oracle.mstep(x, c, disper, "pk", prop, center, disp)
+    b = reference.estim_para(x, c, disper, "pk", prop, center, disp)
+    assert a["status"] == b["status"] and a["emptyk"] == b["emptyk"]
+    for key in ("prop", "center", "disp", "nbobs_k", "nbobs_kd", "iner"):
+        assert bits_equal(a[key], b[key]), key
+
+
+def test_reference_files_equal_reference_memory(reference, tmp_path):
+    """nem() on the five ASCII files and ClassifyByNem on the in-memory structs agree to the print
+    precision of .uf/.mf -- i.e. our input writer emits what the reference's readers expect."""
+    from pangenomenem_amd import nemfiles
+    n, d = 600, 21
+    x, _ = synth.bernoulli_pa_matrix(n, d, 6)
+    nei = synth.contiguity_graph(n, 6)
+    prop, center, disp = synth.default_init(d)
+    base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
+    rc = reference.nem(base, 3, algo=b"nem", it_max=10)
+    assert rc == 0
+    mem = reference.classify(x, nei, 3, prop, center, disp, algo="nem", it_max=10)
+    uf = np.loadtxt(base + ".uf", dtype=np.float64)
+    assert np.max(np.abs(uf - mem["c"])) <= 5.01e-4
+    labels, params, m_crit, _ = nemfiles.read_nem_outputs(str(tmp_path), d)
+    assert abs(m_crit - mem["crit"][3]) <= 1e-5 * abs(mem["crit"][3])
+    assert len(labels) == n and set(labels) <= {"P", "S", "C"}
