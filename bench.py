@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--organisms", type=int, default=500)
     ap.add_argument("--algo", default="ncem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
     ap.add_argument("--cpu-iters", type=int, default=8, help="reference iterations timed for the CPU baseline")
     return ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
     n_loc, d, k, beta = args.families, args.organisms, 3, 0.5
     n_tot = n_loc * world
 
-    if world == 1:
+    if world == 1 and not args.dist:
         from pangenomenem_amd.engine import NemEngine
         x, _ = synth.bernoulli_pa_matrix(n_tot, d, 2)
         nei = synth.contiguity_graph(n_tot, 2)
@@ -129,6 +130,8 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "RANK" not in os.environ:              # plain `python bench.py --dist`: a 1-rank group
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         job = nd.ShardedNem.synthetic(n_loc, d, k, beta, rank, world, local_rank, algo=args.algo)
         cycle = job.iters_to_converge()
@@ -145,7 +148,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_max = float(t.item())
-        extra = dict(parity_iters_to_converge=cycle)
+        extra = dict(iters_to_converge_floor5=cycle)
         x = nei = None
 
     if rank == 0:
@@ -195,7 +198,7 @@ def main():
             + 16 * k * d
         out["roofline"]["whole_iteration_algorithmic_GBps"] = bytes_iter * args.steps / dt_max / 1e9
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.dist and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(x, nei, prop, center, disp, beta, args.algo, args.cpu_iters)
                 out["speedup_vs_cpu_baseline"] = cells_per_s / out["cpu_baseline"]["value"]
@@ -204,7 +207,7 @@ def main():
                                        "sample": "failed: %r" % (exc,)}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if world > 1 or args.dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -142,6 +142,22 @@ int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds);  /* E2 only (one fu
 int nemgpu_mstep(nemgpu_engine* e, int* emptyk);          /* M only */
 int nemgpu_criteria(nemgpu_engine* e, float crit6[6]);    /* C1 only */
 
+/* Multi-GPU step pieces (NCEM; families sharded across engines in contiguous blocks).  The host
+   driver (pangenomenem_amd/distributed.py) owns the GLOBAL label arrays (uint8[n_total], device
+   memory) and the statistics buffer and runs the collectives (RCCL through torch.distributed)
+   between these calls.  All calls are asynchronous on the engine's stream.
+     stats layout: int32[k + k*d] = { N_k, S1[k][j] = #{i in shard : label_i = k, x_ij = 1} }.    */
+int nemgpu_stats_words(const nemgpu_engine* e);
+int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev, int32_t* stats_dev);
+int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev);   /* after all-reduce(sum) */
+int nemgpu_ext_density(nemgpu_engine* e);                                   /* tables + E1 on the shard */
+/* One relaxation round of the E2 sweep for the shard: reads labels_old (partition before the sweep) and
+   labels_guess (previous round's output, all-gathered), writes labels_out[site_lo..site_hi) and ORs 1
+   into flags4_dev[0] when a label differs from its guess (flags4_dev: int32[4], zeroed by the caller). */
+int nemgpu_ext_sweep_round(nemgpu_engine* e, float beta, uint32_t sweep_id, const uint8_t* labels_old_dev,
+                           const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* flags4_dev);
+int nemgpu_ext_emptyk(nemgpu_engine* e, int* emptyk);                       /* syncs the stream */
+
 /* Test hook: load a partition (row-major [n_total x k], HOST) as the current state
    (argmax labels for ncem engines). */
 int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk);

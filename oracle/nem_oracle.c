@@ -155,6 +155,48 @@ int orc_sweep(int n, int k, const int* nei_ptr, const int* nei_idx, const float*
     return nzero;
 }
 
+/* One relaxation round (see nem_oracle.h).  Same arithmetic as orc_sweep, different data flow. */
+int orc_relax_round(int lo, int hi, int k, const int* nei_ptr_local, const int* nei_idx, const float* nei_w,
+                    float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
+                    unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out)
+{
+    double* cinum = (double*)malloc(sizeof(double) * (size_t)k);
+    float* row = (float*)malloc(sizeof(float) * (size_t)k);
+    int* kmaxes = (int*)malloc(sizeof(int) * (size_t)k);
+    int gi, kk, changed = 0;
+    for (gi = lo; gi < hi; gi++) {
+        int il = gi - lo;
+        int b = nei_ptr_local ? nei_ptr_local[il] : 0, e = nei_ptr_local ? nei_ptr_local[il + 1] : 0, t;
+        double cumnum = 0.0;
+        for (kk = 0; kk < k; kk++) {
+            float context = 0.0f;
+            for (t = b; t < e; t++) {
+                int j = nei_idx[t];
+                const float* src = (j < gi) ? c_guess : c_old;
+                context = context + (nei_w[t] * src[(size_t)j * k + kk]);
+            }
+            cinum[kk] = pkfki_local[(size_t)il * k + kk] * exp((double)beta * context);
+            cumnum = cumnum + cinum[kk];
+        }
+        if (cumnum > 0) {
+            if (cumnum > ORC_EPSILON) { double invz = 1 / cumnum; for (kk = 0; kk < k; kk++) row[kk] = (float)(invz * cinum[kk]); }
+            else { double invz = 1 / (cumnum / ORC_EPSILON); for (kk = 0; kk < k; kk++) row[kk] = (float)(invz * (cinum[kk] / ORC_EPSILON)); }
+        } else {
+            double invz = 1.0 / k;
+            for (kk = 0; kk < k; kk++) row[kk] = (float)invz;
+        }
+        if (ncem) {
+            int kmap = orc_map(row, k, tie_rule, tie_seed, sweep_id, (unsigned)gi, kmaxes);
+            for (kk = 0; kk < k; kk++) row[kk] = 0.0f;
+            row[kmap] = 1.0f;
+        }
+        if (memcmp(row, c_guess + (size_t)gi * k, sizeof(float) * (size_t)k) != 0) changed++;
+        memcpy(c_out + (size_t)gi * k, row, sizeof(float) * (size_t)k);
+    }
+    free(cinum); free(row); free(kmaxes);
+    return changed;
+}
+
 /* ------------------------------------------------------------------- M */
 int orc_mstep(int n, int d, int k, const unsigned char* x, const float* c_nk,
               int disper, int propor,

@@ -78,6 +78,15 @@ int orc_sweep(int n, int k, const int* nei_ptr, const int* nei_idx, const float*
               float beta, const double* pkfki_nk, int ncem,
               int tie_rule, unsigned tie_seed, unsigned sweep_id, float* c_nk);
 
+/* One RELAXATION ROUND of the same sweep for sites [lo, hi): site i reads c_guess for neighbours j < i
+   and c_old for neighbours j >= i (rows are GLOBAL), writes c_out[i].  The unique fixed point of these
+   rounds (c_out == c_guess) is exactly orc_sweep()'s result; this is how the HIP engine parallelises
+   the Gauss-Seidel order (tests check the equivalence on CPU).  pkfki_local has (hi-lo) rows.
+   Returns the number of sites of [lo, hi) whose output differs (bitwise) from its guess. */
+int orc_relax_round(int lo, int hi, int k, const int* nei_ptr_local, const int* nei_idx, const float* nei_w,
+                    float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
+                    unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out);
+
 /* M: EstimPara for FAMILY_BERNOULLI (nem_mod.c:415-469, 1180-1479, 1646-1704, 922-1174) */
 int orc_mstep(int n, int d, int k, const unsigned char* x, const float* c_nk,
               int disper, int propor,

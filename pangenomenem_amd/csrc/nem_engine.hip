@@ -708,6 +708,70 @@ int nemgpu_criteria(nemgpu_engine* e, float crit6[6])
     return criteria(e, crit6);
 }
 
+// ---- multi-GPU step pieces: same kernels, caller-owned global label arrays and statistics --------
+int nemgpu_stats_words(const nemgpu_engine* e) { return e ? e->k + e->k * e->d : 0; }
+
+int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev, int32_t* stats_dev)
+{
+    if (!e || !labels_global_dev || !stats_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), e->stream);
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stream);
+    HIPCHK(hipGetLastError());
+    e->masks_valid = false;
+    return NEMGPU_OK;
+}
+
+int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev)
+{
+    if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_mstep_centers_ncem(e->k, e->d, stats_dev, e->center, e->nbobs_k, e->iner, e->stream);
+    launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
+                      e->iter_flags(), e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+int nemgpu_ext_density(nemgpu_engine* e)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = do_tables(e))) return r;
+    return do_density(e);
+}
+
+int nemgpu_ext_sweep_round(nemgpu_engine* e, float beta, uint32_t sweep_id, const uint8_t* labels_old_dev,
+                           const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* flags4_dev)
+{
+    if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev || !flags4_dev) return NEMGPU_E_FUNCARG;
+    if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    SweepArgs a{};
+    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
+    a.use_nei = (e->has_graph && beta != 0.0f) ? 1 : 0;
+    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
+    a.beta = beta; a.pkfki = e->pkfki;
+    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id;
+    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
+    a.flags = flags4_dev; a.prev_changed = nullptr;
+    launch_sweep(a, true, e->stream);
+    HIPCHK(hipGetLastError());
+    e->flags_clean = false;
+    return NEMGPU_OK;
+}
+
+int nemgpu_ext_emptyk(nemgpu_engine* e, int* emptyk)
+{
+    if (!e || !emptyk) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = read_iter_flags(e))) return r;
+    *emptyk = e->flags_host[FLAG_EMPTYK];
+    return NEMGPU_OK;
+}
+
 int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)
 {
     // test hook: load a partition (row-major [n_total x k], HOST) as the current state

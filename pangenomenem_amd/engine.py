@@ -73,6 +73,12 @@ def load_library():
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
     lib.nemgpu_profile_enable.argtypes = [vp, C.c_int]
     lib.nemgpu_profile_read.argtypes = [vp, C.POINTER(C.c_double), ip, C.POINTER(C.c_double)]
+    lib.nemgpu_stats_words.argtypes = [vp]
+    lib.nemgpu_ext_mstep_partial.argtypes = [vp, vp, vp]
+    lib.nemgpu_ext_mstep_finalize.argtypes = [vp, vp]
+    lib.nemgpu_ext_density.argtypes = [vp]
+    lib.nemgpu_ext_sweep_round.argtypes = [vp, C.c_float, C.c_uint32, vp, vp, vp, vp]
+    lib.nemgpu_ext_emptyk.argtypes = [vp, ip]
     lib.nemio_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.nemio_free.argtypes = [vp]
     lib.nemio_free.restype = None
@@ -234,6 +240,28 @@ class NemEngine:
         out = self.params()
         out["c"] = self.partition()
         return out
+
+    # ---- multi-GPU step pieces (raw device pointers; see pangenomenem_amd/distributed.py)
+    def stats_words(self):
+        return int(self.lib.nemgpu_stats_words(self._h))
+
+    def ext_mstep_partial(self, labels_ptr, stats_ptr):
+        self._chk(self.lib.nemgpu_ext_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
+
+    def ext_mstep_finalize(self, stats_ptr):
+        self._chk(self.lib.nemgpu_ext_mstep_finalize(self._h, C.c_void_p(stats_ptr)))
+
+    def ext_density(self):
+        self._chk(self.lib.nemgpu_ext_density(self._h))
+
+    def ext_sweep_round(self, beta, sweep_id, old_ptr, guess_ptr, out_ptr, flags_ptr):
+        self._chk(self.lib.nemgpu_ext_sweep_round(self._h, C.c_float(beta), C.c_uint32(sweep_id), C.c_void_p(old_ptr),
+                                                  C.c_void_p(guess_ptr), C.c_void_p(out_ptr), C.c_void_p(flags_ptr)))
+
+    def ext_emptyk(self):
+        ek = C.c_int(0)
+        self._chk(self.lib.nemgpu_ext_emptyk(self._h, C.byref(ek)))
+        return ek.value
 
     def profile(self, on=True):
         self._chk(self.lib.nemgpu_profile_enable(self._h, int(on)))

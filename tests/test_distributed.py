@@ -1,0 +1,177 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) torch.distributed/gloo runs of the sharded EM driver
+(pangenomenem_amd/distributed.py) with the CPU oracle plugged in as the local stepper.  Checks the
+protocol -- shard bounds, label all-gather per relaxation round, integer statistics all-reduce,
+convergence / empty-class handling -- against the single-process oracle on the global problem."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPS = 1e-20
+
+
+class OracleStepper:
+    """CPU stand-in for GpuStepper: same interface, numbers from the oracle / numpy integer counts."""
+
+    def __init__(self, oracle, x_local, nei_local, k, n_total, lo, hi, prop, center, disp, disper="sk_", seed=0):
+        import torch
+        self.torch, self.o = torch, oracle
+        self.x, self.nei, self.k, self.n_total, self.lo, self.hi = x_local, nei_local, k, n_total, lo, hi
+        self.d = x_local.shape[1]
+        self.p0 = (np.array(prop, np.float32), np.array(center, np.float32), np.array(disp, np.float32))
+        self.disper, self.seed = disper, seed
+        self.reset()
+
+    def alloc(self, n, dtype):
+        return self.torch.zeros(n, dtype=getattr(self.torch, dtype))
+
+    def stats_words(self):
+        return self.k + self.k * self.d
+
+    def reset(self):
+        self.prop, self.center, self.disp = (a.copy() for a in self.p0)
+        self.nbobs_k = np.zeros(self.k, np.float32)
+        self._emptyk = 0
+
+    def density(self):
+        self.pk, _, _ = self.o.density(self.x, self.prop, self.center, self.disp)
+
+    def _onehot(self, lab):
+        c = np.zeros((len(lab), self.k), np.float32)
+        valid = lab < self.k
+        c[np.flatnonzero(valid), lab[valid]] = 1.0
+        return c
+
+    def sweep_round(self, beta, sweep_id, old, guess, out, flags):
+        n = self.n_total
+        c_old, c_guess = self._onehot(old.numpy()[:n]), self._onehot(guess.numpy()[:n])
+        c_out = np.zeros_like(c_old)
+        self.o.relax_round(self.lo, self.hi, self.nei, beta, self.pk, True, c_old, c_guess, c_out, tie="hash",
+                           seed=self.seed, sweep_id=sweep_id)
+        new = c_out[self.lo:self.hi].argmax(1).astype(np.uint8)
+        changed = int(np.any(new != guess.numpy()[self.lo:self.hi]))
+        out.numpy()[self.lo:self.hi] = new
+        flags[0] = max(int(flags[0]), changed)
+
+    def mstep_partial(self, labels, stats):
+        lab = labels.numpy()[self.lo:self.hi]
+        s = stats.numpy()
+        for c in range(self.k):
+            m = lab == c
+            s[c] = int(m.sum())
+            s[self.k + c * self.d:self.k + (c + 1) * self.d] = self.x[m].sum(0)
+
+    def mstep_finalize(self, stats):
+        """k_mstep_centers_ncem + k_mstep_disp (sk_/pk) restated in numpy on the GLOBAL counts."""
+        s = stats.numpy()
+        k, d = self.k, self.d
+        ek = 0
+        iner = np.zeros((k, d), np.float32)
+        for c in range(k):
+            nk = np.float32(s[c])
+            self.nbobs_k[c] = nk
+            if not float(nk) > EPS:
+                ek = c + 1
+                continue
+            s1 = s[k + c * d:k + (c + 1) * d].astype(np.int64)
+            s0 = (int(s[c]) - s1).astype(np.float32)
+            half = np.float32(nk / np.float32(2))
+            mu = np.where(s0 > half, 0.0, np.where(s0 == half, 0.5, 1.0)).astype(np.float32)
+            iner[c] = np.where(mu == 0, s1.astype(np.float32), np.where(mu == 1, s0, np.float32(0.5) * nk))
+            self.center[c] = mu
+        assert self.disper == "sk_"
+        for c in range(k):
+            nk = self.nbobs_k[c]
+            if nk > 0:
+                sn = np.cumsum(np.full(d, nk, np.float32), dtype=np.float32)[-1]       # d-ordered float chains
+                si = np.cumsum(iner[c], dtype=np.float32)[-1]
+                self.disp[c, :] = np.float32(si / sn)
+            self.prop[c] = np.float32(nk / np.float32(self.n_total))
+        self._emptyk = ek
+
+    def emptyk(self):
+        return self._emptyk
+
+    def params(self):
+        return dict(prop=self.prop, center=self.center, disp=self.disp, nbobs_k=self.nbobs_k)
+
+
+def _worker(rank, world, initfile, n, d, beta, kind, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle.pyoracle import Oracle
+    from pangenomenem_amd import synth
+    from pangenomenem_amd.distributed import Comm, ShardedNem, shard_bounds, slice_graph
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        if kind == "empty":
+            x = np.ones((n, d), np.uint8); x[::7, 3] = 0
+        else:
+            x, _ = synth.bernoulli_pa_matrix(n, d, 1)
+        nei = synth.contiguity_graph(n, 1)
+        prop, center, disp = synth.default_init(d)
+        lo, hi, _ = shard_bounds(n, world, rank)
+        st = OracleStepper(Oracle(), x[lo:hi], slice_graph(nei, lo, hi), 3, n, lo, hi, prop, center, disp, seed=11)
+        job = ShardedNem(st, Comm(), n, beta, cvtest="clas", cvthres=1e-8)
+        res = job.run(100)
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), labels=job.global_labels(), iters=res["iters"],
+                 converged=res["converged"], status=res["status"], emptyk=res["emptyk"], rounds=res["sweep_rounds"],
+                 **st.params())
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n, d, beta, kind="normal"):
+    import torch.multiprocessing as mp
+    outdir = tempfile.mkdtemp(prefix="nemdist_")
+    initfile = os.path.join(outdir, "rendezvous")
+    mp.spawn(_worker, args=(world, initfile, n, d, beta, kind, outdir), nprocs=world, join=True)
+    return [np.load(os.path.join(outdir, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n,d,beta", [(2, 2048, 15, 0.5), (3, 1000, 24, 1.0), (2, 1501, 15, 0.0)])
+def test_sharded_em_equals_single_process_oracle(oracle, world, n, d, beta):
+    from pangenomenem_amd import synth
+    outs = _run(world, n, d, beta)
+    x, _ = synth.bernoulli_pa_matrix(n, d, 1)
+    nei = synth.contiguity_graph(n, 1)
+    prop, center, disp = synth.default_init(d)
+    want = oracle.run(x, nei, 3, prop, center, disp, algo="ncem", beta=beta, tie="hash", seed=11)
+    for o in outs:                                            # every rank ends with the same global answer
+        assert int(o["status"]) == want["status"] and int(o["iters"]) == want["iters"]
+        assert bool(o["converged"]) == want["converged"]
+        assert np.array_equal(o["labels"], want["c"].argmax(1))
+        assert np.array_equal(o["center"], want["center"])
+        assert np.array_equal(o["disp"], want["disp"]) and np.array_equal(o["prop"], want["prop"])
+        assert np.array_equal(o["nbobs_k"], want["nbobs_k"])
+
+
+def test_sharded_em_empty_class(oracle):
+    outs = _run(2, 300, 20, 0.5, kind="empty")
+    x = np.ones((300, 20), np.uint8); x[::7, 3] = 0
+    from pangenomenem_amd import synth
+    prop, center, disp = synth.default_init(20)
+    want = oracle.run(x, synth.contiguity_graph(300, 1), 3, prop, center, disp, algo="ncem", beta=0.5, tie="hash", seed=11)
+    assert want["status"] == 2
+    for o in outs:
+        assert int(o["status"]) == 2 and int(o["emptyk"]) == want["emptyk"] and int(o["iters"]) == want["iters"]
+        assert np.array_equal(o["labels"], want["c"].argmax(1))
+
+
+def test_shard_bounds_and_graph_slices():
+    from pangenomenem_amd import synth
+    from pangenomenem_amd.distributed import shard_bounds, slice_graph
+    n = 1003
+    nei = synth.contiguity_graph(n, 3)
+    covered = []
+    for r in range(8):
+        lo, hi, blk = shard_bounds(n, 8, r)
+        assert blk == 126 and 0 <= lo <= hi <= n
+        covered += list(range(lo, hi))
+        p, i, w = slice_graph(nei, lo, hi)
+        assert p[0] == 0 and len(p) == hi - lo + 1 and len(i) == p[-1] == len(w)
+        assert np.array_equal(i, nei[1][nei[0][lo]:nei[0][hi]])
+    assert covered == list(range(n))
