@@ -71,8 +71,9 @@ struct nemgpu_engine {
     int cur = 0;
     uint64_t* mask = nullptr;
     int* stats = nullptr;
-    int* flags_dev = nullptr;                         // [FLAG_ITER_STRIDE] + kRoundCap * FLAG_ROUND_STRIDE
-    int* flags_host = nullptr;                        // pinned mirror
+    int* flags_dev = nullptr;     // [C_WORDS loop control] [FLAG_ITER_STRIDE] [kRoundCap * FLAG_ROUND_STRIDE]
+    int* flags_host = nullptr;    // pinned mirror
+    const int* stop_ptr = nullptr;   // &ctrl[C_STOP] while the pipelined loop is being enqueued, else nullptr
 
     float* c_onehot = nullptr;                        // lazily allocated (criteria / NCEM)
     float *crit_dik = nullptr, *crit_gik = nullptr, *crit6_dev = nullptr;
@@ -91,9 +92,13 @@ struct nemgpu_engine {
     int ev_used = 0;
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
-    int* iter_flags() const { return flags_dev; }
-    int* round_flags(int r) const { return flags_dev + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
-    size_t flag_words() const { return FLAG_ITER_STRIDE + (size_t)kRoundCap * FLAG_ROUND_STRIDE; }
+    int* ctrl() const { return flags_dev; }
+    int* iter_flags() const { return flags_dev + C_WORDS; }
+    int* round_flags(int r) const { return flags_dev + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
+    size_t flag_words() const { return C_WORDS + FLAG_ITER_STRIDE + (size_t)kRoundCap * FLAG_ROUND_STRIDE; }
+    const int* h_ctrl() const { return flags_host; }
+    const int* h_iter() const { return flags_host + C_WORDS; }
+    const int* h_round(int r) const { return flags_host + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
 };
 
 namespace {
@@ -136,6 +141,7 @@ TableArgs table_args(nemgpu_engine* e)
     t.tabT = e->tabT; t.tabL0 = e->tabL0; t.nz0 = e->nz0; t.nz1 = e->nz1;
     t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni; t.epoch = e->table_epoch;
     t.pk = e->pk; t.logpk = e->logpk; t.flags = e->iter_flags();
+    t.stop = e->stop_ptr;
     return t;
 }
 
@@ -158,7 +164,7 @@ int do_density(nemgpu_engine* e)
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    launch_density(table_args(e), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->flags_dev + FLAG_MOVED,
+    launch_density(table_args(e), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
                    1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = true;
@@ -183,7 +189,7 @@ struct SweepCtx {
 
 int clear_sweep_flags(nemgpu_engine* e)
 {
-    HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
     e->flags_clean = true;
     return NEMGPU_OK;
 }
@@ -201,6 +207,7 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
         c.a.flags = e->round_flags(r);
         c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
+        c.a.stop = e->stop_ptr;
         launch_sweep(c.a, ncem, e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -235,8 +242,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
         HIPCHK(hipStreamSynchronize(e->stream));
         if (!c.use_nei) { done_at = 0; break; }
         for (int q = c.checked; q < c.r; q++) {
-            const int* f = e->flags_host + FLAG_ITER_STRIDE + (q % kRoundCap) * FLAG_ROUND_STRIDE;
-            if (f[FLAG_CHANGED] == 0) { done_at = q; break; }
+            if (e->h_round(q)[FLAG_CHANGED] == 0) { done_at = q; break; }
         }
         c.checked = c.r;
         if (done_at >= 0) break;
@@ -244,7 +250,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
         if (c.r % kRoundCap == 0 || c.r % kRoundCap + kRoundBatch > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
-            HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_ITER_STRIDE, 0, kRoundCap * FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+            HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * FLAG_ROUND_STRIDE * sizeof(int), e->stream));
             while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
             c.checked = c.r;
         }
@@ -252,7 +258,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
         if (rr) return rr;
     }
     // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
-    const int* f = e->flags_host + FLAG_ITER_STRIDE + (done_at % kRoundCap) * FLAG_ROUND_STRIDE;
+    const int* f = e->h_round(done_at);
     if (f[FLAG_NZERO] > 0) {
         e->zero_density += f[FLAG_NZERO];
         if (e->first_zero < 0) e->first_zero = e->n_total - f[FLAG_FIRSTZERO];
@@ -274,7 +280,7 @@ int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
 int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf)
 {
     launch_labels_post(e->n, e->lo, e->k, e->nw64, e->lab[newbuf], oldbuf >= 0 ? e->lab[oldbuf] : nullptr, e->mask,
-                       e->iter_flags(), e->stream);
+                       e->iter_flags(), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = true;
     return NEMGPU_OK;
@@ -285,22 +291,22 @@ int do_mstep(nemgpu_engine* e)
 {
     if (e->ncem()) {
         if (!e->masks_valid) { int r = do_labels_post(e, e->cur, -1); if (r) return r; }
-        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stream);
-        launch_mstep_centers_ncem(e->k, e->d, e->stats, e->center, e->nbobs_k, e->iner, e->stream);
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
+        launch_mstep_centers_ncem(e->k, e->d, e->stats, e->center, e->nbobs_k, e->iner, e->stop_ptr, e->stream);
     } else {
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
-                           e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->center, e->iner, e->stream);
+                           e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->center, e->iner, e->stop_ptr, e->stream);
     }
     launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
-                      e->iter_flags(), e->stream);
+                      e->iter_flags(), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
 
 int read_iter_flags(nemgpu_engine* e)
 {
-    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, FLAG_ITER_STRIDE * sizeof(int), hipMemcpyDeviceToHost,
-                          e->stream));
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, (C_WORDS + FLAG_ITER_STRIDE) * sizeof(int),
+                          hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return NEMGPU_OK;
 }
@@ -327,53 +333,114 @@ int init_partition(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-// NemAlgo's loop body (nem_alg.c:1789-1840), up to n_iters iterations.  One host sync per
-// iteration: the convergence bookkeeping is enqueued right behind the first batch of relaxation
-// rounds and redone only if the sweep needed more rounds than that batch.
+// NemAlgo's loop body (nem_alg.c:1789-1840), up to n_iters iterations, as a device-controlled
+// pipeline: the host enqueues up to kPipeDepth whole iterations back to back; k_ctrl (one thread, at
+// the end of each iteration) applies the loop tests on the device and raises ctrl[C_STOP]; every loop
+// kernel returns at once when it is set.  The host synchronises once per batch.  The bookkeeping of
+// an iteration (label masks + "moved" flag, or the fuzzy convergence test) is enqueued right behind
+// the first two relaxation rounds; if a sweep needs more rounds than that, the pipeline stops and the
+// host finishes that iteration round by round (rare: labels are sticky).
 int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf)
 {
     if (e->ncem()) return do_labels_post(e, newbuf, oldbuf);
     if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
         launch_conv_fuzzy((size_t)e->n * e->k, e->cbuf[newbuf] + (size_t)e->lo * e->k,
-                          e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stream);
+                          e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stop_ptr,
+                          e->stream);
         HIPCHK(hipGetLastError());
     }
+    return NEMGPU_OK;
+}
+
+constexpr int kPipeDepth = 6;
+
+// enqueue one whole iteration whose current partition is buffer `cur`
+int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
+{
+    int r;
+    const int saved = e->cur;
+    e->cur = cur;
+    if (!e->cfg.param_fix) {                                       // nem_alg.c:1806
+        if ((r = do_mstep(e))) { e->cur = saved; return r; }
+        if ((r = do_tables(e))) { e->cur = saved; return r; }
+    }
+    if ((r = do_density(e))) { e->cur = saved; return r; }
+    SweepCtx c;
+    e->sweep_counter = sweep_id;
+    if ((r = sweep_enqueue(e, e->cfg.beta, c))) { e->cur = saved; return r; }
+    if ((r = post_sweep(e, (cur + 1) % 3, cur))) { e->cur = saved; return r; }
+    CtrlArgs ca;
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = c.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres;
+    launch_ctrl(ca, e->stream);
+    HIPCHK(hipGetLastError());
+    e->cur = saved;
     return NEMGPU_OK;
 }
 
 int iterate(nemgpu_engine* e, int n_iters)
 {
     int r;
-    for (int it = 0; it < n_iters && !e->converged && e->status == NEMGPU_OK; it++) {
-        if (!e->cfg.param_fix) {                                   // nem_alg.c:1806
-            if ((r = do_mstep(e))) return r;
-            if ((r = do_tables(e))) return r;
+    while (n_iters > 0 && !e->converged && e->status == NEMGPU_OK) {
+        const int g = std::min(n_iters, kPipeDepth);
+        const int base = e->cur;
+        const uint32_t sweep0 = e->sweep_counter;
+        HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
+        e->stop_ptr = e->ctrl() + C_STOP;
+        // the first iteration of a batch may find MOVED / round flags dirty only if no density preceded it;
+        // enqueue_iteration always runs k_density (which clears them) before the sweep.
+        e->masks_valid = e->masks_valid && e->ncem();
+        for (int j = 0; j < g; j++) {
+            r = enqueue_iteration(e, (base + j) % 3, sweep0 + j);
+            if (r) { e->stop_ptr = nullptr; return r; }
         }
-        if ((r = do_density(e))) return r;
-        const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
-        SweepCtx c;
-        if ((r = sweep_enqueue(e, e->cfg.beta, c))) return r;
-        if ((r = post_sweep(e, newbuf, oldbuf))) return r;         // speculative: assumes the batch converges
-        bool extra = false;
-        if ((r = sweep_complete(e, c, nullptr, &extra))) return r; // syncs; all flags are in flags_host
-        e->iters++;
-        const int ek = e->flags_host[FLAG_EMPTYK];
-        if (!e->cfg.param_fix && ek != 0) {                        // nem_alg.c:1831-1838: E-step not run
+        e->stop_ptr = nullptr;
+        HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const int* c = e->h_ctrl();
+        const int done = c[C_ITERS], commits = c[C_COMMITS];
+        e->iters += done;
+        e->sweep_rounds += c[C_SWEEP_ROUNDS];
+        if (c[C_NZERO] > 0) {
+            e->zero_density += c[C_NZERO];
+            if (e->first_zero < 0) e->first_zero = e->n_total - c[C_FIRSTZERO];
+        }
+        e->cur = (base + commits) % 3;
+        e->sweep_counter = sweep0 + (uint32_t)done;
+        if (e->prof && done < g) e->ev_used -= 2 * (g - done);     // launches that returned at the stop word
+        n_iters -= done;
+        e->flags_clean = false;
+        if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
             e->status = NEMGPU_W_EMPTYCLASS;
-            e->emptyk = ek;
-            e->masks_valid = false;
-            break;                                                 // partition stays at buffer `cur`
+            e->emptyk = c[C_EMPTYK];
+            e->masks_valid = false;                                // the speculative E-step rebuilt them for a discarded partition
+            break;
         }
-        if (extra) {                                               // redo the bookkeeping on the final partition
-            HIPCHK(hipMemsetAsync(e->flags_dev + FLAG_MOVED, 0, sizeof(int), e->stream));
+        if (c[C_CONVERGED]) { e->converged = 1; break; }
+        if (c[C_NEED_ROUNDS]) {
+            // iteration #commits of this batch ran its M-step, density and relaxation rounds 0 and 1 and is
+            // not at the fixed point yet: continue its rounds from the host, then redo the bookkeeping.
+            const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
+            SweepCtx sc;
+            sc.use_nei = true;
+            SweepArgs& a = sc.a;
+            a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = 1;
+            a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
+            a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep0 + (uint32_t)(done - 1);
+            sc.r = 2; sc.checked = 2;
+            if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
+            int rounds = 0;
+            if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
+            HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
             if ((r = post_sweep(e, newbuf, oldbuf))) return r;
             if ((r = read_iter_flags(e))) return r;
-        }
-        e->cur = newbuf;
-        if (e->cfg.cvtest == NEMGPU_CV_CLAS) {                     // HasConverged, nem_alg.c:2075-2089
-            const int moved = e->flags_host[FLAG_MOVED];
-            if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
-            else e->converged = !moved;
+            e->cur = newbuf;
+            if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
+                const int moved = e->h_iter()[FLAG_MOVED];
+                if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
+                else e->converged = !moved;
+            }
         }
     }
     return NEMGPU_OK;
@@ -697,8 +764,8 @@ int nemgpu_mstep(nemgpu_engine* e, int* emptyk)
     if ((r = ensure_state_buffers(e))) return r;
     if ((r = do_mstep(e))) return r;
     if ((r = read_iter_flags(e))) return r;
-    if (emptyk) *emptyk = e->flags_host[FLAG_EMPTYK];
-    return e->flags_host[FLAG_EMPTYK] ? NEMGPU_W_EMPTYCLASS : NEMGPU_OK;
+    if (emptyk) *emptyk = e->h_iter()[FLAG_EMPTYK];
+    return e->h_iter()[FLAG_EMPTYK] ? NEMGPU_W_EMPTYCLASS : NEMGPU_OK;
 }
 
 int nemgpu_criteria(nemgpu_engine* e, float crit6[6])
@@ -715,8 +782,8 @@ int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev,
 {
     if (!e || !labels_global_dev || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), e->stream);
-    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stream);
+    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), nullptr, e->stream);
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, nullptr, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = false;
     return NEMGPU_OK;
@@ -726,9 +793,9 @@ int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev)
 {
     if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    launch_mstep_centers_ncem(e->k, e->d, stats_dev, e->center, e->nbobs_k, e->iner, e->stream);
+    launch_mstep_centers_ncem(e->k, e->d, stats_dev, e->center, e->nbobs_k, e->iner, nullptr, e->stream);
     launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
-                      e->iter_flags(), e->stream);
+                      e->iter_flags(), nullptr, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -768,7 +835,7 @@ int nemgpu_ext_emptyk(nemgpu_engine* e, int* emptyk)
     HIPCHK(hipSetDevice(e->device));
     int r;
     if ((r = read_iter_flags(e))) return r;
-    *emptyk = e->flags_host[FLAG_EMPTYK];
+    *emptyk = e->h_iter()[FLAG_EMPTYK];
     return NEMGPU_OK;
 }
 

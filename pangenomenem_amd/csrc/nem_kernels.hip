@@ -89,8 +89,10 @@ __global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
                          uint32_t* __restrict__ nz0, uint32_t* __restrict__ nz1,
                          uint32_t* __restrict__ am0, uint32_t* __restrict__ am1,
                          double2* __restrict__ uni, int* __restrict__ nonuni, int epoch,
-                         double* __restrict__ pk, float* __restrict__ logpk, int* __restrict__ flags)
+                         double* __restrict__ pk, float* __restrict__ logpk, int* __restrict__ flags,
+                         const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     int t = blockIdx.x * blockDim.x + threadIdx.x;      // over K * dpad (dpad % 64 == 0)
     int lane = threadIdx.x & 63;
     if (t >= K * dpad) return;
@@ -152,12 +154,14 @@ struct DensityArgs {
     const double* pk; const float* logpk;
     double* pkfki; float* logpkfki;
     int* zero_flags; int n_zero_flags;
+    const int* stop;
 };
 
 __global__ __launch_bounds__(256) void k_density(DensityArgs a)
 {
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
+    if (a.stop != nullptr && *a.stop) return;
     const int k = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;        // i < npad by construction
     const int npad = a.npad, dpad = a.dpad;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
 template <int KT, bool NCEM>
 __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
 {
+    if (a.stop != nullptr && *a.stop) return;
     if (a.prev_changed != nullptr && *a.prev_changed == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_local) return;
@@ -357,8 +362,9 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* __restrict__ lab_new,
                               const uint8_t* __restrict__ lab_old, uint64_t* __restrict__ mask,
-                              int* __restrict__ flags)
+                              int* __restrict__ flags, const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = i >> 6;
@@ -378,9 +384,11 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
 // M1-M3 for NCEM as integer counts: S1[k][d] = #{i : label_i = k, x_id = 1}, N_k = #{label = k}.
 // grid = d + 1 blocks (the last one counts class sizes); out: stats[0..K) = N_k, stats[K + k*d + j] = S1.
 __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, const uint64_t* __restrict__ xt,
-                                                      const uint64_t* __restrict__ mask, int* __restrict__ stats)
+                                                      const uint64_t* __restrict__ mask, int* __restrict__ stats,
+                                                      const int* __restrict__ stop)
 {
     __shared__ int red[4];
+    if (stop != nullptr && *stop) return;
     const int d = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int k = 0; k < K; k++) {
@@ -405,8 +413,10 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
 //   ComputeMedian (nem_mod.c:1439-1477) gives mu = 0 if S0 > half, 0.5 if S0 == half, 1 otherwise;
 //   EstimLaplaceIner (nem_mod.c:1669-1686) gives S1, S0 or N_K/2 for mu = 0, 1, 0.5 (all exact).
 __global__ void k_mstep_centers_ncem(int K, int D, const int* __restrict__ stats, float* __restrict__ center,
-                                     float* __restrict__ nbobs_k, float* __restrict__ iner)
+                                     float* __restrict__ nbobs_k, float* __restrict__ iner,
+                                     const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= K * D) return;
     const int k = t / D;
@@ -444,7 +454,8 @@ __device__ inline void seq_sum_pair(const float4* __restrict__ v4, int n4, float
 __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, int disper, int propor,
                                                      const float* __restrict__ nbobs_k,
                                                      const float* __restrict__ iner, float* __restrict__ disp,
-                                                     float* __restrict__ prop, int* __restrict__ flags)
+                                                     float* __restrict__ prop, int* __restrict__ flags,
+                                                     const int* __restrict__ stop)
 {
     constexpr int CAP = 12288;                           // staged inertia values (48 KB)
     __shared__ float4 s_in4[CAP / 4];
@@ -453,6 +464,7 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
     __shared__ float s_vol;
     float* s_in = reinterpret_cast<float*>(s_in4);
     const int tid = threadIdx.x;
+    if (stop != nullptr && *stop) return;
     if (disper == NEMGPU_DISP_K_) {
         // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains.  Classes run on
         // different waves; a class's D values are staged in LDS (D4 = D rounded down to 4, tail scalar).
@@ -549,8 +561,10 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
                                                       const float* __restrict__ c, float* __restrict__ nbobs_k,
                                                       float* __restrict__ s0_out, float* __restrict__ in0_out,
-                                                      float* __restrict__ in1_out, float* __restrict__ inh_out)
+                                                      float* __restrict__ in1_out, float* __restrict__ inh_out,
+                                                      const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     const int k = blockIdx.y;
     const int d = blockIdx.x * 64 + threadIdx.x;
     const int dw = min(d, D - 1) >> 5, db = d & 31;
@@ -578,8 +592,10 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
                                                       const float* __restrict__ c, const float* __restrict__ nbobs_k,
                                                       const float* __restrict__ s0_in, const float* __restrict__ in0,
                                                       const float* __restrict__ in1, const float* __restrict__ inh,
-                                                      float* __restrict__ center, float* __restrict__ iner)
+                                                      float* __restrict__ center, float* __restrict__ iner,
+                                                      const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     const int k = blockIdx.y;
     const int d = blockIdx.x * 64 + threadIdx.x;
     const int dc = min(d, D - 1);
@@ -627,8 +643,9 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
 
 // CVTEST_CLAS for float partitions (nem_alg.c:2077-2088): converged iff no |c - cold| >= thres
 __global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float* __restrict__ cold, float thres,
-                             int* __restrict__ flags)
+                             int* __restrict__ flags, const int* __restrict__ stop)
 {
+    if (stop != nullptr && *stop) return;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int bad = 0;
     if (t < m) {
@@ -638,6 +655,44 @@ __global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float*
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
 }
+
+// ------------------------------------------------------------------------------------------
+// Device-side loop control (one thread, once per EM iteration).  The host enqueues several
+// iterations ahead; every loop kernel returns at once when ctrl[C_STOP] is set, so the host only
+// has to look at `ctrl` once per batch instead of once per iteration (NemAlgo's loop test,
+// nem_alg.c:1789-1840: convergence, empty class; plus "the sweep needs more relaxation rounds").
+// ------------------------------------------------------------------------------------------
+__global__ void k_ctrl(CtrlArgs a)
+{
+    int* c = a.ctrl;
+    if (c[C_STOP]) return;
+    c[C_ITERS] += 1;
+    if (!a.param_fix && a.iter_flags[FLAG_EMPTYK] != 0) {         // nem_alg.c:1831-1838: E-step "not run"
+        c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
+        c[C_EMPTYK] = a.iter_flags[FLAG_EMPTYK];
+        c[C_STOP] = 1;
+        return;
+    }
+    const int* f = a.round0;
+    int rounds = 1;
+    if (a.use_nei && a.round0[FLAG_CHANGED] != 0) {
+        if (a.round1[FLAG_CHANGED] != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
+        f = a.round1; rounds = 2;
+    }
+    c[C_SWEEP_ROUNDS] += rounds;
+    if (f[FLAG_NZERO] > 0) {
+        c[C_NZERO] += f[FLAG_NZERO];
+        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
+    }
+    c[C_COMMITS] += 1;
+    if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
+        const int moved = a.iter_flags[FLAG_MOVED];
+        const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
+        if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
+    }
+}
+
+void launch_ctrl(const CtrlArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a); }
 
 // labels -> one-hot float rows (LabelToClassVector, nem_alg.c:649-664)
 __global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* __restrict__ c)
@@ -751,7 +806,7 @@ void launch_tables(const TableArgs& t, hipStream_t s)
 {
     hipLaunchKernelGGL(k_tables, dim3((t.K * t.dpad + 255) / 256), dim3(256), 0, s, t.K, t.D, t.dpad, t.prop, t.center,
                        t.disp, t.tabT, t.tabL0, t.nz0, t.nz1, t.am0, t.am1, t.uni, t.nonuni, t.epoch, t.pk, t.logpk,
-                       t.flags);
+                       t.flags, t.stop);
 }
 
 void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
@@ -762,47 +817,51 @@ void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, dou
     a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
     a.uni = t.uni; a.nonuni = t.nonuni; a.epoch = t.epoch; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
+    a.stop = t.stop;
     hipLaunchKernelGGL(k_density, dim3(npad / 256, t.K), dim3(256), 0, s, a);
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
-                        uint64_t* mask, int* flags, hipStream_t s)
+                        uint64_t* mask, int* flags, const int* stop, hipStream_t s)
 {
     hipLaunchKernelGGL(k_labels_post, dim3((nw64 * 64 + 255) / 256), dim3(256), 0, s, n_local, lo, K, nw64, lab_new,
-                       lab_old, mask, flags);
+                       lab_old, mask, flags, stop);
 }
 
-void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats, hipStream_t s)
+void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
+                         const int* stop, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mstep_counts, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats);
+    hipLaunchKernelGGL(k_mstep_counts, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
 }
 
 void launch_mstep_centers_ncem(int K, int D, const int* stats, float* center, float* nbobs_k, float* iner,
-                               hipStream_t s)
+                               const int* stop, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mstep_centers_ncem, dim3((K * D + 255) / 256), dim3(256), 0, s, K, D, stats, center, nbobs_k,
-                       iner);
+                       iner, stop);
 }
 
 void launch_mstep_disp(int K, int D, int n_total, int disper, int propor, const float* nbobs_k, const float* iner,
-                       float* disp, float* prop, int* flags, hipStream_t s)
+                       float* disp, float* prop, int* flags, const int* stop, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mstep_disp, dim3(1), dim3(1024), 0, s, K, D, n_total, disper, propor, nbobs_k, iner, disp,
-                       prop, flags);
+                       prop, flags, stop);
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
-                        float* in0, float* in1, float* inh, float* center, float* iner, hipStream_t s)
+                        float* in0, float* in1, float* inh, float* center, float* iner, const int* stop, hipStream_t s)
 {
     dim3 grid((D + 63) / 64, K), block(64);
-    hipLaunchKernelGGL(k_mstep_fuzzy_a, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh);
+    hipLaunchKernelGGL(k_mstep_fuzzy_a, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh, stop);
     hipLaunchKernelGGL(k_mstep_fuzzy_b, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh, center,
-                       iner);
+                       iner, stop);
 }
 
-void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, hipStream_t s)
+void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
+                       hipStream_t s)
 {
-    hipLaunchKernelGGL(k_conv_fuzzy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, c, cold, thres, flags);
+    hipLaunchKernelGGL(k_conv_fuzzy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, c, cold, thres, flags,
+                       stop);
 }
 
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)
