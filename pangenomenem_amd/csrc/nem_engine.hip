@@ -60,7 +60,8 @@ struct nemgpu_engine {
     uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
     double2* uni = nullptr;
     int* nonuni = nullptr;
-    int table_epoch = 0;
+    int* sweep_next = nullptr;    // device word: number of the next E-step sweep (tie-break hash key)
+    bool tables_fresh = false;    // density tables match prop/center/disp
     double* pk = nullptr;
     float* logpk = nullptr;
     double* pkfki = nullptr;
@@ -85,6 +86,10 @@ struct nemgpu_engine {
     int zero_density = 0, first_zero = -1, sweep_rounds = 0;
     bool masks_valid = false;
     bool flags_clean = false;     // MOVED + round window are zero (set by k_density, consumed by a sweep)
+
+    // captured batches of the pipelined loop, keyed by (current buffer, iterations in the batch)
+    hipGraphExec_t graphs[3][8] = {};
+    bool use_graphs = true;
 
     // profiling of the E1 kernel
     bool prof = false;
@@ -133,23 +138,27 @@ int ensure_state_buffers(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-TableArgs table_args(nemgpu_engine* e)
+FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
 {
-    TableArgs t;
-    t.K = e->k; t.D = e->d; t.dpad = e->dpad;
-    t.prop = e->prop; t.center = e->center; t.disp = e->disp;
+    FinishArgs t;
+    t.mode = mode;
+    t.K = e->k; t.D = e->d; t.dpad = e->dpad; t.n_total = e->n_total; t.disper = e->cfg.disper; t.propor = e->cfg.propor;
+    t.stats = stats;
+    t.prop = e->prop; t.center = e->center; t.disp = e->disp; t.nbobs_k = e->nbobs_k; t.iner = e->iner;
     t.tabT = e->tabT; t.tabL0 = e->tabL0; t.nz0 = e->nz0; t.nz1 = e->nz1;
-    t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni; t.epoch = e->table_epoch;
+    t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni;
     t.pk = e->pk; t.logpk = e->logpk; t.flags = e->iter_flags();
     t.stop = e->stop_ptr;
     return t;
 }
 
+// density tables from the current parameters (k_finish mode 0); a no-op when they are up to date
 int do_tables(nemgpu_engine* e)
 {
-    e->table_epoch++;                                   // stamps this generation of tables (k_tables / k_density)
-    launch_tables(table_args(e), e->stream);
+    if (e->tables_fresh) return NEMGPU_OK;
+    launch_finish(finish_args(e, 0, nullptr), e->stream);
     HIPCHK(hipGetLastError());
+    e->tables_fresh = true;
     return NEMGPU_OK;
 }
 
@@ -164,7 +173,7 @@ int do_density(nemgpu_engine* e)
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    launch_density(table_args(e), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
+    launch_density(finish_args(e, 0, nullptr), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
                    1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = true;
@@ -225,6 +234,7 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c)
     a.beta = beta;
     a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = e->sweep_counter++;
+    a.sweep_id_ptr = e->stop_ptr != nullptr ? e->sweep_next : nullptr;   // pipelined loop: the device keeps count
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
     return sweep_launch_rounds(e, c, c.use_nei ? kRoundBatch : 1);
@@ -277,10 +287,10 @@ int do_sweep(nemgpu_engine* e, float beta, int* rounds_out)
     return sweep_complete(e, c, rounds_out, nullptr);
 }
 
-int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf)
+int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctrl = nullptr)
 {
     launch_labels_post(e->n, e->lo, e->k, e->nw64, e->lab[newbuf], oldbuf >= 0 ? e->lab[oldbuf] : nullptr, e->mask,
-                       e->iter_flags(), e->stop_ptr, e->stream);
+                       e->iter_flags(), e->stop_ptr, ctrl, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = true;
     return NEMGPU_OK;
@@ -292,14 +302,14 @@ int do_mstep(nemgpu_engine* e)
     if (e->ncem()) {
         if (!e->masks_valid) { int r = do_labels_post(e, e->cur, -1); if (r) return r; }
         launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
-        launch_mstep_centers_ncem(e->k, e->d, e->stats, e->center, e->nbobs_k, e->iner, e->stop_ptr, e->stream);
+        launch_finish(finish_args(e, 1, e->stats), e->stream);
     } else {
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
                            e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->center, e->iner, e->stop_ptr, e->stream);
+        launch_finish(finish_args(e, 2, nullptr), e->stream);
     }
-    launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
-                      e->iter_flags(), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
+    e->tables_fresh = true;                                        // k_finish rebuilt them from the new parameters
     return NEMGPU_OK;
 }
 
@@ -330,6 +340,7 @@ int init_partition(nemgpu_engine* e)
     e->cur = (e->cur + 1) % 3;
     e->masks_valid = false;
     if (e->ncem()) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, (int)e->sweep_counter, 1, e->stream));
     return NEMGPU_OK;
 }
 
@@ -340,13 +351,17 @@ int init_partition(nemgpu_engine* e)
 // an iteration (label masks + "moved" flag, or the fuzzy convergence test) is enqueued right behind
 // the first two relaxation rounds; if a sweep needs more rounds than that, the pipeline stops and the
 // host finishes that iteration round by round (rare: labels are sticky).
-int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf)
+// `ctrl` (pipelined loop only): the loop tests run in the last block of the bookkeeping kernel
+int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctrl = nullptr)
 {
-    if (e->ncem()) return do_labels_post(e, newbuf, oldbuf);
+    if (e->ncem()) return do_labels_post(e, newbuf, oldbuf, ctrl);
     if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
         launch_conv_fuzzy((size_t)e->n * e->k, e->cbuf[newbuf] + (size_t)e->lo * e->k,
-                          e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stop_ptr,
+                          e->cbuf[oldbuf] + (size_t)e->lo * e->k, e->cfg.cvthres, e->iter_flags(), e->stop_ptr, ctrl,
                           e->stream);
+        HIPCHK(hipGetLastError());
+    } else if (ctrl != nullptr) {
+        launch_ctrl(*ctrl, e->stream);
         HIPCHK(hipGetLastError());
     }
     return NEMGPU_OK;
@@ -368,13 +383,11 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     SweepCtx c;
     e->sweep_counter = sweep_id;
     if ((r = sweep_enqueue(e, e->cfg.beta, c))) { e->cur = saved; return r; }
-    if ((r = post_sweep(e, (cur + 1) % 3, cur))) { e->cur = saved; return r; }
     CtrlArgs ca;
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = c.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
-    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres;
-    launch_ctrl(ca, e->stream);
-    HIPCHK(hipGetLastError());
+    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; }
     e->cur = saved;
     return NEMGPU_OK;
 }
@@ -386,17 +399,41 @@ int iterate(nemgpu_engine* e, int n_iters)
         const int g = std::min(n_iters, kPipeDepth);
         const int base = e->cur;
         const uint32_t sweep0 = e->sweep_counter;
-        HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
-        e->stop_ptr = e->ctrl() + C_STOP;
-        // the first iteration of a batch may find MOVED / round flags dirty only if no density preceded it;
-        // enqueue_iteration always runs k_density (which clears them) before the sweep.
-        e->masks_valid = e->masks_valid && e->ncem();
-        for (int j = 0; j < g; j++) {
-            r = enqueue_iteration(e, (base + j) % 3, sweep0 + j);
-            if (r) { e->stop_ptr = nullptr; return r; }
+        // state every captured batch may rely on: class masks of the current labels, fresh tables when the
+        // parameters are fixed (otherwise k_finish rebuilds them inside the batch)
+        if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+        if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
+        const bool graphed = e->use_graphs && !e->prof && g < 8;
+        hipGraphExec_t exec = graphed ? e->graphs[base][g] : nullptr;
+        if (exec == nullptr) {
+            if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            r = NEMGPU_OK;
+            hipError_t herr = hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
+            e->stop_ptr = e->ctrl() + C_STOP;
+            for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)
+                r = enqueue_iteration(e, (base + j) % 3, sweep0 + j);
+            e->stop_ptr = nullptr;
+            if (herr == hipSuccess && r == NEMGPU_OK)
+                herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
+                                      e->stream);
+            if (graphed) {
+                hipGraph_t graph = nullptr;
+                hipError_t cerr = hipStreamEndCapture(e->stream, &graph);
+                if (herr == hipSuccess && r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    e->graphs[base][g] = exec;
+                } else {
+                    exec = nullptr;
+                    e->use_graphs = false;                         // fall back to plain launches for good
+                    if (herr == hipSuccess && cerr != hipSuccess) herr = cerr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                if (exec == nullptr && r == NEMGPU_OK && herr == hipSuccess) { e->sweep_counter = sweep0; continue; }   // redo this batch ungraphed
+            }
+            if (r) return r;
+            HIPCHK(herr);
         }
-        e->stop_ptr = nullptr;
-        HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        if (exec != nullptr) HIPCHK(hipGraphLaunch(exec, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         const int* c = e->h_ctrl();
         const int done = c[C_ITERS], commits = c[C_COMMITS];
@@ -411,6 +448,8 @@ int iterate(nemgpu_engine* e, int n_iters)
         if (e->prof && done < g) e->ev_used -= 2 * (g - done);     // launches that returned at the stop word
         n_iters -= done;
         e->flags_clean = false;
+        e->tables_fresh = true;
+        if (e->ncem()) e->masks_valid = true;
         if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
             e->status = NEMGPU_W_EMPTYCLASS;
             e->emptyk = c[C_EMPTYK];
@@ -428,6 +467,7 @@ int iterate(nemgpu_engine* e, int n_iters)
             a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = 1;
             a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
             a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep0 + (uint32_t)(done - 1);
+            a.sweep_id_ptr = nullptr;
             sc.r = 2; sc.checked = 2;
             if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
             int rounds = 0;
@@ -444,6 +484,13 @@ int iterate(nemgpu_engine* e, int n_iters)
         }
     }
     return NEMGPU_OK;
+}
+
+void drop_graphs(nemgpu_engine* e)
+{
+    for (auto& row : e->graphs)
+        for (auto& g : row)
+            if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
 
 int ensure_crit_buffers(nemgpu_engine* e)
@@ -491,6 +538,8 @@ int reset_state(nemgpu_engine* e)
         HIPCHK(hipMemcpyAsync(e->disp, e->disp0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
     }
     HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
+    HIPCHK(hipMemsetAsync(e->sweep_next, 0, sizeof(int), e->stream));
+    e->tables_fresh = false;
     e->cur = 0; e->sweep_counter = 0;
     e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
     e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
@@ -564,7 +613,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
     A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
     A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
-    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k));
+    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)2));   // [0] sweep number, [1] last-block ticket
     A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
     A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
     A(dev_alloc(&e->mask, (size_t)k * e->nw64));
@@ -585,11 +634,12 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->xw, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
                     e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
-                    e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
+                    e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->sweep_next, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
                     e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
                     e->crit6_dev, e->crit_lfi, e->crit_lzi};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->flags_host) (void)hipHostFree(e->flags_host);
+    drop_graphs(e);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -650,6 +700,7 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     }
     e->nnz = nnz;
     e->has_graph = nnz > 0;
+    drop_graphs(e);
     return NEMGPU_OK;
 }
 
@@ -676,6 +727,7 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
     e->cfg = *cfg;
     HIPCHK(hipSetDevice(e->device));
+    drop_graphs(e);                                                // kernel arguments are baked into captured batches
     return reset_state(e);
 }
 
@@ -782,7 +834,7 @@ int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev,
 {
     if (!e || !labels_global_dev || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), nullptr, e->stream);
+    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), nullptr, nullptr, e->stream);
     launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, nullptr, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = false;
@@ -793,10 +845,9 @@ int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev)
 {
     if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    launch_mstep_centers_ncem(e->k, e->d, stats_dev, e->center, e->nbobs_k, e->iner, nullptr, e->stream);
-    launch_mstep_disp(e->k, e->d, e->n_total, e->cfg.disper, e->cfg.propor, e->nbobs_k, e->iner, e->disp, e->prop,
-                      e->iter_flags(), nullptr, e->stream);
+    launch_finish(finish_args(e, 1, stats_dev), e->stream);
     HIPCHK(hipGetLastError());
+    e->tables_fresh = true;
     return NEMGPU_OK;
 }
 

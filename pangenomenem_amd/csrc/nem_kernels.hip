@@ -83,59 +83,51 @@ __global__ void k_layout_bits(const uint32_t* __restrict__ xw, int npad, int d, 
 //   "null density" bit when the mismatch is non-zero (nem_mod.c:662-666).
 // Padding organisms (d >= D) get all-zero entries: the chain step is then an exact no-op.
 // ------------------------------------------------------------------------------------------
-__global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
-                         const float* __restrict__ center, const float* __restrict__ disp,
-                         double2* __restrict__ tabT, double* __restrict__ tabL0,
-                         uint32_t* __restrict__ nz0, uint32_t* __restrict__ nz1,
-                         uint32_t* __restrict__ am0, uint32_t* __restrict__ am1,
-                         double2* __restrict__ uni, int* __restrict__ nonuni, int epoch,
-                         double* __restrict__ pk, float* __restrict__ logpk, int* __restrict__ flags,
-                         const int* __restrict__ stop)
+// one table entry t = k * dpad + dd; called by whole waves (dpad % 64 == 0)
+__device__ inline void table_entry(const FinishArgs& a, int t)
 {
-    if (stop != nullptr && *stop) return;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;      // over K * dpad (dpad % 64 == 0)
-    int lane = threadIdx.x & 63;
-    if (t >= K * dpad) return;
-    int k = t / dpad, dd = t - k * dpad;
+    const int K = a.K, D = a.D, dpad = a.dpad;
+    const int lane = threadIdx.x & 63;
+    (void)K;
+    const int k = t / dpad, dd = t - k * dpad;
     double t0 = 0.0, t1 = 0.0, l0 = 0.0;
     int n0 = 0, n1 = 0, a0 = 0, a1 = 0;
     if (dd < D) {
-        float eps = disp[k * D + dd];
-        float mu = center[k * D + dd];
-        int ad0 = abs((int)(0.0f - mu));
-        int ad1 = abs((int)(1.0f - mu));
+        const float eps = a.disp[k * D + dd];
+        const float mu = a.center[k * D + dd];
+        const int ad0 = abs((int)(0.0f - mu));
+        const int ad1 = abs((int)(1.0f - mu));
         a0 = (ad0 != 0); a1 = (ad1 != 0);
-        bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(disp[k * D]));
+        bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(a.disp[k * D]));
         if ((double)eps > kEpsilonD) {
-            double l1 = log((double)((1.0f - eps) / eps));
+            const double l1 = log((double)((1.0f - eps) / eps));
             l0 = log((double)(1.0f - eps));
             t0 = (double)ad0 * l1;
             t1 = (double)ad1 * l1;
-            if (dd == 0) uni[k] = make_double2(l1, l0);
+            if (dd == 0) a.uni[k] = make_double2(l1, l0);
             if (!isfinite(l1) || !isfinite(l0)) general = true;   // 0 * inf / NaN must propagate as in the reference
         } else {
             n0 = a0; n1 = a1;
             general = true;
         }
-        // class k may use the uniform-dispersion chain only if every organism agrees (epoch-stamped,
-        // so the word never needs clearing)
-        if (general) nonuni[k] = epoch;
+        // class k may use the uniform-dispersion chain only if every organism agrees
+        if (general) a.nonuni[k] = 1;
     }
-    tabT[t] = make_double2(t0, t1);
-    tabL0[t] = l0;
-    uint64_t m0 = __ballot(n0), m1 = __ballot(n1), b0 = __ballot(a0), b1 = __ballot(a1);
+    a.tabT[t] = make_double2(t0, t1);
+    a.tabL0[t] = l0;
+    const uint64_t m0 = __ballot(n0), m1 = __ballot(n1), b0 = __ballot(a0), b1 = __ballot(a1);
     if (lane == 0) {
-        int w = t >> 5;                                  // word index inside [K][dpad/32]
-        nz0[w] = (uint32_t)m0; nz0[w + 1] = (uint32_t)(m0 >> 32);
-        nz1[w] = (uint32_t)m1; nz1[w + 1] = (uint32_t)(m1 >> 32);
-        am0[w] = (uint32_t)b0; am0[w + 1] = (uint32_t)(b0 >> 32);
-        am1[w] = (uint32_t)b1; am1[w + 1] = (uint32_t)(b1 >> 32);
+        const int w = t >> 5;                            // word index inside [K][dpad/32]
+        a.nz0[w] = (uint32_t)m0; a.nz0[w + 1] = (uint32_t)(m0 >> 32);
+        a.nz1[w] = (uint32_t)m1; a.nz1[w + 1] = (uint32_t)(m1 >> 32);
+        a.am0[w] = (uint32_t)b0; a.am0[w + 1] = (uint32_t)(b0 >> 32);
+        a.am1[w] = (uint32_t)b1; a.am1[w + 1] = (uint32_t)(b1 >> 32);
     }
     if (dd == 0) {                                       // ComputePkFkiM, nem_alg.c:2262-2271
-        double p = (double)prop[k];
-        pk[k] = p;
-        if (p > kEpsilonD) logpk[k] = (float)log(p);
-        else { logpk[k] = -INFINITY; atomicOr(&flags[FLAG_EMPTY_PROP], 1); }
+        const double p = (double)a.prop[k];
+        a.pk[k] = p;
+        if (p > kEpsilonD) a.logpk[k] = (float)log(p);
+        else { a.logpk[k] = -INFINITY; atomicOr(&a.flags[FLAG_EMPTY_PROP], 1); }
     }
 }
 
@@ -147,10 +139,15 @@ __global__ void k_tables(int K, int D, int dpad, const float* __restrict__ prop,
 // ------------------------------------------------------------------------------------------
 constexpr int DCH = 2048;
 
+__device__ inline float bern_step(float dk, bool b, double l1, double l0)
+{
+    return (float)(((double)dk + (b ? l1 : 0.0)) - l0);              // nem_mod.c:661
+}
+
 struct DensityArgs {
     const uint32_t* xw; int n, npad, dpad, D;
     const double2* tabT; const double* tabL0; const uint32_t* nz0; const uint32_t* nz1;
-    const uint32_t* am0; const uint32_t* am1; const double2* uni; const int* nonuni; int epoch;
+    const uint32_t* am0; const uint32_t* am1; const double2* uni; const int* nonuni;
     const double* pk; const float* logpk;
     double* pkfki; float* logpkfki;
     int* zero_flags; int n_zero_flags;
@@ -163,18 +160,22 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
     __shared__ double sL[DCH];
     if (a.stop != nullptr && *a.stop) return;
     const int k = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;        // i < npad by construction
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;                // i < npad by construction
     const int npad = a.npad, dpad = a.dpad;
     const int W = dpad >> 5;
     float dk = 0.0f;
     uint32_t nul = 0;
     // the sweep that follows this launch starts from clean flags (MOVED + the relaxation-round window)
     if (blockIdx.x == 0 && blockIdx.y == 0)
-        for (int t = threadIdx.x; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
+        for (int t = tid; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
 
-    if (a.nonuni[k] != a.epoch) {
+    if (a.nonuni[k] == 0) {
         // ---- uniform dispersion in this class (sk_, s__, the default .m): the step constants are two
         // wave-uniform doubles; which organisms mismatch comes from two bit masks per word.
+        // (An exact "fast-forward" of whole runs of steps inside one float binade -- integer adds on the
+        // bit pattern + popcounts -- was built and is bit-identical, but lane divergence at the binade
+        // crossings made it slower than this plain chain at D = 500)
         const double l1 = a.uni[k].x, l0 = a.uni[k].y;
         const int wlast = (a.D - 1) >> 5;                // padding organisms must not take a step here
         uint32_t xnext = a.xw[i];
@@ -185,15 +186,9 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
             const int nb = (w < wlast) ? 32 : (a.D - (wlast << 5));
             if (nb == 32) {
 #pragma unroll
-                for (int b = 0; b < 32; b++) {
-                    const double add = ((m >> b) & 1u) ? l1 : 0.0;
-                    dk = (float)(((double)dk + add) - l0);       // nem_mod.c:661
-                }
+                for (int b = 0; b < 32; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
             } else {
-                for (int b = 0; b < nb; b++) {
-                    const double add = ((m >> b) & 1u) ? l1 : 0.0;
-                    dk = (float)(((double)dk + add) - l0);
-                }
+                for (int b = 0; b < nb; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
             }
         }
     } else {
@@ -201,7 +196,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         for (int d0 = 0; d0 < dpad; d0 += DCH) {
             const int dn = min(DCH, dpad - d0);
             __syncthreads();
-            for (int t = threadIdx.x; t < dn; t += 256) {
+            for (int t = tid; t < dn; t += 256) {
                 sT[t] = a.tabT[(size_t)k * dpad + d0 + t];
                 sL[t] = a.tabL0[(size_t)k * dpad + d0 + t];
             }
@@ -315,7 +310,8 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
 #pragma unroll
             for (int k = 1; k < KA; k++) if (k < K && k > kmax && cf[k] == ukmax) nequal++;
             if (nequal > 0) {
-                int pick = (int)(mix32(a.tie_seed, a.sweep_id, (uint32_t)gi) % (uint32_t)(nequal + 1));
+                const uint32_t sid = a.sweep_id_ptr != nullptr ? (uint32_t)*a.sweep_id_ptr : a.sweep_id;
+                int pick = (int)(mix32(a.tie_seed, sid, (uint32_t)gi) % (uint32_t)(nequal + 1));
                 int seen = 0, chosen = kmax;
 #pragma unroll
                 for (int k = 1; k < KA; k++)
@@ -357,28 +353,91 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-side loop control (one thread, once per EM iteration).  The host enqueues several
+// iterations ahead; every loop kernel returns at once when ctrl[C_STOP] is set, so the host only
+// has to look at `ctrl` once per batch instead of once per iteration (NemAlgo's loop test,
+// nem_alg.c:1789-1840: convergence, empty class; plus "the sweep needs more relaxation rounds").
+// Runs in the last block to finish of the iteration's bookkeeping kernel (k_labels_post /
+// k_conv_fuzzy), or as its own tiny launch when there is no such kernel.
+// ------------------------------------------------------------------------------------------
+__device__ inline void ctrl_logic(const CtrlArgs& a)
+{
+    int* c = a.ctrl;
+    if (c[C_STOP]) return;
+    c[C_ITERS] += 1;
+    *a.sweep_next += 1;                                           // the tie-break hash is keyed by the sweep number
+    const int emptyk = a.iter_flags[FLAG_EMPTYK];
+    const int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
+    const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!a.param_fix && emptyk != 0) {                            // nem_alg.c:1831-1838: E-step "not run"
+        c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
+        c[C_EMPTYK] = emptyk;
+        c[C_STOP] = 1;
+        return;
+    }
+    const int* f = a.round0;
+    int rounds = 1;
+    if (a.use_nei && ch0 != 0) {
+        if (ch1 != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
+        f = a.round1; rounds = 2;
+    }
+    c[C_SWEEP_ROUNDS] += rounds;
+    if (f[FLAG_NZERO] > 0) {
+        c[C_NZERO] += f[FLAG_NZERO];
+        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
+    }
+    c[C_COMMITS] += 1;
+    if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
+        const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
+        if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
+    }
+}
+
+// last-block-done ticket: returns true in exactly one thread of the grid, after every block's global
+// writes (made before its call) are visible to it
+__device__ inline bool last_block_ticket(int* ticket, int nblocks)
+{
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket, 1);
+        s_last = (t == nblocks - 1);
+        if (s_last) { *ticket = 0; __threadfence(); }
+    }
+    __syncthreads();
+    return s_last && threadIdx.x == 0;
+}
+
+__global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
+
+void launch_ctrl(const CtrlArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a); }
+
+// ------------------------------------------------------------------------------------------
 // NCEM bookkeeping after a sweep: per-class membership bitmasks (for the popcount M-step) and
 // the CVTEST_CLAS flag (HasConverged, nem_alg.c:2075-2089: max|c - cold| is 1 iff a label moved).
 // ------------------------------------------------------------------------------------------
 __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* __restrict__ lab_new,
                               const uint8_t* __restrict__ lab_old, uint64_t* __restrict__ mask,
-                              int* __restrict__ flags, const int* __restrict__ stop)
+                              int* __restrict__ flags, const int* __restrict__ stop, CtrlArgs ca)
 {
     if (stop != nullptr && *stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = i >> 6;
-    if (wave >= nw64) return;
-    int lab = 255, moved = 0;
-    if (i < n_local) {
-        lab = lab_new[lo + i];
-        if (lab_old != nullptr) moved = (lab != (int)lab_old[lo + i]);
+    if (wave < nw64) {
+        int lab = 255, moved = 0;
+        if (i < n_local) {
+            lab = lab_new[lo + i];
+            if (lab_old != nullptr) moved = (lab != (int)lab_old[lo + i]);
+        }
+        for (int k = 0; k < K; k++) {
+            uint64_t m = __ballot(lab == k);
+            if (lane == 0) mask[(size_t)k * nw64 + wave] = m;
+        }
+        if (__any(moved) && lane == 0) atomicOr(&flags[FLAG_MOVED], 1);
     }
-    for (int k = 0; k < K; k++) {
-        uint64_t m = __ballot(lab == k);
-        if (lane == 0) mask[(size_t)k * nw64 + wave] = m;
-    }
-    if (__any(moved) && lane == 0) atomicOr(&flags[FLAG_MOVED], 1);
+    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
 }
 
 // M1-M3 for NCEM as integer counts: S1[k][d] = #{i : label_i = k, x_id = 1}, N_k = #{label = k}.
@@ -412,13 +471,9 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
 //   N_K = count (EstimSizes, nem_mod.c:1293-1315);  halfwei = N_K/2;  zeros-side weight S0 = N_K - S1;
 //   ComputeMedian (nem_mod.c:1439-1477) gives mu = 0 if S0 > half, 0.5 if S0 == half, 1 otherwise;
 //   EstimLaplaceIner (nem_mod.c:1669-1686) gives S1, S0 or N_K/2 for mu = 0, 1, 0.5 (all exact).
-__global__ void k_mstep_centers_ncem(int K, int D, const int* __restrict__ stats, float* __restrict__ center,
-                                     float* __restrict__ nbobs_k, float* __restrict__ iner,
-                                     const int* __restrict__ stop)
+__device__ inline void centers_ncem_entry(int K, int D, const int* __restrict__ stats, float* __restrict__ center,
+                                          float* __restrict__ nbobs_k, float* __restrict__ iner, int t)
 {
-    if (stop != nullptr && *stop) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= K * D) return;
     const int k = t / D;
     const int nk = stats[k];
     const float nkf = (float)nk;
@@ -451,11 +506,19 @@ __device__ inline void seq_sum_pair(const float4* __restrict__ v4, int n4, float
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, int disper, int propor,
-                                                     const float* __restrict__ nbobs_k,
-                                                     const float* __restrict__ iner, float* __restrict__ disp,
-                                                     float* __restrict__ prop, int* __restrict__ flags,
-                                                     const int* __restrict__ stop)
+__device__ inline long long wave_reduce_add_ll(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// `exact_half_ints`: the inertia values are non-negative multiples of 1/2 and N_K is an integer (NCEM).
+// Then a d-ordered float chain whose total stays below 2^24 half-units never rounds, and equals the
+// closed form; only larger totals (e.g. 50 000 x 1 000) take the sequential chain.
+__device__ inline void disp_body(int K, int D, int n_total, int disper, int propor, int exact_half_ints,
+                                 const float* __restrict__ nbobs_k, const float* __restrict__ iner,
+                                 float* __restrict__ disp, float* __restrict__ prop, int* __restrict__ flags)
 {
     constexpr int CAP = 12288;                           // staged inertia values (48 KB)
     __shared__ float4 s_in4[CAP / 4];
@@ -463,14 +526,41 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
     __shared__ int s_valid[kMaxKernelK];
     __shared__ float s_vol;
     float* s_in = reinterpret_cast<float*>(s_in4);
+    __shared__ unsigned long long s_tot2[kMaxKernelK];
+    __shared__ int s_seq[kMaxKernelK];
     const int tid = threadIdx.x;
-    if (stop != nullptr && *stop) return;
     if (disper == NEMGPU_DISP_K_) {
+        // closed form where the chain provably never rounds (see above)
+        if (tid < K) { s_tot2[tid] = 0ull; s_seq[tid] = 1; s_valid[tid] = 0; }
+        __syncthreads();
+        if (exact_half_ints) {
+            for (int k = 0; k < K; k++) {
+                long long acc = 0;
+                for (int d = tid; d < D; d += 1024) acc += (long long)(2.0f * iner[k * D + d]);
+                acc = wave_reduce_add_ll(acc);
+                if ((tid & 63) == 0 && acc != 0) atomicAdd(&s_tot2[k], (unsigned long long)acc);
+            }
+            __syncthreads();
+            if (tid < K) {
+                const float nk = nbobs_k[tid];
+                const long long cap = 1ll << 24;
+                if ((long long)s_tot2[tid] <= cap && (long long)nk * (long long)D <= cap) {
+                    s_seq[tid] = 0;
+                    s_valid[tid] = (nk > 0);
+                    if (nk > 0) s_disp[tid] = (0.5f * (float)(long long)s_tot2[tid]) / (nk * (float)D);
+                }
+            }
+            __syncthreads();
+        }
+        bool any_seq = false;
+        for (int k = 0; k < K; k++) any_seq |= (s_seq[k] != 0);
         // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains.  Classes run on
         // different waves; a class's D values are staged in LDS (D4 = D rounded down to 4, tail scalar).
         const int dq = D & ~3;
         const int per = max(1, min(K, CAP / max(D, 1)));          // classes staged per pass
-        if (per >= 1 && D <= CAP) {
+        if (!any_seq) {
+            // nothing left for the sequential chains
+        } else if (per >= 1 && D <= CAP) {
             for (int k0 = 0; k0 < K; k0 += per) {
                 const int kn = min(per, K - k0);
                 __syncthreads();
@@ -483,6 +573,7 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
                 if ((tid & 63) == 0) {
                     for (int kk = wv; kk < kn; kk += 16) {
                         const int k = k0 + kk;
+                        if (!s_seq[k]) continue;
                         const float nk = nbobs_k[k];
                         s_valid[k] = (nk > 0);
                         if (nk > 0) {
@@ -496,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
                 }
             }
         } else {                                                   // very wide matrices: straight from global
-            if (tid < K) {
+            if (tid < K && s_seq[tid]) {
                 const int k = tid;
                 const float nk = nbobs_k[k];
                 s_valid[k] = (nk > 0);
@@ -549,6 +640,27 @@ __global__ __launch_bounds__(1024) void k_mstep_disp(int K, int D, int n_total, 
         for (int k = 0; k < K; k++) if (!((double)nbobs_k[k] > kEpsilonD)) ek = k + 1;
         flags[FLAG_EMPTYK] = ek;
     }
+}
+
+// The whole parameter update behind the sufficient statistics in ONE single-block launch:
+// centres + inertia (NCEM, from the counts), dispersion + proportions, then the density tables
+// E1 reads.  K*D is small (1 500 at configs[1], 15 000 at configs[3]); the only long part is the
+// d-ordered float chain of the sk_/s__ models.
+__global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
+{
+    if (a.stop != nullptr && *a.stop) return;
+    const int tid = threadIdx.x;
+    if (a.mode == 1) {
+        for (int t = tid; t < a.K * a.D; t += 1024) centers_ncem_entry(a.K, a.D, a.stats, a.center, a.nbobs_k, a.iner, t);
+        __syncthreads();
+    }
+    if (a.mode != 0) {
+        disp_body(a.K, a.D, a.n_total, a.disper, a.propor, a.mode == 1, a.nbobs_k, a.iner, a.disp, a.prop, a.flags);
+        __syncthreads();
+    }
+    if (tid < a.K) a.nonuni[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < a.K * a.dpad; t += 1024) table_entry(a, t);     // K*dpad and 1024 are multiples of 64
 }
 
 // ------------------------------------------------------------------------------------------
@@ -643,7 +755,7 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
 
 // CVTEST_CLAS for float partitions (nem_alg.c:2077-2088): converged iff no |c - cold| >= thres
 __global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float* __restrict__ cold, float thres,
-                             int* __restrict__ flags, const int* __restrict__ stop)
+                             int* __restrict__ flags, const int* __restrict__ stop, CtrlArgs ca)
 {
     if (stop != nullptr && *stop) return;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -654,45 +766,8 @@ __global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float*
         bad = (dif >= thres);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
+    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
 }
-
-// ------------------------------------------------------------------------------------------
-// Device-side loop control (one thread, once per EM iteration).  The host enqueues several
-// iterations ahead; every loop kernel returns at once when ctrl[C_STOP] is set, so the host only
-// has to look at `ctrl` once per batch instead of once per iteration (NemAlgo's loop test,
-// nem_alg.c:1789-1840: convergence, empty class; plus "the sweep needs more relaxation rounds").
-// ------------------------------------------------------------------------------------------
-__global__ void k_ctrl(CtrlArgs a)
-{
-    int* c = a.ctrl;
-    if (c[C_STOP]) return;
-    c[C_ITERS] += 1;
-    if (!a.param_fix && a.iter_flags[FLAG_EMPTYK] != 0) {         // nem_alg.c:1831-1838: E-step "not run"
-        c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
-        c[C_EMPTYK] = a.iter_flags[FLAG_EMPTYK];
-        c[C_STOP] = 1;
-        return;
-    }
-    const int* f = a.round0;
-    int rounds = 1;
-    if (a.use_nei && a.round0[FLAG_CHANGED] != 0) {
-        if (a.round1[FLAG_CHANGED] != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
-        f = a.round1; rounds = 2;
-    }
-    c[C_SWEEP_ROUNDS] += rounds;
-    if (f[FLAG_NZERO] > 0) {
-        c[C_NZERO] += f[FLAG_NZERO];
-        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
-    }
-    c[C_COMMITS] += 1;
-    if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
-        const int moved = a.iter_flags[FLAG_MOVED];
-        const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
-        if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
-    }
-}
-
-void launch_ctrl(const CtrlArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a); }
 
 // labels -> one-hot float rows (LabelToClassVector, nem_alg.c:649-664)
 __global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* __restrict__ c)
@@ -802,50 +877,33 @@ void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, in
     hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
 }
 
-void launch_tables(const TableArgs& t, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_tables, dim3((t.K * t.dpad + 255) / 256), dim3(256), 0, s, t.K, t.D, t.dpad, t.prop, t.center,
-                       t.disp, t.tabT, t.tabL0, t.nz0, t.nz1, t.am0, t.am1, t.uni, t.nonuni, t.epoch, t.pk, t.logpk,
-                       t.flags, t.stop);
-}
+void launch_finish(const FinishArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, s, a); }
 
-void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                     int* zero_flags, int n_zero_flags, hipStream_t s)
 {
     DensityArgs a;
     a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D;
     a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
-    a.uni = t.uni; a.nonuni = t.nonuni; a.epoch = t.epoch; a.pk = t.pk; a.logpk = t.logpk;
+    a.uni = t.uni; a.nonuni = t.nonuni; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
     a.stop = t.stop;
     hipLaunchKernelGGL(k_density, dim3(npad / 256, t.K), dim3(256), 0, s, a);
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
-                        uint64_t* mask, int* flags, const int* stop, hipStream_t s)
+                        uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s)
 {
+    CtrlArgs ca{};
+    if (ctrl != nullptr) ca = *ctrl;
     hipLaunchKernelGGL(k_labels_post, dim3((nw64 * 64 + 255) / 256), dim3(256), 0, s, n_local, lo, K, nw64, lab_new,
-                       lab_old, mask, flags, stop);
+                       lab_old, mask, flags, stop, ca);
 }
 
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
                          const int* stop, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mstep_counts, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
-}
-
-void launch_mstep_centers_ncem(int K, int D, const int* stats, float* center, float* nbobs_k, float* iner,
-                               const int* stop, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_mstep_centers_ncem, dim3((K * D + 255) / 256), dim3(256), 0, s, K, D, stats, center, nbobs_k,
-                       iner, stop);
-}
-
-void launch_mstep_disp(int K, int D, int n_total, int disper, int propor, const float* nbobs_k, const float* iner,
-                       float* disp, float* prop, int* flags, const int* stop, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_mstep_disp, dim3(1), dim3(1024), 0, s, K, D, n_total, disper, propor, nbobs_k, iner, disp,
-                       prop, flags, stop);
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
@@ -858,10 +916,12 @@ void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
-                       hipStream_t s)
+                       const CtrlArgs* ctrl, hipStream_t s)
 {
+    CtrlArgs ca{};
+    if (ctrl != nullptr) ca = *ctrl;
     hipLaunchKernelGGL(k_conv_fuzzy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, c, cold, thres, flags,
-                       stop);
+                       stop, ca);
 }
 
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)

@@ -24,6 +24,8 @@ enum { C_STOP = 0, C_ITERS = 1, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CON
 struct CtrlArgs {
     int* ctrl; const int* iter_flags; const int* round0; const int* round1;
     int param_fix, use_nei, cvtest, ncem; float cvthres;
+    int* sweep_next;               // device word: number of the next sweep (tie-break hash key)
+    int* ticket;                   // last-block-done counter (self-resetting)
 };
 void launch_ctrl(const CtrlArgs& a, hipStream_t s);
 
@@ -37,6 +39,7 @@ struct SweepArgs {
     // fuzzy state: float rows [n_total][K], GLOBAL family indexing
     const float* c_old; const float* c_guess; float* c_out;
     int tie_rule; uint32_t tie_seed; uint32_t sweep_id;
+    const int* sweep_id_ptr;                   // when set, the sweep number is read from the device instead
     int* flags;                                // this round's slot
     const int* prev_changed;                   // previous round's FLAG_CHANGED (nullptr for round 0)
     const int* stop;                           // loop-control stop word (nullptr outside the pipelined loop)
@@ -44,31 +47,29 @@ struct SweepArgs {
 
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
                    hipStream_t s);
-// per-(class, organism) density constants, produced by k_tables and consumed by k_density
-struct TableArgs {
-    int K, D, dpad;
-    const float* prop; const float* center; const float* disp;
-    double2* tabT; double* tabL0; uint32_t* nz0; uint32_t* nz1;   // general path
-    uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni; int epoch;   // uniform-dispersion path
+// parameter update + density tables (k_finish); also carries the table pointers k_density reads
+struct FinishArgs {
+    int mode;                      // 0: tables only; 1: NCEM centres from counts + dispersion + tables; 2: dispersion + tables
+    int K, D, dpad, n_total, disper, propor;
+    const int* stats;
+    float* prop; float* center; float* disp; float* nbobs_k; float* iner;
+    double2* tabT; double* tabL0; uint32_t* nz0; uint32_t* nz1;
+    uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni;
     double* pk; float* logpk; int* flags;
     const int* stop;
 };
-void launch_tables(const TableArgs& t, hipStream_t s);
-void launch_density(const TableArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+void launch_finish(const FinishArgs& a, hipStream_t s);
+void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                     int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
-                        uint64_t* mask, int* flags, const int* stop, hipStream_t s);
+                        uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s);
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
                          const int* stop, hipStream_t s);
-void launch_mstep_centers_ncem(int K, int D, const int* stats, float* center, float* nbobs_k, float* iner,
-                               const int* stop, hipStream_t s);
-void launch_mstep_disp(int K, int D, int n_total, int disper, int propor, const float* nbobs_k, const float* iner,
-                       float* disp, float* prop, int* flags, const int* stop, hipStream_t s);
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
                         float* in0, float* in1, float* inh, float* center, float* iner, const int* stop, hipStream_t s);
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
-                       hipStream_t s);
+                       const CtrlArgs* ctrl, hipStream_t s);
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s);
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
                      float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,

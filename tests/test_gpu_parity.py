@@ -40,6 +40,32 @@ def test_density_matches_oracle(gpu_lib, oracle, n, d, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,seed", [(1500, 15, 1), (900, 500, 2), (400, 3100, 3), (700, 97, 4)])
+def test_density_uniform_dispersion_fast_forward(gpu_lib, oracle, n, d, seed):
+    """One epsilon per class (sk_, s__, the default .m): the kernel replaces runs of chain steps inside a
+    float binade by integer adds on the bit pattern.  Must stay bit-identical to the step-by-step chain
+    for any epsilon in (0, 1/2], tiny ones, 1/2 itself, centres 0 / 1/2 / 1, and thousands of organisms."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed)
+    for trial in range(6):
+        k = [3, 2, 5, 10, 3, 4][trial]
+        eps = rng.uniform(1e-3, 0.5, size=k).astype(np.float32)
+        if trial == 1:
+            eps[:] = [0.5, 1e-7][:k]
+        if trial == 4:
+            eps[:] = [1e-19, 0.25, 0.4999999]
+        center = rng.choice(np.array([0.0, 0.5, 1.0], np.float32), size=(k, d))
+        center[0] = 1.0
+        disp = np.repeat(eps[:, None], d, axis=1)
+        prop = np.full(k, 1.0 / k, np.float32)
+        eng = make_engine(x, None, k, prop, center, disp)
+        pk, lp = eng.density()
+        opk, olp, _ = oracle.density(x, prop, center, disp)
+        assert bits_equal(lp, olp), (trial, eps)
+        assert ulp_diff64(pk, opk) <= 2
+        eng.close()
+
+
 def test_density_null_dispersion_and_half_centres(gpu_lib, oracle):
     n, d = 512, 70
     x, _ = synth.bernoulli_pa_matrix(n, d, 9)
