@@ -143,20 +143,33 @@ int nemgpu_mstep(nemgpu_engine* e, int* emptyk);          /* M only */
 int nemgpu_criteria(nemgpu_engine* e, float crit6[6]);    /* C1 only */
 
 /* Multi-GPU step pieces (NCEM; families sharded across engines in contiguous blocks).  The host
-   driver (pangenomenem_amd/distributed.py) owns the GLOBAL label arrays (uint8[n_total], device
-   memory) and the statistics buffer and runs the collectives (RCCL through torch.distributed)
-   between these calls.  All calls are asynchronous on the engine's stream.
-     stats layout: int32[k + k*d] = { N_k, S1[k][j] = #{i in shard : label_i = k, x_ij = 1} }.    */
+   driver (pangenomenem_amd/distributed.py) owns the all-gathered label arrays (device memory) and
+   the statistics buffer and runs the collectives (RCCL through torch.distributed) between these
+   calls.  All calls are asynchronous on the engine's stream; between nemgpu_shard_begin and
+   nemgpu_shard_end the loop tests run on the device, as in the single-GPU pipelined loop.
+
+   Label arrays are uint8[world * stride]: rank r owns slots [r*stride, r*stride + blk) (its families,
+   in order) and the byte at r*stride + blk carries its "a label changed in this round" flag, so ONE
+   all-gather per relaxation round moves labels and flags together.  The engine is created with
+   n_total = world*stride, site_lo = rank*stride, site_hi = site_lo + (families of the shard) and the
+   graph's neighbour indices are slot indices.
+   stats: int32[k + k*d] = { N_k, S1[k][j] = #{i in shard : label_i = k, x_ij = 1} }.                  */
 int nemgpu_stats_words(const nemgpu_engine* e);
-int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev, int32_t* stats_dev);
-int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev);   /* after all-reduce(sum) */
-int nemgpu_ext_density(nemgpu_engine* e);                                   /* tables + E1 on the shard */
-/* One relaxation round of the E2 sweep for the shard: reads labels_old (partition before the sweep) and
-   labels_guess (previous round's output, all-gathered), writes labels_out[site_lo..site_hi) and ORs 1
-   into flags4_dev[0] when a label differs from its guess (flags4_dev: int32[4], zeroed by the caller). */
-int nemgpu_ext_sweep_round(nemgpu_engine* e, float beta, uint32_t sweep_id, const uint8_t* labels_old_dev,
-                           const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* flags4_dev);
-int nemgpu_ext_emptyk(nemgpu_engine* e, int* emptyk);                       /* syncs the stream */
+int nemgpu_shard_layout(nemgpu_engine* e, int world, int rank, int blk, int stride, int n_families_total);
+int nemgpu_shard_begin(nemgpu_engine* e);
+int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, int32_t* stats_dev);
+/* stats_dev (all-reduced) -> parameters, or NULL to keep them; density; round 0; sweep_id < 0 = device counter */
+int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float beta, int sweep_id,
+                              const uint8_t* labels_old_dev, uint8_t* labels_out_dev);
+int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                              const uint8_t* labels_guess_dev, uint8_t* labels_out_dev);
+int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, const uint8_t* labels_old_dev,
+                                  const uint8_t* labels_q_dev, const uint8_t* labels_r_dev);
+int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                            const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int* changed);
+int nemgpu_shard_end_enqueue(nemgpu_engine* e);   /* async copy of the control block; last call of a batch */
+int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* need_rounds);   /* sync + report */
+int nemgpu_shard_set_sweep_number(nemgpu_engine* e, int next_sweep);
 
 /* Test hook: load a partition (row-major [n_total x k], HOST) as the current state
    (argmax labels for ncem engines). */
@@ -186,11 +199,13 @@ int nemio_write_cf(const char* path, const float* c_nk, int n, int k, int tie_ru
 int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, int k, const float* center,
                    const float* prop, const float* disp);
 
-/* Kernel timing probe for bench.py: average duration (ms) of the E1 density kernel over the
-   launches since the last call, measured with hipEvents on the engine's stream. */
-int nemgpu_profile_enable(nemgpu_engine* e, int on);
-int nemgpu_profile_read(nemgpu_engine* e, double* density_ms_avg, int* density_launches,
-                        double* algorithmic_bytes_per_launch);
+/* Kernel-duration probe for bench.py: `reps` launches of the E1 density kernel on the current
+   parameters, each bracketed by HIP events on the engine's stream; average duration (ms) and the
+   algorithmic bytes one launch moves. */
+int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch);
+
+/* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
+int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);
 
 #ifdef __cplusplus
 }

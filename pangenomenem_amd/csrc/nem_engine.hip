@@ -39,6 +39,8 @@ constexpr int kRoundBatch = 2;    // rounds enqueued between host checks (round 
 
 struct nemgpu_engine {
     int n_total = 0, d = 0, k = 0, lo = 0, hi = 0, n = 0;
+    int n_true = 0;               // families of the whole problem (= n_total unless label slots carry padding)
+    int sh_world = 1, sh_rank = 0, sh_blk = 0, sh_stride = 0;   // sharded label-slot layout (stride 0 = plain)
     int npad = 0, dpad = 0, W = 0, wf = 0, nw64 = 0, device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -62,6 +64,7 @@ struct nemgpu_engine {
     int* nonuni = nullptr;
     int* sweep_next = nullptr;    // device word: number of the next E-step sweep (tie-break hash key)
     bool tables_fresh = false;    // density tables match prop/center/disp
+    bool density_fresh = false;   // pkfki / logpkfki match the tables
     double* pk = nullptr;
     float* logpk = nullptr;
     double* pkfki = nullptr;
@@ -91,10 +94,7 @@ struct nemgpu_engine {
     hipGraphExec_t graphs[3][8] = {};
     bool use_graphs = true;
 
-    // profiling of the E1 kernel
-    bool prof = false;
-    std::vector<hipEvent_t> ev;
-    int ev_used = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -142,7 +142,7 @@ FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
 {
     FinishArgs t;
     t.mode = mode;
-    t.K = e->k; t.D = e->d; t.dpad = e->dpad; t.n_total = e->n_total; t.disper = e->cfg.disper; t.propor = e->cfg.propor;
+    t.K = e->k; t.D = e->d; t.dpad = e->dpad; t.n_total = e->n_true; t.disper = e->cfg.disper; t.propor = e->cfg.propor;
     t.stats = stats;
     t.prop = e->prop; t.center = e->center; t.disp = e->disp; t.nbobs_k = e->nbobs_k; t.iner = e->iner;
     t.tabT = e->tabT; t.tabL0 = e->tabL0; t.nz0 = e->nz0; t.nz1 = e->nz1;
@@ -159,28 +159,17 @@ int do_tables(nemgpu_engine* e)
     launch_finish(finish_args(e, 0, nullptr), e->stream);
     HIPCHK(hipGetLastError());
     e->tables_fresh = true;
+    e->density_fresh = false;
     return NEMGPU_OK;
 }
 
 int do_density(nemgpu_engine* e)
 {
-    if (e->prof) {
-        if ((int)e->ev.size() < e->ev_used + 2) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b));
-            e->ev.push_back(a); e->ev.push_back(b);
-        }
-        HIPCHK(hipEventRecord(e->ev[e->ev_used], e->stream));
-    }
     launch_density(finish_args(e, 0, nullptr), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
                    1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = true;
-    if (e->prof) {
-        HIPCHK(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
-        e->ev_used += 2;
-    }
+    e->density_fresh = true;
     return NEMGPU_OK;
 }
 
@@ -310,6 +299,7 @@ int do_mstep(nemgpu_engine* e)
     }
     HIPCHK(hipGetLastError());
     e->tables_fresh = true;                                        // k_finish rebuilt them from the new parameters
+    e->density_fresh = false;
     return NEMGPU_OK;
 }
 
@@ -383,7 +373,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     SweepCtx c;
     e->sweep_counter = sweep_id;
     if ((r = sweep_enqueue(e, e->cfg.beta, c))) { e->cur = saved; return r; }
-    CtrlArgs ca;
+    CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = c.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
@@ -403,7 +393,7 @@ int iterate(nemgpu_engine* e, int n_iters)
         // parameters are fixed (otherwise k_finish rebuilds them inside the batch)
         if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
         if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
-        const bool graphed = e->use_graphs && !e->prof && g < 8;
+        const bool graphed = e->use_graphs && g < 8;
         hipGraphExec_t exec = graphed ? e->graphs[base][g] : nullptr;
         if (exec == nullptr) {
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -445,7 +435,6 @@ int iterate(nemgpu_engine* e, int n_iters)
         }
         e->cur = (base + commits) % 3;
         e->sweep_counter = sweep0 + (uint32_t)done;
-        if (e->prof && done < g) e->ev_used -= 2 * (g - done);     // launches that returned at the stop word
         n_iters -= done;
         e->flags_clean = false;
         e->tables_fresh = true;
@@ -540,6 +529,7 @@ int reset_state(nemgpu_engine* e)
     HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
     HIPCHK(hipMemsetAsync(e->sweep_next, 0, sizeof(int), e->stream));
     e->tables_fresh = false;
+    e->density_fresh = false;
     e->cur = 0; e->sweep_counter = 0;
     e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
     e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
@@ -587,7 +577,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (device < 0 || device >= ndev) { set_error("nemgpu_create: bad device index"); return NEMGPU_E_ARG; }
     HIPCHK(hipSetDevice(device));
     nemgpu_engine* e = new nemgpu_engine();
-    e->n_total = n_total; e->d = d; e->k = k; e->lo = site_lo; e->hi = site_hi; e->n = site_hi - site_lo;
+    e->n_total = n_total; e->n_true = n_total; e->d = d; e->k = k; e->lo = site_lo; e->hi = site_hi; e->n = site_hi - site_lo;
     e->device = device;
     e->npad = (e->n + 255) / 256 * 256;
     e->dpad = (d + 63) / 64 * 64;
@@ -640,7 +630,8 @@ void nemgpu_destroy(nemgpu_engine* e)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->flags_host) (void)hipHostFree(e->flags_host);
     drop_graphs(e);
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -827,66 +818,188 @@ int nemgpu_criteria(nemgpu_engine* e, float crit6[6])
     return criteria(e, crit6);
 }
 
-// ---- multi-GPU step pieces: same kernels, caller-owned global label arrays and statistics --------
+// ---- multi-GPU (sharded) step pieces ----------------------------------------------------------
+// Same kernels; the host driver (pangenomenem_amd/distributed.py) owns the all-gathered label arrays
+// and the statistics buffer and runs the collectives between these calls.  Everything is
+// asynchronous on the engine's stream; between nemgpu_shard_begin and nemgpu_shard_end the loop
+// control lives on the device (k_ctrl), exactly like the single-GPU pipelined loop.
 int nemgpu_stats_words(const nemgpu_engine* e) { return e ? e->k + e->k * e->d : 0; }
 
-int nemgpu_ext_mstep_partial(nemgpu_engine* e, const uint8_t* labels_global_dev, int32_t* stats_dev)
+int nemgpu_shard_layout(nemgpu_engine* e, int world, int rank, int blk, int stride, int n_true)
 {
-    if (!e || !labels_global_dev || !stats_dev) return NEMGPU_E_FUNCARG;
+    if (!e || world <= 0 || rank < 0 || rank >= world || blk <= 0 || stride < blk + 1 || n_true <= 0) return NEMGPU_E_FUNCARG;
+    if (e->lo != rank * stride || e->n > blk || e->n_total != world * stride) {
+        set_error("shard layout does not match the engine's slot range");
+        return NEMGPU_E_ARG;
+    }
+    e->sh_world = world; e->sh_rank = rank; e->sh_blk = blk; e->sh_stride = stride; e->n_true = n_true;
+    return NEMGPU_OK;
+}
+
+namespace {
+void shard_sweep_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id)
+{
+    a = SweepArgs{};
+    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
+    a.use_nei = (e->has_graph && beta != 0.0f) ? 1 : 0;
+    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
+    a.beta = beta; a.pkfki = e->pkfki;
+    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed;
+    a.sweep_id = sweep_id >= 0 ? (uint32_t)sweep_id : 0u;
+    a.sweep_id_ptr = sweep_id >= 0 ? nullptr : e->sweep_next;     // -1: the device keeps count (pipelined loop)
+    a.stop = e->stop_ptr;
+    a.n_ranks = e->sh_world; a.slot_stride = e->sh_stride; a.slot_pad = e->sh_stride - e->sh_blk;
+}
+uint8_t* own_flag_byte(nemgpu_engine* e, uint8_t* labels) { return labels + (size_t)e->sh_rank * e->sh_stride + e->sh_blk; }
+}  // namespace
+
+int nemgpu_shard_begin(nemgpu_engine* e)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
+    if (e->sh_stride == 0) { set_error("nemgpu_shard_layout must be called first"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
-    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_global_dev, nullptr, e->mask, e->iter_flags(), nullptr, nullptr, e->stream);
-    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, nullptr, e->stream);
+    HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
+    e->stop_ptr = e->ctrl() + C_STOP;
+    return NEMGPU_OK;
+}
+
+// local class masks of the current labels + popcounts -> stats_dev (then: all-reduce(sum))
+int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, int32_t* stats_dev)
+{
+    if (!e || !labels_cur_dev || !stats_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_cur_dev, nullptr, e->mask, e->iter_flags(), e->stop_ptr,
+                       nullptr, e->stream);
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = false;
     return NEMGPU_OK;
 }
 
-int nemgpu_ext_mstep_finalize(nemgpu_engine* e, const int32_t* stats_dev)
+// [parameter update from the summed statistics] + density + relaxation round 0 (guess = old) + this rank's
+// changed byte behind its label block (then: all-gather of labels_out)
+int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float beta, int sweep_id,
+                              const uint8_t* labels_old_dev, uint8_t* labels_out_dev)
 {
-    if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
-    HIPCHK(hipSetDevice(e->device));
-    launch_finish(finish_args(e, 1, stats_dev), e->stream);
-    HIPCHK(hipGetLastError());
-    e->tables_fresh = true;
-    return NEMGPU_OK;
-}
-
-int nemgpu_ext_density(nemgpu_engine* e)
-{
-    if (!e) return NEMGPU_E_FUNCARG;
+    if (!e || !labels_old_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     int r;
-    if ((r = do_tables(e))) return r;
-    return do_density(e);
-}
-
-int nemgpu_ext_sweep_round(nemgpu_engine* e, float beta, uint32_t sweep_id, const uint8_t* labels_old_dev,
-                           const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* flags4_dev)
-{
-    if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev || !flags4_dev) return NEMGPU_E_FUNCARG;
-    if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
-    HIPCHK(hipSetDevice(e->device));
-    SweepArgs a{};
-    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
-    a.use_nei = (e->has_graph && beta != 0.0f) ? 1 : 0;
-    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
-    a.beta = beta; a.pkfki = e->pkfki;
-    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id;
-    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
-    a.flags = flags4_dev; a.prev_changed = nullptr;
+    if (stats_dev != nullptr) {
+        launch_finish(finish_args(e, 1, stats_dev), e->stream);
+        HIPCHK(hipGetLastError());
+        e->tables_fresh = true;
+        e->density_fresh = false;
+    } else if ((r = do_tables(e))) return r;
+    if (e->density_fresh) { if ((r = clear_sweep_flags(e))) return r; }   // same parameters as the last E1: keep pkfki
+    else if ((r = do_density(e))) return r;                        // also clears MOVED + the round flag window
+    SweepArgs a;
+    shard_sweep_args(e, a, beta, sweep_id);
+    a.lab_old = labels_old_dev; a.lab_guess = labels_old_dev; a.lab_out = labels_out_dev;
+    a.flags = e->round_flags(0);
     launch_sweep(a, true, e->stream);
+    launch_publish_flag(e->round_flags(0), own_flag_byte(e, labels_out_dev), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = false;
     return NEMGPU_OK;
 }
 
-int nemgpu_ext_emptyk(nemgpu_engine* e, int* emptyk)
+// relaxation round 1 (guess = round 0's all-gathered output); returns at once on every rank when no rank
+// changed a label in round 0 (then: all-gather of labels_out, whose content is unused in that case)
+int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                              const uint8_t* labels_guess_dev, uint8_t* labels_out_dev)
 {
-    if (!e || !emptyk) return NEMGPU_E_FUNCARG;
+    if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    int r;
-    if ((r = read_iter_flags(e))) return r;
-    *emptyk = e->h_iter()[FLAG_EMPTYK];
+    SweepArgs a;
+    shard_sweep_args(e, a, beta, sweep_id);
+    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
+    a.flags = e->round_flags(1);
+    a.flags_in = labels_guess_dev + e->sh_blk;                     // rank 0's flag byte; stride = slot_stride
+    launch_sweep(a, true, e->stream);
+    launch_publish_flag(e->round_flags(1), own_flag_byte(e, labels_out_dev), e->stop_ptr, e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+// convergence test over the whole label array + the device-side loop tests (k_ctrl logic)
+int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, const uint8_t* labels_old_dev,
+                                  const uint8_t* labels_q_dev, const uint8_t* labels_r_dev)
+{
+    if (!e || !labels_old_dev || !labels_q_dev || !labels_r_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    CtrlArgs ca{};
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = beta != 0.0f ? 1 : 0; ca.cvtest = e->cfg.cvtest; ca.ncem = 1;
+    ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    ca.q_flags = labels_q_dev + e->sh_blk; ca.r_flags = labels_r_dev + e->sh_blk;
+    ca.n_ranks = e->sh_world; ca.flag_stride = e->sh_stride; ca.is_init = is_init;
+    launch_moved_global(e->n_true, e->sh_blk, e->sh_stride, labels_q_dev, labels_old_dev, e->iter_flags(), e->stop_ptr,
+                        &ca, e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+// one host-checked relaxation round (fallback when a sweep needs more than two rounds): returns whether
+// THIS rank changed a label; the caller all-gathers labels_out and max-reduces the flag
+int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                            const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int* changed)
+{
+    if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev || !changed) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    const int* saved = e->stop_ptr;
+    e->stop_ptr = nullptr;
+    SweepArgs a;
+    shard_sweep_args(e, a, beta, sweep_id);
+    e->stop_ptr = saved;
+    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
+    a.flags = e->round_flags(2);
+    HIPCHK(hipMemsetAsync(e->round_flags(2), 0, FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+    launch_sweep(a, true, e->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *changed = e->h_round(2)[FLAG_CHANGED] != 0;
+    return NEMGPU_OK;
+}
+
+// end of a batch: read the loop-control block back (one sync).  res->iters etc. are the batch's increments.
+int nemgpu_shard_end_enqueue(nemgpu_engine* e)
+{
+    // last call of a batch's enqueue phase (may be inside a graph capture): copy the control block to the host
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    e->stop_ptr = nullptr;
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    return NEMGPU_OK;
+}
+
+int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* need_rounds)
+{
+    // wait for the batch and report; call after nemgpu_shard_end_enqueue (or after replaying a captured batch)
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    e->stop_ptr = nullptr;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int* c = e->h_ctrl();
+    if (res) {
+        res->status = c[C_STATUS]; res->iters = c[C_ITERS]; res->converged = c[C_CONVERGED]; res->emptyk = c[C_EMPTYK];
+        res->zero_density_sites = c[C_NZERO];
+        res->first_zero_density_site = c[C_NZERO] > 0 ? e->n_total - c[C_FIRSTZERO] : -1;
+        res->sweep_rounds = c[C_SWEEP_ROUNDS];
+    }
+    if (commits) *commits = c[C_COMMITS];
+    if (need_rounds) *need_rounds = c[C_NEED_ROUNDS];
+    e->flags_clean = false;
+    return NEMGPU_OK;
+}
+
+// host-side completion of an iteration whose sweep needed extra rounds: count it like k_ctrl would have
+int nemgpu_shard_set_sweep_number(nemgpu_engine* e, int next_sweep)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, next_sweep, 1, e->stream));
     return NEMGPU_OK;
 }
 
@@ -974,35 +1087,43 @@ int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
     return NEMGPU_OK;
 }
 
-int nemgpu_profile_enable(nemgpu_engine* e, int on)
+// Kernel-duration probe for bench.py: `reps` launches of the E1 density kernel on the current parameters,
+// each bracketed by HIP events recorded on the engine's stream; returns the average duration and the
+// algorithmic bytes one launch moves.
+int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch)
 {
-    if (!e) return NEMGPU_E_FUNCARG;
-    e->prof = on != 0;
-    e->ev_used = 0;
-    return NEMGPU_OK;
-}
-
-int nemgpu_profile_read(nemgpu_engine* e, double* density_ms_avg, int* density_launches,
-                        double* algorithmic_bytes_per_launch)
-{
-    if (!e) return NEMGPU_E_FUNCARG;
+    if (!e || reps <= 0) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    int r;
+    if ((r = do_tables(e))) return r;
+    if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }
     double total = 0.0;
-    const int launches = e->ev_used / 2;
-    for (int i = 0; i < launches; i++) {
+    for (int i = 0; i < reps; i++) {
+        HIPCHK(hipEventRecord(e->ev0, e->stream));
+        if ((r = do_density(e))) return r;
+        HIPCHK(hipEventRecord(e->ev1, e->stream));
+        HIPCHK(hipEventSynchronize(e->ev1));
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[2 * i], e->ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
         total += ms;
     }
-    if (density_ms_avg) *density_ms_avg = launches ? total / launches : 0.0;
-    if (density_launches) *density_launches = launches;
+    if (avg_ms) *avg_ms = total / reps;
     if (algorithmic_bytes_per_launch) {
         // E1 per launch: the bit-packed matrix once, the (k,d) tables once, pk*fk (f64) and log (f32) out
         *algorithmic_bytes_per_launch = (double)e->n * e->wf * 4.0 + (double)e->k * e->d * 24.0 +
                                         (double)e->n * e->k * 12.0;
     }
-    e->ev_used = 0;
+    return NEMGPU_OK;
+}
+
+// Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph).
+int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
+{
+    if (!e || !hip_stream) return NEMGPU_E_FUNCARG;
+    if (e->own_stream && e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    e->stream = (hipStream_t)hip_stream;
+    e->own_stream = false;
+    drop_graphs(e);
     return NEMGPU_OK;
 }
 

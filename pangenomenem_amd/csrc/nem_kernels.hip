@@ -241,6 +241,11 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
 {
     if (a.stop != nullptr && *a.stop) return;
     if (a.prev_changed != nullptr && *a.prev_changed == 0) return;
+    if (a.flags_in != nullptr) {                         // sharded: did ANY rank change a label last round?
+        int any = 0;
+        for (int r = 0; r < a.n_ranks; r++) any |= a.flags_in[(size_t)r * a.slot_stride];
+        if (!any) return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_local) return;
     const int gi = a.lo + i;
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
             for (int k = 1; k < KA; k++) if (k < K && k > kmax && cf[k] == ukmax) nequal++;
             if (nequal > 0) {
                 const uint32_t sid = a.sweep_id_ptr != nullptr ? (uint32_t)*a.sweep_id_ptr : a.sweep_id;
-                int pick = (int)(mix32(a.tie_seed, sid, (uint32_t)gi) % (uint32_t)(nequal + 1));
+                // the hash is keyed by the TRUE family index (label slots of a sharded run carry a flag tail per rank)
+                const uint32_t site = a.slot_stride > 0 ? (uint32_t)(gi - (gi / a.slot_stride) * a.slot_pad) : (uint32_t)gi;
+                int pick = (int)(mix32(a.tie_seed, sid, site) % (uint32_t)(nequal + 1));
                 int seen = 0, chosen = kmax;
 #pragma unroll
                 for (int k = 1; k < KA; k++)
@@ -364,10 +371,22 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
 {
     int* c = a.ctrl;
     if (c[C_STOP]) return;
-    c[C_ITERS] += 1;
-    *a.sweep_next += 1;                                           // the tie-break hash is keyed by the sweep number
+    if (a.is_init) *a.sweep_next = 2;                             // sweeps 0 and 1 are the two initial ones
+    else { c[C_ITERS] += 1; *a.sweep_next += 1; }                 // the tie-break hash is keyed by the sweep number
     const int emptyk = a.iter_flags[FLAG_EMPTYK];
-    const int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
+    int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
+    if (a.q_flags != nullptr) {                                   // sharded: any rank's flag byte
+        ch0 = 0; ch1 = 0;
+        for (int r = 0; r < a.n_ranks; r++) ch0 |= a.q_flags[(size_t)r * a.flag_stride];
+        if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
+    }
+    if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
+        if (a.use_nei && ch0 != 0 && ch1 != 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
+        const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
+        c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one
+        if (fi[FLAG_NZERO] > 0) { c[C_NZERO] += fi[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = fi[FLAG_FIRSTZERO]; }
+        return;
+    }
     const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!a.param_fix && emptyk != 0) {                            // nem_alg.c:1831-1838: E-step "not run"
         c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
@@ -410,6 +429,46 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks)
 }
 
 __global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
+
+// sharded runs: a rank's "some label changed in this round" byte, stored behind its block of labels so that
+// the label all-gather carries it to every rank
+__global__ void k_publish_flag(const int* __restrict__ flags4, uint8_t* __restrict__ out_byte,
+                               const int* __restrict__ stop)
+{
+    if (stop != nullptr && *stop) return;
+    *out_byte = (uint8_t)(flags4[FLAG_CHANGED] != 0);
+}
+
+void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, s, flags4, out_byte, stop);
+}
+
+// sharded runs: CVTEST_CLAS over the WHOLE (all-gathered) label array, so every rank takes the same decision
+// without another collective; slot t of true family f: (f / blk) * stride + f % blk
+__global__ void k_moved_global(int n_true, int blk, int stride, const uint8_t* __restrict__ lab_new,
+                               const uint8_t* __restrict__ lab_old, int* __restrict__ flags,
+                               const int* __restrict__ stop, CtrlArgs ca)
+{
+    if (stop != nullptr && *stop) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    int moved = 0;
+    if (f < n_true) {
+        const size_t slot = (size_t)(f / blk) * stride + (f % blk);
+        moved = lab_new[slot] != lab_old[slot];
+    }
+    if (__any(moved) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
+    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
+}
+
+void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
+                         const int* stop, const CtrlArgs* ctrl, hipStream_t s)
+{
+    CtrlArgs ca{};
+    if (ctrl != nullptr) ca = *ctrl;
+    hipLaunchKernelGGL(k_moved_global, dim3((n_true + 255) / 256), dim3(256), 0, s, n_true, blk, stride, lab_new,
+                       lab_old, flags, stop, ca);
+}
 
 void launch_ctrl(const CtrlArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a); }
 

@@ -26,6 +26,10 @@ struct CtrlArgs {
     int param_fix, use_nei, cvtest, ncem; float cvthres;
     int* sweep_next;               // device word: number of the next sweep (tie-break hash key)
     int* ticket;                   // last-block-done counter (self-resetting)
+    // sharded runs: every rank's "some label changed" byte for round 0 / round 1, as all-gathered at the tail
+    // of each rank's block of the label arrays (nullptr on a single GPU: the int flags above are used)
+    const uint8_t* q_flags; const uint8_t* r_flags; int n_ranks, flag_stride;
+    int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
 };
 void launch_ctrl(const CtrlArgs& a, hipStream_t s);
 
@@ -43,7 +47,14 @@ struct SweepArgs {
     int* flags;                                // this round's slot
     const int* prev_changed;                   // previous round's FLAG_CHANGED (nullptr for round 0)
     const int* stop;                           // loop-control stop word (nullptr outside the pipelined loop)
+    // sharded runs: label arrays are laid out in per-rank blocks of `slot_stride` bytes (labels + flag tail);
+    // flags_in = previous round's all-gathered flag bytes (round exits when none is set)
+    const uint8_t* flags_in; int n_ranks, slot_stride, slot_pad;
 };
+void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s);
+void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
+                         const int* stop, const CtrlArgs* ctrl, hipStream_t s);
+
 
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
                    hipStream_t s);

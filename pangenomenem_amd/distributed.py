@@ -8,20 +8,25 @@ therefore exact under any reduction order:
   * M-step: each rank popcounts its shard -> int32 statistics {N_k, S1[k][d]} ->
     ONE all-reduce(sum) over RCCL/xGMI -> every rank derives mu, epsilon, pi locally.
   * E-step density (E1): embarrassingly parallel over the shard.
-  * E-step sweep (E2): the Gauss-Seidel sweep is solved by relaxation rounds (see k_sweep in
-    csrc/nem_kernels.hip); a round only needs the other shards' labels of the previous round, so
-    each round ends with ONE all-gather of the uint8 label shards (n_total bytes) plus a 4-byte
-    all-reduce(max) of the "changed" flag.  The fixed point is the same global sequential sweep
-    the reference computes, so labels are bit-identical to a single-GPU run.
+  * E-step sweep (E2): the Gauss-Seidel sweep is solved by relaxation rounds (k_sweep in
+    csrc/nem_kernels.hip); a round only needs the other shards' labels of the previous round, so each
+    round ends with ONE all-gather of the uint8 label blocks.  Every block carries, in its tail, the
+    rank's "a label changed" byte, so the same all-gather tells every rank whether another round is
+    needed -- no separate flag collective and no host round trip.  The fixed point is the global
+    sequential sweep of the reference, so labels are bit-identical to a single-GPU run.
+  * Loop control runs on the device (k_ctrl logic, identical data on every rank => identical
+    decisions); the host enqueues a batch of whole iterations, collectives included, and synchronises
+    once per batch.
 
-torch is plumbing here: device memory for the collective buffers, streams, torch.distributed.
-All arithmetic happens in the HIP kernels behind the C ABI (``nemgpu_ext_*``).  The driver is
-written against a small *stepper* interface so that the protocol can be rehearsed on CPU with the
-gloo backend (tests/test_distributed.py plugs the CPU oracle in as the stepper).
+torch is plumbing here: device memory for the collective buffers, streams, torch.distributed.  All
+arithmetic happens in the HIP kernels behind the C ABI (``nemgpu_shard_*``).  The driver is written
+against a small *stepper* interface so that the protocol can be rehearsed on CPU with the gloo
+backend (tests/test_distributed.py plugs the CPU oracle in as the stepper).
 """
 import numpy as np
 
 STATUS_OK, STATUS_W_EMPTYCLASS = 0, 2
+FLAG_TAIL = 16          # bytes behind every rank's label block (byte 0 = "changed" flag), keeps 16-B alignment
 
 
 def shard_bounds(n_total, world, rank):
@@ -32,17 +37,32 @@ def shard_bounds(n_total, world, rank):
     return lo, hi, blk
 
 
-def slice_graph(nei, lo, hi):
-    """Rows [lo, hi) of a global CSR graph; neighbour indices stay global."""
+def slot_layout(n_total, world):
+    """Label arrays: rank r owns slots [r*stride, r*stride+blk); stride = blk rounded up to 16 + FLAG_TAIL."""
+    blk = (n_total + world - 1) // world
+    stride = (blk + 15) // 16 * 16 + FLAG_TAIL
+    return blk, stride
+
+
+def family_to_slot(idx, blk, stride):
+    idx = np.asarray(idx, np.int64)
+    return ((idx // blk) * stride + idx % blk).astype(np.int32)
+
+
+def slice_graph(nei, lo, hi, blk=None, stride=None):
+    """Rows [lo, hi) of a global CSR graph.  Neighbour indices stay global family indices, or become label
+    slots when (blk, stride) is given."""
     ptr, idx, w = nei
     b, e = int(ptr[lo]), int(ptr[hi])
-    return (np.asarray(ptr[lo:hi + 1], np.int64) - b).astype(np.int32), np.ascontiguousarray(idx[b:e], np.int32), \
-        np.ascontiguousarray(w[b:e], np.float32)
+    sub = np.ascontiguousarray(idx[b:e], np.int32)
+    if blk is not None:
+        sub = family_to_slot(sub, blk, stride)
+    return (np.asarray(ptr[lo:hi + 1], np.int64) - b).astype(np.int32), sub, np.ascontiguousarray(w[b:e], np.float32)
 
 
 class Comm:
-    """The three collectives of the sharded EM.  With the nccl (= RCCL) backend they run directly on
-    device tensors; with gloo, device tensors are staged through host memory (rehearsal only)."""
+    """The collectives of the sharded EM.  With the nccl (= RCCL) backend they run directly on device
+    tensors, asynchronously; with gloo, device tensors are staged through host memory (rehearsal only)."""
 
     def __init__(self, group=None):
         import torch
@@ -52,28 +72,24 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
 
-    def _staged(self, t):
-        return self.backend == "gloo" and t.is_cuda
-
     def allreduce_sum_(self, t):
-        if self._staged(t):
+        if self.backend == "gloo" and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def allreduce_max_(self, t):
-        if self._staged(t):
-            h = t.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
-            t.copy_(h)
-        else:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+    def allreduce_max_int(self, v):
+        t = self.torch.tensor([int(v)], dtype=self.torch.int32)
+        if self.backend != "gloo":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
-    def allgather_blocks_(self, buf, blk):
-        """In-place all-gather: rank r owns buf[r*blk:(r+1)*blk]; afterwards every rank holds all blocks."""
-        mine = buf[self.rank * blk:(self.rank + 1) * blk]
+    def allgather_blocks_(self, buf, stride):
+        """In-place all-gather: rank r owns buf[r*stride:(r+1)*stride]; afterwards every rank holds all blocks."""
+        mine = buf[self.rank * stride:(self.rank + 1) * stride]
         if self.backend == "gloo":
             h = mine.cpu() if mine.is_cuda else mine.clone()
             parts = [self.torch.empty_like(h) for _ in range(self.world)]
@@ -84,23 +100,33 @@ class Comm:
 
 
 class GpuStepper:
-    """The local compute of one rank: a NemEngine shard driven through the nemgpu_ext_* C ABI."""
+    """The local compute of one rank: a NemEngine shard driven through the nemgpu_shard_* C ABI."""
 
-    def __init__(self, x_local, nei_local, k, n_total, lo, hi, prop, center, disp, device, cfg):
+    def __init__(self, x_local, nei_slots, k, n_total, world, rank, prop, center, disp, device, cfg):
         import torch
         from .engine import NemEngine
         self.torch = torch
         self.device = torch.device("cuda", device)
         d = x_local.shape[1]
-        self.eng = NemEngine(n_total, d, k, device=device, stream=torch.cuda.current_stream(self.device).cuda_stream,
-                             site_lo=lo, site_hi=hi)
+        blk, stride = slot_layout(n_total, world)
+        # one dedicated (non-default) stream carries this rank's kernels AND the collectives torch issues for
+        # it, so everything is stream-ordered and the whole batch can be captured into a graph
+        self.stream = torch.cuda.Stream(self.device)
+        self.eng = NemEngine(world * stride, d, k, device=device, stream=self.stream.cuda_stream,
+                             site_lo=rank * stride, site_hi=rank * stride + x_local.shape[0])
         self.eng.set_matrix(x_local)
-        self.eng.set_graph(nei_local)
+        self.eng.set_graph(nei_slots)
         self.eng.set_params(prop, center, disp)
         self.eng.configure(**cfg)
+        self.eng.shard_layout(world, rank, blk, stride, n_total)
 
     def alloc(self, n, dtype):
         return self.torch.zeros(n, dtype=getattr(self.torch, dtype), device=self.device)
+
+    def on_stream(self):
+        """Context under which the driver issues this rank's work (kernels through the engine, collectives
+        through torch): the stepper's stream."""
+        return self.torch.cuda.stream(self.stream)
 
     def stats_words(self):
         return self.eng.stats_words()
@@ -108,20 +134,56 @@ class GpuStepper:
     def reset(self):
         self.eng.reset()
 
-    def density(self):
-        self.eng.ext_density()
-
-    def sweep_round(self, beta, sweep_id, old, guess, out, flags):
-        self.eng.ext_sweep_round(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr(), flags.data_ptr())
+    def begin(self):
+        self.eng.shard_begin()
 
     def mstep_partial(self, labels, stats):
-        self.eng.ext_mstep_partial(labels.data_ptr(), stats.data_ptr())
+        self.eng.shard_mstep_partial(labels.data_ptr(), stats.data_ptr())
 
-    def mstep_finalize(self, stats):
-        self.eng.ext_mstep_finalize(stats.data_ptr())
+    def estep_round0(self, stats, beta, sweep_id, old, out):
+        self.eng.shard_estep_round0(stats.data_ptr() if stats is not None else None, beta, sweep_id, old.data_ptr(),
+                                    out.data_ptr())
 
-    def emptyk(self):
-        return self.eng.ext_emptyk()
+    def estep_round1(self, beta, sweep_id, old, guess, out):
+        self.eng.shard_estep_round1(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr())
+
+    def finish_iteration(self, beta, is_init, old, q, r):
+        self.eng.shard_finish_iteration(beta, is_init, old.data_ptr(), q.data_ptr(), r.data_ptr())
+
+    def round_sync(self, beta, sweep_id, old, guess, out):
+        return self.eng.shard_round_sync(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr())
+
+    def end_enqueue(self):
+        self.eng.shard_end_enqueue()
+
+    def end(self):
+        return self.eng.shard_end()
+
+    # ---- whole-batch capture (kernels AND collectives) into one graph replay
+    can_capture = True
+
+    def capture(self, enqueue):
+        """Record everything `enqueue()` launches -- this engine's kernels and the RCCL collectives torch issues --
+        into a torch.cuda.CUDAGraph on the stepper's stream.  Returns the graph, or None when something in the
+        batch cannot be captured here (the caller then stays eager)."""
+        torch = self.torch
+        self.stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=self.stream):
+                enqueue()
+        except Exception:
+            self.stream.synchronize()
+            return None
+        return graph
+
+    def set_sweep_number(self, n):
+        self.eng.shard_set_sweep_number(n)
+
+    def set_cvtest(self, name):
+        from .engine import CVT
+        self.eng.cfg.cvtest = CVT[name]
+        self.eng._chk(self.eng.lib.nemgpu_configure(self.eng._h, self.eng.cfg))   # also resets the engine state
 
     def params(self):
         return self.eng.params()
@@ -130,15 +192,19 @@ class GpuStepper:
 class ShardedNem:
     """EM driver over a stepper + Comm (mirrors NemAlgo, nem_alg.c:1746-1879, for NCEM)."""
 
+    PIPE_DEPTH = 6       # whole iterations enqueued between host synchronisations
+
     def __init__(self, stepper, comm, n_total, beta, cvtest="clas", cvthres=1e-8, param_fix=False):
         self.st, self.comm = stepper, comm
         self.n_total = n_total
-        self.lo, self.hi, self.blk = shard_bounds(n_total, comm.world, comm.rank)
+        self.blk, self.stride = slot_layout(n_total, comm.world)
+        self.lo, self.hi, _ = shard_bounds(n_total, comm.world, comm.rank)
         self.beta, self.cvtest, self.cvthres, self.param_fix = float(beta), cvtest, float(cvthres), param_fix
-        npad = self.blk * comm.world
-        self.labels = [stepper.alloc(npad, "uint8") for _ in range(3)]
+        self.labels = [stepper.alloc(self.stride * comm.world, "uint8") for _ in range(3)]
         self.stats = stepper.alloc(stepper.stats_words(), "int32")
-        self.flags = stepper.alloc(4, "int32")
+        import os
+        self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", "1") != "0"
+        self._graphs, self._seen = {}, set()
         self.reset()
 
     @property
@@ -147,89 +213,153 @@ class ShardedNem:
 
     def reset(self):
         self.st.reset()
+        with self.st.on_stream():
+            self.labels[0].zero_()
         self.cur = 0
         self.sweep_id = 0
         self.iters, self.converged, self.status, self.emptyk, self.sweep_rounds = 0, False, STATUS_OK, 0, 0
 
-    # one Gauss-Seidel sweep == relaxation rounds until no label differs from its guess on ANY rank
-    def _sweep(self, beta, use_nei):
-        P = self.cur
-        Q, R = (P + 1) % 3, (P + 2) % 3
-        sid = self.sweep_id
-        self.sweep_id += 1
-        r = 0
+    def _block_view(self, t):
+        return t.reshape(self.comm.world, self.stride)[:, :self.blk]
+
+    # ---- enqueue helpers (no host synchronisation)
+    def _enqueue_init(self):
+        L, use_nei = self.labels, self.beta != 0.0
+        self.st.estep_round0(None, 0.0, 0, L[0], L[1])                    # blind beta = 0 sweep (nem_alg.c:1972-1976)
+        self.comm.allgather_blocks_(L[1], self.stride)
+        self.st.estep_round0(None, self.beta, 1, L[1], L[2])              # the sweep with the real beta (:1980)
+        self.comm.allgather_blocks_(L[2], self.stride)
+        if use_nei:
+            self.st.estep_round1(self.beta, 1, L[1], L[2], L[0])
+            self.comm.allgather_blocks_(L[0], self.stride)
+        self.st.finish_iteration(self.beta, 1, L[1], L[2], L[0])
+
+    def _enqueue_iteration(self, P):
+        L, Q, R = self.labels, (P + 1) % 3, (P + 2) % 3
+        stats = None
+        if not self.param_fix:                                            # nem_alg.c:1806
+            self.st.mstep_partial(L[P], self.stats)
+            self.comm.allreduce_sum_(self.stats)
+            stats = self.stats
+        self.st.estep_round0(stats, self.beta, -1, L[P], L[Q])
+        self.comm.allgather_blocks_(L[Q], self.stride)
+        if self.beta != 0.0:
+            self.st.estep_round1(self.beta, -1, L[P], L[Q], L[R])
+            self.comm.allgather_blocks_(L[R], self.stride)
+        self.st.finish_iteration(self.beta, 0, L[P], L[Q], L[R])
+
+    def _finish_sweep_on_host(self, P, sweep_id):
+        """A sweep that needed more than two relaxation rounds: continue them with a host check per round."""
+        L, Q, R = self.labels, (P + 1) % 3, (P + 2) % 3
+        r = 2
         while True:
-            guess = P if r == 0 else (Q if (r - 1) % 2 == 0 else R)
-            out = Q if r % 2 == 0 else R
-            self.flags.zero_()
-            self.st.sweep_round(beta if use_nei else 0.0, sid, self.labels[P], self.labels[guess], self.labels[out],
-                                self.flags)
-            self.comm.allgather_blocks_(self.labels[out], self.blk)
-            r += 1
-            if not use_nei:
-                break
-            self.comm.allreduce_max_(self.flags)
-            if int(self.flags[0].item()) == 0:
-                break
-        self.sweep_rounds += r
-        return out
+            guess, out = (R, Q) if r % 2 == 0 else (Q, R)
+            with self.st.on_stream():
+                changed = self.st.round_sync(self.beta, sweep_id, L[P], L[guess], L[out])
+                self.comm.allgather_blocks_(L[out], self.stride)
+                r += 1
+                if self.comm.allreduce_max_int(changed) == 0:
+                    break
+        self.sweep_rounds += r            # out == guess now, so L[Q] holds the result whichever buffer was last
+        return Q
+
+    def _enqueue_batch(self, with_init, g, base):
+        self.st.begin()
+        if with_init:
+            self._enqueue_init()
+        for j in range(g):
+            self._enqueue_iteration((base + j) % 3)
+        self.st.end_enqueue()
+
+    def _run_batch(self, with_init, g):
+        """Enqueue [the two initial sweeps +] g whole iterations, synchronise once, account for what ran.
+        The second time a batch shape is seen it is captured (kernels + collectives) into one graph."""
+        base = 2 if with_init else self.cur
+        s0 = 2 if with_init else self.sweep_id
+        key = (with_init, g, base)
+        graph = self._graphs.get(key)
+        if graph is None and self.use_graphs and getattr(self.st, "can_capture", False) and key in self._seen:
+            graph = self.st.capture(lambda: self._enqueue_batch(with_init, g, base))
+            if graph is None:
+                self.use_graphs = False
+            else:
+                self._graphs[key] = graph
+        self._seen.add(key)
+        with self.st.on_stream():
+            if graph is not None:
+                graph.replay()
+            else:
+                self._enqueue_batch(with_init, g, base)
+        res = self.st.end()
+        self.sweep_rounds += res["sweep_rounds"]
+        if with_init and res["need_rounds"] == 2:
+            # the initial beta sweep was not at its fixed point after two rounds: finish it from the host;
+            # the iterations enqueued behind it all returned at the stop word
+            self._finish_sweep_on_host(1, 1)
+            self.cur, self.sweep_id = 2, 2
+            self.st.set_sweep_number(2)
+            return 0
+        self.iters += res["iters"]
+        self.cur = (base + res["commits"]) % 3
+        self.sweep_id = s0 + res["iters"]
+        if res["status"] == STATUS_W_EMPTYCLASS:                          # nem_alg.c:1831-1838
+            self.status, self.emptyk = STATUS_W_EMPTYCLASS, res["emptyk"]
+        elif res["converged"]:
+            self.converged = True
+        elif res["need_rounds"] == 1:
+            P = self.cur
+            new = self._finish_sweep_on_host(P, s0 + res["iters"] - 1)
+            self.cur = new
+            if self.cvtest == "clas":                                     # HasConverged, nem_alg.c:2075-2089
+                with self.st.on_stream():
+                    moved = not bool((self._block_view(self.labels[new]) == self._block_view(self.labels[P])).all().item())
+                self.converged = (1.0 < self.cvthres) if moved else (0.0 < self.cvthres)
+        return res["iters"]
 
     def init_partition(self):
-        """ComputePartitionFromPara(Needinit=1), nem_alg.c:1967-1981."""
-        self.st.density()
-        self.cur = self._sweep(0.0, False)
-        self.cur = self._sweep(self.beta, self.beta != 0.0)
+        """ComputePartitionFromPara(Needinit=1), nem_alg.c:1967-1981 (one batch, one synchronisation)."""
+        self._run_batch(True, 0)
+        self.cur, self.sweep_id = 2, 2
 
-    def iterate(self, n_iters):
-        for _ in range(n_iters):
-            if self.converged or self.status != STATUS_OK:
+    def iterate(self, n_iters, with_init=False):
+        first, remaining = with_init, int(n_iters)
+        while True:
+            done = self._run_batch(first, min(remaining, self.PIPE_DEPTH))
+            first = False
+            remaining -= done
+            if self.converged or self.status != STATUS_OK or remaining <= 0:
                 break
-            old = self.cur
-            if not self.param_fix:
-                self.st.mstep_partial(self.labels[old], self.stats)
-                self.comm.allreduce_sum_(self.stats)
-                self.st.mstep_finalize(self.stats)
-            self.st.density()
-            new = self._sweep(self.beta, self.beta != 0.0)
-            self.iters += 1
-            ek = 0 if self.param_fix else self.st.emptyk()
-            if ek:
-                self.status, self.emptyk = STATUS_W_EMPTYCLASS, ek       # nem_alg.c:1831-1838
-                break
-            self.cur = new
-            if self.cvtest == "clas":                                    # HasConverged, nem_alg.c:2075-2089
-                moved = not bool((self.labels[new][:self.n_total] == self.labels[old][:self.n_total]).all().item())
-                self.converged = (1.0 < self.cvthres) if moved else (0.0 < self.cvthres)
         return dict(iters=self.iters, converged=self.converged, status=self.status, emptyk=self.emptyk,
                     sweep_rounds=self.sweep_rounds)
 
     def run(self, it_max=100):
         self.reset()
-        self.init_partition()
-        return self.iterate(it_max)
+        return self.iterate(it_max, with_init=True)
 
     def global_labels(self):
-        return self.labels[self.cur][:self.n_total].cpu().numpy()
+        with self.st.on_stream():
+            return self._block_view(self.labels[self.cur]).reshape(-1)[:self.n_total].cpu().numpy()
 
     # ---- bench helpers
+    def set_cvtest(self, name):
+        self.cvtest = name
+        self.st.set_cvtest(name)
+        self._graphs, self._seen = {}, set()      # kernel arguments are baked into captured batches
+
     def iters_to_converge(self, it_max=100):
         keep = self.cvtest
-        self.cvtest = "clas"
+        self.set_cvtest("clas")
         res = self.run(it_max)
-        self.cvtest = keep
+        self.set_cvtest(keep)
         return max(5, int(res["iters"]))
 
     def run_steps(self, count, cycle):
-        keep = self.cvtest
-        self.cvtest = "none"
         done = 0
         while done < count:
             m = min(cycle, count - done)
             self.reset()
-            self.init_partition()
-            self.iterate(m)
+            self.iterate(m, with_init=True)
             done += m
-        self.cvtest = keep
 
     @classmethod
     def synthetic(cls, n_loc, d, k, beta, rank, world, local_rank, algo="ncem"):
@@ -240,9 +370,10 @@ class ShardedNem:
             raise ValueError("the sharded path is NCEM-only (fuzzy sums are order-dependent, SURVEY.md §8e)")
         n_total = n_loc * world
         lo, hi, _ = shard_bounds(n_total, world, rank)
+        blk, stride = slot_layout(n_total, world)
         x_local, _ = synth.bernoulli_pa_matrix(hi - lo, d, 2 + 1000 * rank)
-        nei = slice_graph(synth.contiguity_graph(n_total, 2), lo, hi)
+        nei = slice_graph(synth.contiguity_graph(n_total, 2), lo, hi, blk, stride)
         prop, center, disp = synth.default_init(d)
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)
-        st = GpuStepper(x_local, nei, k, n_total, lo, hi, prop, center, disp, local_rank, cfg)
+        st = GpuStepper(x_local, nei, k, n_total, world, rank, prop, center, disp, local_rank, cfg)
         return cls(st, Comm(), n_total, beta, cvtest="none")

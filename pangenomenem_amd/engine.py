@@ -71,14 +71,19 @@ def load_library():
     lib.nemgpu_get_labels.argtypes = [vp, vp]
     lib.nemgpu_get_params.argtypes = [vp, vp, vp, vp, vp]
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
-    lib.nemgpu_profile_enable.argtypes = [vp, C.c_int]
-    lib.nemgpu_profile_read.argtypes = [vp, C.POINTER(C.c_double), ip, C.POINTER(C.c_double)]
+    lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.nemgpu_set_stream.argtypes = [vp, vp]
+    lib.nemgpu_shard_end_enqueue.argtypes = [vp]
     lib.nemgpu_stats_words.argtypes = [vp]
-    lib.nemgpu_ext_mstep_partial.argtypes = [vp, vp, vp]
-    lib.nemgpu_ext_mstep_finalize.argtypes = [vp, vp]
-    lib.nemgpu_ext_density.argtypes = [vp]
-    lib.nemgpu_ext_sweep_round.argtypes = [vp, C.c_float, C.c_uint32, vp, vp, vp, vp]
-    lib.nemgpu_ext_emptyk.argtypes = [vp, ip]
+    lib.nemgpu_shard_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.nemgpu_shard_begin.argtypes = [vp]
+    lib.nemgpu_shard_mstep_partial.argtypes = [vp, vp, vp]
+    lib.nemgpu_shard_estep_round0.argtypes = [vp, vp, C.c_float, C.c_int, vp, vp]
+    lib.nemgpu_shard_estep_round1.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
+    lib.nemgpu_shard_finish_iteration.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
+    lib.nemgpu_shard_round_sync.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp, ip]
+    lib.nemgpu_shard_end.argtypes = [vp, C.POINTER(Result), ip, ip]
+    lib.nemgpu_shard_set_sweep_number.argtypes = [vp, C.c_int]
     lib.nemio_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.nemio_free.argtypes = [vp]
     lib.nemio_free.restype = None
@@ -245,31 +250,54 @@ class NemEngine:
     def stats_words(self):
         return int(self.lib.nemgpu_stats_words(self._h))
 
-    def ext_mstep_partial(self, labels_ptr, stats_ptr):
-        self._chk(self.lib.nemgpu_ext_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
+    def shard_layout(self, world, rank, blk, stride, n_true):
+        self._chk(self.lib.nemgpu_shard_layout(self._h, world, rank, blk, stride, n_true))
 
-    def ext_mstep_finalize(self, stats_ptr):
-        self._chk(self.lib.nemgpu_ext_mstep_finalize(self._h, C.c_void_p(stats_ptr)))
+    def shard_begin(self):
+        self._chk(self.lib.nemgpu_shard_begin(self._h))
 
-    def ext_density(self):
-        self._chk(self.lib.nemgpu_ext_density(self._h))
+    def shard_mstep_partial(self, labels_ptr, stats_ptr):
+        self._chk(self.lib.nemgpu_shard_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
 
-    def ext_sweep_round(self, beta, sweep_id, old_ptr, guess_ptr, out_ptr, flags_ptr):
-        self._chk(self.lib.nemgpu_ext_sweep_round(self._h, C.c_float(beta), C.c_uint32(sweep_id), C.c_void_p(old_ptr),
-                                                  C.c_void_p(guess_ptr), C.c_void_p(out_ptr), C.c_void_p(flags_ptr)))
+    def shard_estep_round0(self, stats_ptr, beta, sweep_id, old_ptr, out_ptr):
+        self._chk(self.lib.nemgpu_shard_estep_round0(self._h, C.c_void_p(stats_ptr) if stats_ptr else None,
+                                                     C.c_float(beta), int(sweep_id), C.c_void_p(old_ptr),
+                                                     C.c_void_p(out_ptr)))
 
-    def ext_emptyk(self):
-        ek = C.c_int(0)
-        self._chk(self.lib.nemgpu_ext_emptyk(self._h, C.byref(ek)))
-        return ek.value
+    def shard_estep_round1(self, beta, sweep_id, old_ptr, guess_ptr, out_ptr):
+        self._chk(self.lib.nemgpu_shard_estep_round1(self._h, C.c_float(beta), int(sweep_id), C.c_void_p(old_ptr),
+                                                     C.c_void_p(guess_ptr), C.c_void_p(out_ptr)))
 
-    def profile(self, on=True):
-        self._chk(self.lib.nemgpu_profile_enable(self._h, int(on)))
+    def shard_finish_iteration(self, beta, is_init, old_ptr, q_ptr, r_ptr):
+        self._chk(self.lib.nemgpu_shard_finish_iteration(self._h, C.c_float(beta), int(is_init), C.c_void_p(old_ptr),
+                                                         C.c_void_p(q_ptr), C.c_void_p(r_ptr)))
 
-    def profile_read(self):
-        ms, n, b = C.c_double(0), C.c_int(0), C.c_double(0)
-        self._chk(self.lib.nemgpu_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
-        return dict(density_ms_avg=ms.value, density_launches=n.value, algorithmic_bytes_per_launch=b.value)
+    def shard_round_sync(self, beta, sweep_id, old_ptr, guess_ptr, out_ptr):
+        ch = C.c_int(0)
+        self._chk(self.lib.nemgpu_shard_round_sync(self._h, C.c_float(beta), int(sweep_id), C.c_void_p(old_ptr),
+                                                   C.c_void_p(guess_ptr), C.c_void_p(out_ptr), C.byref(ch)))
+        return ch.value
+
+    def shard_end_enqueue(self):
+        self._chk(self.lib.nemgpu_shard_end_enqueue(self._h))
+
+    def shard_end(self):
+        r, commits, need = Result(), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.nemgpu_shard_end(self._h, C.byref(r), C.byref(commits), C.byref(need)))
+        return dict(status=r.status, iters=r.iters, converged=bool(r.converged), emptyk=r.emptyk,
+                    sweep_rounds=r.sweep_rounds, commits=commits.value, need_rounds=need.value)
+
+    def shard_set_sweep_number(self, n):
+        self._chk(self.lib.nemgpu_shard_set_sweep_number(self._h, int(n)))
+
+    def profile_density(self, reps=50):
+        """Average duration of the E1 density kernel (HIP events on the engine's stream) and its algorithmic bytes."""
+        ms, b = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.nemgpu_profile_density(self._h, int(reps), C.byref(ms), C.byref(b)))
+        return dict(density_ms_avg=ms.value, density_launches=int(reps), algorithmic_bytes_per_launch=b.value)
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
 
 
 def solve(x, nei, k, prop, center, disp, device=0, **cfg):

@@ -14,19 +14,29 @@ EPS = 1e-20
 
 
 class OracleStepper:
-    """CPU stand-in for GpuStepper: same interface, numbers from the oracle / numpy integer counts."""
+    """CPU stand-in for GpuStepper: same interface (including the device-side loop control, emulated
+    here in Python), numbers from the oracle / numpy integer counts."""
 
-    def __init__(self, oracle, x_local, nei_local, k, n_total, lo, hi, prop, center, disp, disper="sk_", seed=0):
+    def __init__(self, oracle, x_local, nei_slots, k, n_total, world, rank, prop, center, disp, beta, seed=0,
+                 cvtest="clas", cvthres=1e-8):
         import torch
+        from pangenomenem_amd.distributed import slot_layout
         self.torch, self.o = torch, oracle
-        self.x, self.nei, self.k, self.n_total, self.lo, self.hi = x_local, nei_local, k, n_total, lo, hi
+        self.x, self.nei, self.k, self.n_total, self.world, self.rank = x_local, nei_slots, k, n_total, world, rank
+        self.blk, self.stride = slot_layout(n_total, world)
+        self.lo = rank * self.stride
+        self.n = x_local.shape[0]
         self.d = x_local.shape[1]
         self.p0 = (np.array(prop, np.float32), np.array(center, np.float32), np.array(disp, np.float32))
-        self.disper, self.seed = disper, seed
+        self.seed, self.cvtest, self.cvthres, self.beta = seed, cvtest, cvthres, beta
         self.reset()
 
     def alloc(self, n, dtype):
         return self.torch.zeros(n, dtype=getattr(self.torch, dtype))
+
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
 
     def stats_words(self):
         return self.k + self.k * self.d
@@ -34,10 +44,28 @@ class OracleStepper:
     def reset(self):
         self.prop, self.center, self.disp = (a.copy() for a in self.p0)
         self.nbobs_k = np.zeros(self.k, np.float32)
-        self._emptyk = 0
+        self.sweep_next = 0
+        self.pk = None
+        self.emptyk_flag = 0
 
-    def density(self):
-        self.pk, _, _ = self.o.density(self.x, self.prop, self.center, self.disp)
+    def set_sweep_number(self, n):
+        self.sweep_next = n
+
+    def set_cvtest(self, name):
+        self.cvtest = name
+
+    # ---- loop control (mirrors k_ctrl / ctrl_logic)
+    def begin(self):
+        self.c = dict(stop=0, iters=0, commits=0, status=0, emptyk=0, converged=0, need_rounds=0, sweep_rounds=0)
+        self.changed = [0, 0]
+
+    def end_enqueue(self):
+        pass
+
+    def end(self):
+        out = dict(self.c)
+        out["converged"] = bool(out["converged"])
+        return out
 
     def _onehot(self, lab):
         c = np.zeros((len(lab), self.k), np.float32)
@@ -45,27 +73,18 @@ class OracleStepper:
         c[np.flatnonzero(valid), lab[valid]] = 1.0
         return c
 
-    def sweep_round(self, beta, sweep_id, old, guess, out, flags):
-        n = self.n_total
-        c_old, c_guess = self._onehot(old.numpy()[:n]), self._onehot(guess.numpy()[:n])
-        c_out = np.zeros_like(c_old)
-        self.o.relax_round(self.lo, self.hi, self.nei, beta, self.pk, True, c_old, c_guess, c_out, tie="hash",
-                           seed=self.seed, sweep_id=sweep_id)
-        new = c_out[self.lo:self.hi].argmax(1).astype(np.uint8)
-        changed = int(np.any(new != guess.numpy()[self.lo:self.hi]))
-        out.numpy()[self.lo:self.hi] = new
-        flags[0] = max(int(flags[0]), changed)
-
     def mstep_partial(self, labels, stats):
-        lab = labels.numpy()[self.lo:self.hi]
+        if self.c["stop"]:
+            return
+        lab = labels.numpy()[self.lo:self.lo + self.n]
         s = stats.numpy()
         for c in range(self.k):
             m = lab == c
             s[c] = int(m.sum())
             s[self.k + c * self.d:self.k + (c + 1) * self.d] = self.x[m].sum(0)
 
-    def mstep_finalize(self, stats):
-        """k_mstep_centers_ncem + k_mstep_disp (sk_/pk) restated in numpy on the GLOBAL counts."""
+    def _finalize(self, stats):
+        """k_finish mode 1 (sk_/pk) restated in numpy on the GLOBAL counts."""
         s = stats.numpy()
         k, d = self.k, self.d
         ek = 0
@@ -82,7 +101,6 @@ class OracleStepper:
             mu = np.where(s0 > half, 0.0, np.where(s0 == half, 0.5, 1.0)).astype(np.float32)
             iner[c] = np.where(mu == 0, s1.astype(np.float32), np.where(mu == 1, s0, np.float32(0.5) * nk))
             self.center[c] = mu
-        assert self.disper == "sk_"
         for c in range(k):
             nk = self.nbobs_k[c]
             if nk > 0:
@@ -90,10 +108,78 @@ class OracleStepper:
                 si = np.cumsum(iner[c], dtype=np.float32)[-1]
                 self.disp[c, :] = np.float32(si / sn)
             self.prop[c] = np.float32(nk / np.float32(self.n_total))
-        self._emptyk = ek
+        self.emptyk_flag = ek
+        self.pk = None
 
-    def emptyk(self):
-        return self._emptyk
+    def _round(self, beta, sweep_id, old, guess, out):
+        sid = self.sweep_next if sweep_id < 0 else sweep_id
+        c_old, c_guess = self._onehot(old.numpy()), self._onehot(guess.numpy())
+        c_out = np.zeros_like(c_old)
+        # the oracle's round works on the slot index space directly (lo/hi/nei are slots); its tie hash is
+        # keyed by the slot index too, so the tests use tie-free data
+        self.o.relax_round(self.lo, self.lo + self.n, self.nei, beta, self.pk, True, c_old, c_guess, c_out, tie="hash",
+                           seed=self.seed, sweep_id=sid)
+        new = c_out[self.lo:self.lo + self.n].argmax(1).astype(np.uint8)
+        changed = int(np.any(new != guess.numpy()[self.lo:self.lo + self.n]))
+        out.numpy()[self.lo:self.lo + self.n] = new
+        return changed
+
+    def estep_round0(self, stats, beta, sweep_id, old, out):
+        if self.c["stop"]:
+            return
+        if stats is not None:
+            self._finalize(stats)
+        if self.pk is None:
+            self.pk, _, _ = self.o.density(self.x, self.prop, self.center, self.disp)
+        self.changed = [self._round(beta, sweep_id, old, old, out), 0]
+        out.numpy()[self.lo + self.blk] = self.changed[0]
+
+    def estep_round1(self, beta, sweep_id, old, guess, out):
+        if self.c["stop"]:
+            return
+        flags = guess.numpy()[self.blk::self.stride][:self.world]
+        if not flags.any():
+            return
+        self.changed[1] = self._round(beta, sweep_id, old, guess, out)
+        out.numpy()[self.lo + self.blk] = self.changed[1]
+
+    def finish_iteration(self, beta, is_init, old, q, r):
+        c = self.c
+        if c["stop"]:
+            return
+        use_nei = beta != 0.0
+        ch0 = int(q.numpy()[self.blk::self.stride][:self.world].any())
+        ch1 = int(r.numpy()[self.blk::self.stride][:self.world].any()) if ch0 else 0
+        if is_init:
+            self.sweep_next = 2
+            if use_nei and ch0 and ch1:
+                c["need_rounds"], c["stop"] = 2, 1
+            else:
+                c["sweep_rounds"] += 3 if (use_nei and ch0) else 2
+            return
+        c["iters"] += 1
+        self.sweep_next += 1
+        if self.emptyk_flag:
+            c["status"], c["emptyk"], c["stop"] = 2, self.emptyk_flag, 1
+            return
+        rounds = 1
+        if use_nei and ch0:
+            if ch1:
+                c["need_rounds"], c["stop"] = 1, 1
+                return
+            rounds = 2
+        c["sweep_rounds"] += rounds
+        c["commits"] += 1
+        if self.cvtest == "clas":
+            qv = q.numpy().reshape(self.world, self.stride)[:, :self.blk]
+            ov = old.numpy().reshape(self.world, self.stride)[:, :self.blk]
+            moved = bool((qv != ov).any())
+            conv = (1.0 < self.cvthres) if moved else (0.0 < self.cvthres)
+            if conv:
+                c["converged"], c["stop"] = 1, 1
+
+    def round_sync(self, beta, sweep_id, old, guess, out):
+        return self._round(beta, sweep_id, old, guess, out)
 
     def params(self):
         return dict(prop=self.prop, center=self.center, disp=self.disp, nbobs_k=self.nbobs_k)
@@ -104,7 +190,7 @@ def _worker(rank, world, initfile, n, d, beta, kind, outdir):
     import torch.distributed as dist
     from oracle.pyoracle import Oracle
     from pangenomenem_amd import synth
-    from pangenomenem_amd.distributed import Comm, ShardedNem, shard_bounds, slice_graph
+    from pangenomenem_amd.distributed import Comm, ShardedNem, shard_bounds, slice_graph, slot_layout
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     try:
         if kind == "empty":
@@ -114,7 +200,9 @@ def _worker(rank, world, initfile, n, d, beta, kind, outdir):
         nei = synth.contiguity_graph(n, 1)
         prop, center, disp = synth.default_init(d)
         lo, hi, _ = shard_bounds(n, world, rank)
-        st = OracleStepper(Oracle(), x[lo:hi], slice_graph(nei, lo, hi), 3, n, lo, hi, prop, center, disp, seed=11)
+        blk, stride = slot_layout(n, world)
+        st = OracleStepper(Oracle(), x[lo:hi], slice_graph(nei, lo, hi, blk, stride), 3, n, world, rank, prop, center,
+                           disp, beta, seed=11)
         job = ShardedNem(st, Comm(), n, beta, cvtest="clas", cvthres=1e-8)
         res = job.run(100)
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), labels=job.global_labels(), iters=res["iters"],

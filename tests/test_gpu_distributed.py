@@ -18,7 +18,7 @@ def _worker(rank, world, backend, initfile, n, d, beta, outdir):
     import torch
     import torch.distributed as dist
     from pangenomenem_amd import synth
-    from pangenomenem_amd.distributed import Comm, GpuStepper, ShardedNem, shard_bounds, slice_graph
+    from pangenomenem_amd.distributed import Comm, GpuStepper, ShardedNem, shard_bounds, slice_graph, slot_layout
     torch.cuda.set_device(0)
     kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
     dist.init_process_group(backend, init_method="file://" + initfile, rank=rank, world_size=world, **kw)
@@ -27,8 +27,9 @@ def _worker(rank, world, backend, initfile, n, d, beta, outdir):
         nei = synth.contiguity_graph(n, 1)
         prop, center, disp = synth.default_init(d)
         lo, hi, _ = shard_bounds(n, world, rank)
+        blk, stride = slot_layout(n, world)
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="clas", seed=11)
-        st = GpuStepper(x[lo:hi], slice_graph(nei, lo, hi), 3, n, lo, hi, prop, center, disp, 0, cfg)
+        st = GpuStepper(x[lo:hi], slice_graph(nei, lo, hi, blk, stride), 3, n, world, rank, prop, center, disp, 0, cfg)
         job = ShardedNem(st, Comm(), n, beta, cvtest="clas", cvthres=1e-8)
         res = job.run(100)
         labels = job.global_labels().copy()
