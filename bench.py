@@ -110,9 +110,7 @@ def main():
             rounds = 0
             while done < count:
                 m = min(cycle, count - done)
-                eng.reset()
-                eng.init_partition()
-                rounds += eng.iterate(m)["sweep_rounds"]
+                rounds += eng.restart_iterate(m)["sweep_rounds"]      # reset + initial sweeps + m iterations
                 done += m
             return rounds
 

@@ -137,6 +137,7 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res);
 int nemgpu_init_partition(nemgpu_engine* e);              /* ComputePartitionFromPara(Needinit=1) */
 int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res);  /* up to n_iters EM iterations */
 int nemgpu_reset(nemgpu_engine* e);                       /* back to the initial parameters, zero partition */
+int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res);  /* reset + init + n iterations, one pipeline */
 int nemgpu_density(nemgpu_engine* e);                     /* E1 only */
 int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds);  /* E2 only (one full Gauss-Seidel sweep) */
 int nemgpu_mstep(nemgpu_engine* e, int* emptyk);          /* M only */

@@ -91,7 +91,7 @@ struct nemgpu_engine {
     bool flags_clean = false;     // MOVED + round window are zero (set by k_density, consumed by a sweep)
 
     // captured batches of the pipelined loop, keyed by (current buffer, iterations in the batch)
-    hipGraphExec_t graphs[3][8] = {};
+    hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
     bool use_graphs = true;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
@@ -212,7 +212,7 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
     return NEMGPU_OK;
 }
 
-int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c)
+int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false)
 {
     c = SweepCtx();
     c.use_nei = e->has_graph && beta != 0.0f;
@@ -223,7 +223,7 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c)
     a.beta = beta;
     a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = e->sweep_counter++;
-    a.sweep_id_ptr = e->stop_ptr != nullptr ? e->sweep_next : nullptr;   // pipelined loop: the device keeps count
+    a.sweep_id_ptr = (e->stop_ptr != nullptr && !id_by_value) ? e->sweep_next : nullptr;   // pipelined loop: the device keeps count
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
     return sweep_launch_rounds(e, c, c.use_nei ? kRoundBatch : 1);
@@ -311,6 +311,10 @@ int read_iter_flags(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
+int reset_device(nemgpu_engine* e);
+int reset_state(nemgpu_engine* e);
+void drop_graphs(nemgpu_engine* e);
+
 // ComputePartitionFromPara(Needinit = 1), nem_alg.c:1967-1981
 int init_partition(nemgpu_engine* e)
 {
@@ -382,24 +386,61 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     return NEMGPU_OK;
 }
 
-int iterate(nemgpu_engine* e, int n_iters)
+// the restart + the two initial sweeps as the head of a pipelined batch (buffers 0 -> 1 -> 2)
+int enqueue_init(nemgpu_engine* e)
 {
     int r;
-    while (n_iters > 0 && !e->converged && e->status == NEMGPU_OK) {
+    if ((r = reset_device(e))) return r;
+    e->tables_fresh = false; e->density_fresh = false;
+    e->cur = 0;
+    if ((r = do_tables(e))) return r;
+    if ((r = do_density(e))) return r;
+    SweepCtx c0, c1;
+    e->sweep_counter = 0;
+    if ((r = sweep_enqueue(e, 0.0f, c0, true))) return r;          // blind sweep: one round, 0 -> 1
+    e->cur = 1;
+    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    CtrlArgs ca{};
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = c1.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    ca.is_init = 1;
+    if (e->ncem()) { if ((r = do_labels_post(e, 2, -1, &ca))) return r; }
+    else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }
+    e->cur = 2;
+    return NEMGPU_OK;
+}
+
+int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
+{
+    int r;
+    if (with_init) {
+        if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
+        if ((r = ensure_state_buffers(e))) return r;
+        // host half of a restart (the device half is the head of the first batch)
+        e->cur = 0; e->sweep_counter = 0;
+        e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
+        e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
+    }
+    bool first = with_init;
+    while ((n_iters > 0 || first) && !e->converged && e->status == NEMGPU_OK) {
         const int g = std::min(n_iters, kPipeDepth);
-        const int base = e->cur;
-        const uint32_t sweep0 = e->sweep_counter;
+        const int base = first ? 2 : e->cur;
+        const uint32_t sweep0 = first ? 2u : e->sweep_counter;
         // state every captured batch may rely on: class masks of the current labels, fresh tables when the
         // parameters are fixed (otherwise k_finish rebuilds them inside the batch)
-        if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
-        if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
+        if (!first) {
+            if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+            if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
+        }
         const bool graphed = e->use_graphs && g < 8;
-        hipGraphExec_t exec = graphed ? e->graphs[base][g] : nullptr;
+        hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
         if (exec == nullptr) {
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             r = NEMGPU_OK;
             hipError_t herr = hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
             e->stop_ptr = e->ctrl() + C_STOP;
+            if (first && herr == hipSuccess) r = enqueue_init(e);
             for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)
                 r = enqueue_iteration(e, (base + j) % 3, sweep0 + j);
             e->stop_ptr = nullptr;
@@ -411,14 +452,18 @@ int iterate(nemgpu_engine* e, int n_iters)
                 hipError_t cerr = hipStreamEndCapture(e->stream, &graph);
                 if (herr == hipSuccess && r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr &&
                     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    e->graphs[base][g] = exec;
+                    e->graphs[first ? 1 : 0][base][g] = exec;
                 } else {
                     exec = nullptr;
                     e->use_graphs = false;                         // fall back to plain launches for good
                     if (herr == hipSuccess && cerr != hipSuccess) herr = cerr;
                 }
                 if (graph) (void)hipGraphDestroy(graph);
-                if (exec == nullptr && r == NEMGPU_OK && herr == hipSuccess) { e->sweep_counter = sweep0; continue; }   // redo this batch ungraphed
+                if (exec == nullptr && r == NEMGPU_OK && herr == hipSuccess) {   // redo this batch ungraphed
+                    e->sweep_counter = sweep0;
+                    if (first) e->cur = 0;
+                    continue;
+                }
             }
             if (r) return r;
             HIPCHK(herr);
@@ -433,12 +478,34 @@ int iterate(nemgpu_engine* e, int n_iters)
             e->zero_density += c[C_NZERO];
             if (e->first_zero < 0) e->first_zero = e->n_total - c[C_FIRSTZERO];
         }
-        e->cur = (base + commits) % 3;
-        e->sweep_counter = sweep0 + (uint32_t)done;
-        n_iters -= done;
         e->flags_clean = false;
         e->tables_fresh = true;
         if (e->ncem()) e->masks_valid = true;
+        if (first && c[C_NEED_ROUNDS] == 2) {
+            // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after two rounds; every
+            // iteration behind it returned at the stop word.  Finish it from the host, then go on.
+            e->cur = 1;
+            SweepCtx sc;
+            sc.use_nei = true;
+            SweepArgs& a = sc.a;
+            a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = 1;
+            a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
+            a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = 1u; a.sweep_id_ptr = nullptr;
+            sc.r = 2; sc.checked = 2;
+            if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
+            if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
+            e->sweep_rounds += 1;                                  // + the blind sweep
+            e->cur = 2; e->sweep_counter = 2;
+            e->masks_valid = false;
+            if (e->ncem()) { if ((r = do_labels_post(e, 2, -1))) return r; }
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, 2, 1, e->stream));
+            first = false;
+            continue;
+        }
+        first = false;
+        e->cur = (base + commits) % 3;
+        e->sweep_counter = sweep0 + (uint32_t)done;
+        n_iters -= done;
         if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
             e->status = NEMGPU_W_EMPTYCLASS;
             e->emptyk = c[C_EMPTYK];
@@ -477,9 +544,10 @@ int iterate(nemgpu_engine* e, int n_iters)
 
 void drop_graphs(nemgpu_engine* e)
 {
-    for (auto& row : e->graphs)
-        for (auto& g : row)
-            if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto& plane : e->graphs)
+        for (auto& row : plane)
+            for (auto& g : row)
+                if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
 
 int ensure_crit_buffers(nemgpu_engine* e)
@@ -519,7 +587,7 @@ int criteria(nemgpu_engine* e, float crit6[6])
     return NEMGPU_OK;
 }
 
-int reset_state(nemgpu_engine* e)
+int reset_device(nemgpu_engine* e)
 {
     if (e->have_params) {
         HIPCHK(hipMemcpyAsync(e->prop, e->prop0, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
@@ -528,6 +596,13 @@ int reset_state(nemgpu_engine* e)
     }
     HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
     HIPCHK(hipMemsetAsync(e->sweep_next, 0, sizeof(int), e->stream));
+    return NEMGPU_OK;
+}
+
+int reset_state(nemgpu_engine* e)
+{
+    int r0 = reset_device(e);
+    if (r0) return r0;
     e->tables_fresh = false;
     e->density_fresh = false;
     e->cur = 0; e->sweep_counter = 0;
@@ -751,16 +826,25 @@ int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
     return NEMGPU_OK;
 }
 
+int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
+{
+    // reset + ComputePartitionFromPara(Needinit=1) + up to n_iters EM iterations as ONE pipelined batch sequence
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r = iterate(e, n_iters, true);
+    if (r) return r;
+    fill_result(e, res);
+    return NEMGPU_OK;
+}
+
 int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     int r;
-    if ((r = reset_state(e))) return r;
-    if ((r = init_partition(e))) return r;
     HIPCHK(hipStreamSynchronize(e->stream));
     auto t0 = std::chrono::steady_clock::now();
-    if ((r = iterate(e, e->cfg.it_max))) return r;
+    if ((r = iterate(e, e->cfg.it_max, true))) return r;           // restart + initial sweeps + EM loop, pipelined
     HIPCHK(hipStreamSynchronize(e->stream));
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (e->iters == 0) {                                           // nem_alg.c:1845-1851

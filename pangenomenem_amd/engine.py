@@ -62,6 +62,7 @@ def load_library():
     lib.nemgpu_init_partition.argtypes = [vp]
     lib.nemgpu_iterate.argtypes = [vp, C.c_int, C.POINTER(Result)]
     lib.nemgpu_reset.argtypes = [vp]
+    lib.nemgpu_restart_iterate.argtypes = [vp, C.c_int, C.POINTER(Result)]
     lib.nemgpu_density.argtypes = [vp]
     lib.nemgpu_sweep.argtypes = [vp, C.c_float, ip]
     lib.nemgpu_mstep.argtypes = [vp, ip]
@@ -194,6 +195,12 @@ class NemEngine:
 
     def reset(self):
         self._chk(self.lib.nemgpu_reset(self._h))
+
+    def restart_iterate(self, n_iters):
+        """reset + initial sweeps + up to n_iters EM iterations, enqueued as one pipelined sequence."""
+        r = Result()
+        self._chk(self.lib.nemgpu_restart_iterate(self._h, int(n_iters), C.byref(r)))
+        return self._result(r)
 
     def density(self):
         self._chk(self.lib.nemgpu_density(self._h))
