@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -369,11 +370,26 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     int r;
     const int saved = e->cur;
     e->cur = cur;
-    if (!e->cfg.param_fix) {                                       // nem_alg.c:1806
-        if ((r = do_mstep(e))) { e->cur = saved; return r; }
-        if ((r = do_tables(e))) { e->cur = saved; return r; }
+    const bool fused = !e->cfg.param_fix && e->ncem() && e->d <= kFusedMaxD &&
+                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
+    if (fused) {
+        // M-step counts, then ONE kernel: parameter update (per block, from the counts) + density
+        if (!e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) { e->cur = saved; return r; } }
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
+        launch_density_fused(finish_args(e, 1, e->stats), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+                             e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { e->cur = saved; set_error(std::string("launch failed: ") + hipGetErrorString(le)); return NEMGPU_E_DEVICE; }
+        e->flags_clean = true;
+        e->tables_fresh = false;                                   // the table buffers were not rebuilt
+        e->density_fresh = true;
+    } else {
+        if (!e->cfg.param_fix) {                                   // nem_alg.c:1806
+            if ((r = do_mstep(e))) { e->cur = saved; return r; }
+            if ((r = do_tables(e))) { e->cur = saved; return r; }
+        }
+        if ((r = do_density(e))) { e->cur = saved; return r; }
     }
-    if ((r = do_density(e))) { e->cur = saved; return r; }
     SweepCtx c;
     e->sweep_counter = sweep_id;
     if ((r = sweep_enqueue(e, e->cfg.beta, c))) { e->cur = saved; return r; }
@@ -479,7 +495,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             if (e->first_zero < 0) e->first_zero = e->n_total - c[C_FIRSTZERO];
         }
         e->flags_clean = false;
-        e->tables_fresh = true;
+        e->tables_fresh = e->cfg.param_fix;                        // (the fused density kernel does not rebuild the table buffers)
         if (e->ncem()) e->masks_valid = true;
         if (first && c[C_NEED_ROUNDS] == 2) {
             // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after two rounds; every
@@ -662,6 +678,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     e->cfg.algo = NEMGPU_ALGO_NCEM; e->cfg.beta = 0.5f; e->cfg.disper = NEMGPU_DISP_K_; e->cfg.propor = NEMGPU_PROP_K;
     e->cfg.cvtest = NEMGPU_CV_CLAS; e->cfg.cvthres = 1e-8f; e->cfg.it_max = 100; e->cfg.param_fix = 0;
     e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
+    if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
         if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }

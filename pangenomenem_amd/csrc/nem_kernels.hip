@@ -39,6 +39,13 @@ __device__ inline int wave_reduce_add(int v)
     return v;
 }
 
+__device__ inline long long wave_reduce_add_ll(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // layout kernels (one-off, at upload time)
 //   xf  [n][W]      family-major bit rows (host layout)
@@ -224,6 +231,225 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         a.pkfki[(size_t)k * npad + i] = a.pk[k] * fk;            // nem_alg.c:2282
         a.logpkfki[(size_t)k * npad + i] = a.logpk[k] + logfk;   // nem_alg.c:2283
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// E1 with the NCEM parameter update folded in (sk_ and skd models): every block derives the
+// constants of ITS class straight from the globally summed integer statistics -- centres by
+// ComputeMedian's rule, inertia in closed form, dispersion, proportion, the two logs -- instead of
+// waiting for a single-block "finish" launch to publish tables.  K*D is tiny, so the redundancy
+// across blocks is cheaper than a kernel boundary.  Block (0, k) also publishes class k's new
+// centre / dispersion / proportion / size; block (0, 0) the empty-class flag.
+// ------------------------------------------------------------------------------------------
+constexpr int FD_MAXD = 8192;     // organisms the fused kernel supports (iner/eps staged in LDS as floats)
+constexpr int FD_CH = 1024;       // organisms per general-path table chunk
+
+struct FusedDensityArgs {
+    const uint32_t* xw; int n, npad, dpad, D, K, n_total, disper, propor;
+    const int* stats;
+    float* center; float* disp; float* prop; float* nbobs_k;
+    int* iter_flags;
+    double* pkfki; float* logpkfki;
+    int* zero_flags; int n_zero_flags;
+    const int* stop;
+};
+
+__global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
+{
+    __shared__ float sVal[FD_MAXD];                      // inertia per organism, later epsilon per organism
+    __shared__ double2 sT[FD_CH];
+    __shared__ double sL[FD_CH];
+    __shared__ uint32_t sAm0[FD_MAXD / 32], sAm1[FD_MAXD / 32], sNz0[FD_CH / 32], sNz1[FD_CH / 32];
+    __shared__ unsigned long long sTot2;
+    __shared__ float sEps;
+    __shared__ int sGeneral;
+    if (a.stop != nullptr && *a.stop) return;
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = blockIdx.x * 256 + tid;                // i < npad by construction
+    const int npad = a.npad, dpad = a.dpad, D = a.D, K = a.K;
+    const bool writer = (blockIdx.x == 0);               // this block publishes class k's parameters
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int t = tid; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
+        if (tid == 0) {                                  // EstimLaplaceCenters, nem_mod.c:1404-1408
+            int ek = 0;
+            for (int c = 0; c < K; c++) if (!((double)(float)a.stats[c] > kEpsilonD)) ek = c + 1;
+            a.iter_flags[FLAG_EMPTYK] = ek;
+        }
+    }
+    if (tid == 0) { sTot2 = 0ull; sGeneral = 0; }
+    __syncthreads();
+
+    // ---- centres + inertia of class k from the counts (k_finish's centers_ncem_entry, per block)
+    const int nkI = a.stats[k];
+    const float nkf = (float)nkI;
+    const bool nonempty = (double)nkf > kEpsilonD;
+    long long acc2 = 0;
+    int general = 0;
+    for (int d = tid; d < dpad; d += 256) {              // dpad % 64 == 0: whole waves reach the ballots
+        float mu = 0.0f, in = 0.0f;
+        int a0 = 0, a1 = 0;
+        if (d < D) {
+            if (nonempty) {
+                const float half = nkf / 2;
+                const int s1 = a.stats[K + k * D + d];
+                const float s0f = (float)(nkI - s1);
+                if (s0f > half) { mu = 0.0f; in = (float)s1; }
+                else if (s0f == half) { mu = 0.5f; in = 0.5f * nkf; }
+                else { mu = 1.0f; in = s0f; }
+                if (writer) a.center[k * D + d] = mu;
+            } else {
+                mu = a.center[k * D + d];                // empty class keeps its centre (nem_mod.c:1405)
+            }
+            const int ad0 = abs((int)(0.0f - mu)), ad1 = abs((int)(1.0f - mu));
+            a0 = (ad0 != 0); a1 = (ad1 != 0);
+            if (ad0 > 1 || ad1 > 1) general = 1;
+            sVal[d] = in;
+            acc2 += (long long)(2.0f * in);
+        }
+        const uint64_t b0 = __ballot(a0), b1 = __ballot(a1);
+        if (lane == 0) {
+            const int w = d >> 5;
+            sAm0[w] = (uint32_t)b0; sAm0[w + 1] = (uint32_t)(b0 >> 32);
+            sAm1[w] = (uint32_t)b1; sAm1[w + 1] = (uint32_t)(b1 >> 32);
+        }
+    }
+    acc2 = wave_reduce_add_ll(acc2);
+    if (lane == 0 && acc2 != 0) atomicAdd(&sTot2, (unsigned long long)acc2);
+    if (general) sGeneral = 1;
+    __syncthreads();
+
+    // ---- dispersion (InerToDispK_ / InerToDispKD with MISSING_IGNORE, nem_mod.c:1043-1073, 1152-1170)
+    bool eps_per_d = false;                              // epsilon differs between organisms -> general chain
+    if (a.disper == NEMGPU_DISP_K_) {
+        if (nkf > 0) {
+            if (tid == 0) {
+                const long long cap = 1ll << 24;
+                float e;
+                if ((long long)sTot2 <= cap && (long long)nkI * (long long)D <= cap) {
+                    e = (0.5f * (float)(long long)sTot2) / (nkf * (float)D);     // the d-ordered chains never round here
+                } else {
+                    float sn = 0.0f, si = 0.0f;
+                    for (int d = 0; d < D; d++) { sn += nkf; si += sVal[d]; }
+                    e = si / sn;
+                }
+                sEps = e;
+            }
+            __syncthreads();
+            const float e = sEps;
+            if (writer) for (int d = tid; d < D; d += 256) a.disp[k * D + d] = e;
+        } else {
+            // empty class keeps whatever dispersions it had (possibly different per organism)
+            __syncthreads();
+            for (int d = tid; d < D; d += 256) sVal[d] = a.disp[k * D + d];
+            eps_per_d = true;
+        }
+    } else {                                             // NEMGPU_DISP_KD
+        __syncthreads();
+        for (int d = tid; d < D; d += 256) {
+            float e;
+            if (nonempty) { e = sVal[d] / nkf; if (writer) a.disp[k * D + d] = e; }
+            else e = a.disp[k * D + d];
+            sVal[d] = e;
+        }
+        eps_per_d = true;
+    }
+    // ---- proportion (nem_mod.c:456-465) and the class constants of ComputePkFkiM (nem_alg.c:2262-2271)
+    const float propk = (a.propor == NEMGPU_PROP_K) ? nkf / (float)a.n_total : (float)(1.0 / K);
+    if (writer && tid == 0) { a.prop[k] = propk; a.nbobs_k[k] = nkf; }
+    const double pkd = (double)propk;
+    const float logpk = (pkd > kEpsilonD) ? (float)log(pkd) : -INFINITY;
+    __syncthreads();
+
+    float dk = 0.0f;
+    uint32_t nul = 0;
+    const float eps_u = sEps;
+    bool uniform = !eps_per_d && !sGeneral && ((double)eps_u > kEpsilonD);
+    double l1 = 0.0, l0 = 0.0;
+    if (uniform) {
+        l1 = log((double)((1.0f - eps_u) / eps_u));
+        l0 = log((double)(1.0f - eps_u));
+        if (!isfinite(l1) || !isfinite(l0)) uniform = false;
+    }
+    if (uniform) {
+        const int wlast = (D - 1) >> 5;
+        uint32_t xnext = a.xw[i];
+        for (int w = 0; w <= wlast; w++) {
+            const uint32_t x = xnext;
+            if (w < wlast) xnext = a.xw[(size_t)(w + 1) * npad + i];
+            const uint32_t m = (x & sAm1[w]) | (~x & sAm0[w]);
+            const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
+            if (nb == 32) {
+#pragma unroll
+                for (int b = 0; b < 32; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+            } else {
+                for (int b = 0; b < nb; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+            }
+        }
+    } else {
+        // general chain: per-organism constants built chunk by chunk in LDS (table_entry's arithmetic)
+        for (int d0 = 0; d0 < dpad; d0 += FD_CH) {
+            const int dn = min(FD_CH, dpad - d0);
+            __syncthreads();
+            for (int t = tid; t < dn; t += 256) {        // dn % 64 == 0
+                const int d = d0 + t;
+                double t0 = 0.0, t1 = 0.0, ll0 = 0.0;
+                int n0 = 0, n1 = 0;
+                if (d < D) {
+                    const float eps = eps_per_d ? sVal[d] : eps_u;
+                    int ad0, ad1;
+                    if (nonempty) { ad0 = (sAm0[d >> 5] >> (d & 31)) & 1; ad1 = (sAm1[d >> 5] >> (d & 31)) & 1; }
+                    else { const float mu = a.center[k * D + d]; ad0 = abs((int)(0.0f - mu)); ad1 = abs((int)(1.0f - mu)); }
+                    if ((double)eps > kEpsilonD) {
+                        const double ll1 = log((double)((1.0f - eps) / eps));
+                        ll0 = log((double)(1.0f - eps));
+                        t0 = (double)ad0 * ll1;
+                        t1 = (double)ad1 * ll1;
+                    } else { n0 = (ad0 != 0); n1 = (ad1 != 0); }
+                }
+                sT[t] = make_double2(t0, t1);
+                sL[t] = ll0;
+                const uint64_t m0 = __ballot(n0), m1 = __ballot(n1);
+                if (lane == 0) {
+                    sNz0[t >> 5] = (uint32_t)m0; sNz0[(t >> 5) + 1] = (uint32_t)(m0 >> 32);
+                    sNz1[t >> 5] = (uint32_t)m1; sNz1[(t >> 5) + 1] = (uint32_t)(m1 >> 32);
+                }
+            }
+            __syncthreads();
+            const int w0 = d0 >> 5, wn = dn >> 5;
+            uint32_t xnext = a.xw[(size_t)w0 * npad + i];
+            for (int w = 0; w < wn; w++) {
+                const uint32_t x = xnext;
+                if (w + 1 < wn) xnext = a.xw[(size_t)(w0 + w + 1) * npad + i];
+                nul |= (x & sNz1[w]) | (~x & sNz0[w]);
+#pragma unroll 8
+                for (int b = 0; b < 32; b++) {
+                    const double2 tt = sT[w * 32 + b];
+                    const double c0 = sL[w * 32 + b];
+                    const double add = ((x >> b) & 1u) ? tt.y : tt.x;
+                    dk = (float)(((double)dk + add) - c0);       // nem_mod.c:661
+                }
+            }
+        }
+    }
+    if (i < a.n) {
+        float logfk; double fk;
+        if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
+        else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
+        a.pkfki[(size_t)k * npad + i] = pkd * fk;                // nem_alg.c:2282
+        a.logpkfki[(size_t)k * npad + i] = logpk + logfk;        // nem_alg.c:2283
+    }
+}
+
+void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+                          int* zero_flags, int n_zero_flags, hipStream_t s)
+{
+    FusedDensityArgs a;
+    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
+    a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
+    a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
+    a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
+    hipLaunchKernelGGL(k_density_fused, dim3(npad / 256, t.K), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -563,13 +789,6 @@ __device__ inline void seq_sum_pair(const float4* __restrict__ v4, int n4, float
         si = (((si + v.x) + v.y) + v.z) + v.w;
         sn = (((sn + nk) + nk) + nk) + nk;
     }
-}
-
-__device__ inline long long wave_reduce_add_ll(long long v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
 }
 
 // `exact_half_ints`: the inertia values are non-negative multiples of 1/2 and N_K is an integer (NCEM).

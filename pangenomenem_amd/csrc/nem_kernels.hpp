@@ -72,6 +72,10 @@ struct FinishArgs {
 void launch_finish(const FinishArgs& a, hipStream_t s);
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                     int* zero_flags, int n_zero_flags, hipStream_t s);
+// NCEM, sk_/skd, D <= kFusedMaxD: parameter update from t.stats folded into the density kernel (no k_finish)
+constexpr int kFusedMaxD = 8192;
+void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+                          int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
                         uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s);
