@@ -986,14 +986,26 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
     if (!e || !labels_old_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     int r;
-    if (stats_dev != nullptr) {
-        launch_finish(finish_args(e, 1, stats_dev), e->stream);
+    const bool fused = stats_dev != nullptr && e->d <= kFusedMaxD &&
+                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
+    if (fused) {
+        // parameter update (per block, from the summed counts) + density in one launch
+        launch_density_fused(finish_args(e, 1, stats_dev), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+                             e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
         HIPCHK(hipGetLastError());
-        e->tables_fresh = true;
-        e->density_fresh = false;
-    } else if ((r = do_tables(e))) return r;
-    if (e->density_fresh) { if ((r = clear_sweep_flags(e))) return r; }   // same parameters as the last E1: keep pkfki
-    else if ((r = do_density(e))) return r;                        // also clears MOVED + the round flag window
+        e->tables_fresh = false;
+        e->density_fresh = true;
+        e->flags_clean = true;
+    } else {
+        if (stats_dev != nullptr) {
+            launch_finish(finish_args(e, 1, stats_dev), e->stream);
+            HIPCHK(hipGetLastError());
+            e->tables_fresh = true;
+            e->density_fresh = false;
+        } else if ((r = do_tables(e))) return r;
+        if (e->density_fresh) { if ((r = clear_sweep_flags(e))) return r; }   // same parameters as the last E1: keep pkfki
+        else if ((r = do_density(e))) return r;                    // also clears MOVED + the round flag window
+    }
     SweepArgs a;
     shard_sweep_args(e, a, beta, sweep_id);
     a.lab_old = labels_old_dev; a.lab_guess = labels_old_dev; a.lab_out = labels_out_dev;
