@@ -527,8 +527,12 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
         const float u = (float)(1.0 / K);
 #pragma unroll
         for (int k = 0; k < KA; k++) if (k < K) cf[k] = u;
-        atomicAdd(&a.flags[FLAG_NZERO], 1);
-        atomicMax(&a.flags[FLAG_FIRSTZERO], a.n_total - gi);   // first site = n_total - max
+        // (lanes of a wave are consecutive sites: the first active lane here is the wave's lowest zero-density site)
+        const uint64_t zmask = __ballot(1);
+        if ((threadIdx.x & 63) == __ffsll((long long)zmask) - 1) {
+            atomicAdd(&a.flags[FLAG_NZERO], (int)__popcll(zmask));
+            atomicMax(&a.flags[FLAG_FIRSTZERO], a.n_total - gi);   // first site = n_total - max
+        }
     }
 
     bool changed = false;
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
             }
         }
     }
-    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
+    if (__any(changed) && (threadIdx.x & 63) == 0 && a.flags[FLAG_CHANGED] == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
 }
 
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
@@ -720,7 +724,7 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
             uint64_t m = __ballot(lab == k);
             if (lane == 0) mask[(size_t)k * nw64 + wave] = m;
         }
-        if (__any(moved) && lane == 0) atomicOr(&flags[FLAG_MOVED], 1);
+        if (__any(moved) && lane == 0 && flags[FLAG_MOVED] == 0) atomicOr(&flags[FLAG_MOVED], 1);
     }
     if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
 }

@@ -73,7 +73,7 @@ void launch_finish(const FinishArgs& a, hipStream_t s);
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                     int* zero_flags, int n_zero_flags, hipStream_t s);
 // NCEM, sk_/skd, D <= kFusedMaxD: parameter update from t.stats folded into the density kernel (no k_finish)
-constexpr int kFusedMaxD = 8192;
+constexpr int kFusedMaxD = 1024;   // beyond this the per-block parameter derivation costs more than a k_finish launch
 void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                           int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);

@@ -19,8 +19,12 @@ def bernoulli_pa_matrix(n, d, seed, mix=(0.30, 0.20, 0.50), p=(0.97, 0.5, 0.03))
     one random 1 (a family absent from every selected organism is never written, ppanggolin.py:849)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     z = rng.choice(len(mix), size=n, p=np.asarray(mix) / np.sum(mix))
-    pz = np.asarray(p, np.float64)[z]
-    x = (rng.random((n, d)) < pz[:, None]).astype(np.uint8)
+    pz = np.asarray(p, np.float32)[z]
+    x = np.empty((n, d), np.uint8)
+    step = max(1, (1 << 26) // max(d, 1))              # rows per chunk: keeps the float scratch around 256 MB
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        x[r0:r1] = rng.random((r1 - r0, d), dtype=np.float32) < pz[r0:r1, None]
     empty = np.flatnonzero(x.sum(axis=1) == 0)
     x[empty, rng.integers(0, d, size=len(empty))] = 1
     return x, z
