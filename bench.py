@@ -73,6 +73,22 @@ def cpu_baseline(x, nei, prop, center, disp, beta, algo, iters):
                 em_iterations_per_sec=1.0 / per_it)
 
 
+def pmc_traffic(kernel, n_loc, d):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_density.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this very command,
+    FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, checked with a known-size read).  Only valid
+    for the workload it was measured on; null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_density.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("families") == n_loc and rec.get("organisms") == d and kernel in rec.get("kernels", {}):
+            return rec["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -177,12 +193,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_density (E1 Bernoulli log-density chains)",
+                "kernel": prof.get("kernel", "k_density") + " (E1 Bernoulli log-density chains)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(prof.get("kernel", "k_density"), n_loc, d),
                 "algorithmic_bytes_per_launch": prof["algorithmic_bytes_per_launch"],
                 "avg_launch_ms": prof["density_ms_avg"],
                 "launches_timed": prof["density_launches"],

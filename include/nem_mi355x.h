@@ -203,7 +203,11 @@ int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, in
 /* Kernel-duration probe for bench.py: `reps` launches of the E1 density kernel on the current
    parameters, each bracketed by HIP events on the engine's stream; average duration (ms) and the
    algorithmic bytes one launch moves. */
-int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch);
+int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch,
+                           int* used_fused_kernel);
+/* FETCH_SIZE calibration helper: `reps` launches reading `bytes` of device memory one dword per lane (E1's
+   pattern); run under `rocprofv3 --pmc FETCH_SIZE` and compare with the known byte count (profiles/README.md). */
+int nemgpu_calibrate_fetch(size_t bytes, int reps);
 
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);

@@ -1203,7 +1203,8 @@ int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
 // Kernel-duration probe for bench.py: `reps` launches of the E1 density kernel on the current parameters,
 // each bracketed by HIP events recorded on the engine's stream; returns the average duration and the
 // algorithmic bytes one launch moves.
-int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch)
+int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch,
+                           int* used_fused_kernel)
 {
     if (!e || reps <= 0) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
@@ -1211,9 +1212,16 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
     if ((r = do_tables(e))) return r;
     if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }
     double total = 0.0;
+    // measure the kernel the EM loop actually launches: the fused one (parameter update + density) when it applies
+    const bool fused = !e->cfg.param_fix && e->ncem() && e->d <= kFusedMaxD && e->iters > 0 &&
+                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
     for (int i = 0; i < reps; i++) {
         HIPCHK(hipEventRecord(e->ev0, e->stream));
-        if ((r = do_density(e))) return r;
+        if (fused) {
+            launch_density_fused(finish_args(e, 1, e->stats), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+                                 e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+            HIPCHK(hipGetLastError());
+        } else if ((r = do_density(e))) return r;
         HIPCHK(hipEventRecord(e->ev1, e->stream));
         HIPCHK(hipEventSynchronize(e->ev1));
         float ms = 0.f;
@@ -1221,11 +1229,29 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
         total += ms;
     }
     if (avg_ms) *avg_ms = total / reps;
+    if (used_fused_kernel) *used_fused_kernel = fused ? 1 : 0;
     if (algorithmic_bytes_per_launch) {
         // E1 per launch: the bit-packed matrix once, the (k,d) tables once, pk*fk (f64) and log (f32) out
         *algorithmic_bytes_per_launch = (double)e->n * e->wf * 4.0 + (double)e->k * e->d * 24.0 +
                                         (double)e->n * e->k * 12.0;
     }
+    return NEMGPU_OK;
+}
+
+// FETCH_SIZE calibration helper (profiles/README.md): one launch that reads `bytes` of freshly written device
+// memory with E1's dword-per-lane pattern.  Run it under `rocprofv3 --pmc FETCH_SIZE` and compare.
+int nemgpu_calibrate_fetch(size_t bytes, int reps)
+{
+    if (bytes < 4096 || reps <= 0) return NEMGPU_E_FUNCARG;
+    uint32_t* buf = nullptr; uint32_t* sink = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, bytes));
+    HIPCHK(hipMalloc((void**)&sink, 64));
+    HIPCHK(hipMemset(buf, 0x5A, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < reps; i++) launch_calib_read(buf, bytes / 4, sink, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    (void)hipFree(buf); (void)hipFree(sink);
+    HIPCHK(err);
     return NEMGPU_OK;
 }
 

@@ -146,13 +146,26 @@ __device__ inline void table_entry(const FinishArgs& a, int t)
 // ------------------------------------------------------------------------------------------
 constexpr int DCH = 2048;
 
+// XCD-aware tile mapping for the density kernels (1-D grid of ceil(tiles/8)*8*K blocks).  Blocks are dealt
+// round-robin over the 8 XCDs, so blocks b, b+8, b+16, ... share an XCD and its L2: the K class-blocks of one
+// family tile are placed 8 apart and pull the tile's matrix words through ONE L2 instead of K
+// (speed only: any placement computes the same thing).
+__device__ inline bool density_tile(int K, int ntiles, int& tile, int& k)
+{
+    const int b = blockIdx.x;
+    const int g = b / (8 * K), r = b - g * (8 * K);
+    k = r >> 3;
+    tile = g * 8 + (r & 7);
+    return tile < ntiles;
+}
+
 __device__ inline float bern_step(float dk, bool b, double l1, double l0)
 {
     return (float)(((double)dk + (b ? l1 : 0.0)) - l0);              // nem_mod.c:661
 }
 
 struct DensityArgs {
-    const uint32_t* xw; int n, npad, dpad, D;
+    const uint32_t* xw; int n, npad, dpad, D, K;
     const double2* tabT; const double* tabL0; const uint32_t* nz0; const uint32_t* nz1;
     const uint32_t* am0; const uint32_t* am1; const double2* uni; const int* nonuni;
     const double* pk; const float* logpk;
@@ -166,15 +179,16 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
     if (a.stop != nullptr && *a.stop) return;
-    const int k = blockIdx.y;
+    int k, tile;
+    if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;                // i < npad by construction
+    const int i = tile * 256 + tid;                      // i < npad by construction
     const int npad = a.npad, dpad = a.dpad;
     const int W = dpad >> 5;
     float dk = 0.0f;
     uint32_t nul = 0;
     // the sweep that follows this launch starts from clean flags (MOVED + the relaxation-round window)
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (tile == 0 && k == 0)
         for (int t = tid; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
 
     if (a.nonuni[k] == 0) {
@@ -264,12 +278,13 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     __shared__ float sEps;
     __shared__ int sGeneral;
     if (a.stop != nullptr && *a.stop) return;
-    const int k = blockIdx.y;
+    int k, tile;
+    if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int i = blockIdx.x * 256 + tid;                // i < npad by construction
+    const int i = tile * 256 + tid;                      // i < npad by construction
     const int npad = a.npad, dpad = a.dpad, D = a.D, K = a.K;
-    const bool writer = (blockIdx.x == 0);               // this block publishes class k's parameters
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    const bool writer = (tile == 0);                     // this block publishes class k's parameters
+    if (tile == 0 && k == 0) {
         for (int t = tid; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
         if (tid == 0) {                                  // EstimLaplaceCenters, nem_mod.c:1404-1408
             int ek = 0;
@@ -449,7 +464,7 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
     a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
     a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
-    hipLaunchKernelGGL(k_density_fused, dim3(npad / 256, t.K), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_density_fused, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1165,12 +1180,12 @@ void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, do
                     int* zero_flags, int n_zero_flags, hipStream_t s)
 {
     DensityArgs a;
-    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D;
+    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K;
     a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
     a.uni = t.uni; a.nonuni = t.nonuni; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
     a.stop = t.stop;
-    hipLaunchKernelGGL(k_density, dim3(npad / 256, t.K), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_density, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
@@ -1210,6 +1225,21 @@ void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)
 {
     size_t m = (size_t)n * K;
     hipLaunchKernelGGL(k_onehot, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, n, K, lab, c);
+}
+
+// FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): a read of a KNOWN byte count with E1's access
+// pattern -- one dword per lane, lanes consecutive, row after row -- so that the counter can be scaled.
+__global__ __launch_bounds__(256) void k_calib_read_dwords(const uint32_t* __restrict__ buf, size_t words,
+                                                           uint32_t* __restrict__ sink)
+{
+    uint32_t acc = 0;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (size_t)gridDim.x * 256) acc ^= buf[t];
+    if (acc == 0x9E3779B9u) sink[0] = acc;               // keeps the loads alive; practically never taken
+}
+
+void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_calib_read_dwords, dim3(256 * 16), dim3(256), 0, s, buf, words, sink);
 }
 
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,

@@ -72,7 +72,8 @@ def load_library():
     lib.nemgpu_get_labels.argtypes = [vp, vp]
     lib.nemgpu_get_params.argtypes = [vp, vp, vp, vp, vp]
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
-    lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), ip]
+    lib.nemgpu_calibrate_fetch.argtypes = [C.c_size_t, C.c_int]
     lib.nemgpu_set_stream.argtypes = [vp, vp]
     lib.nemgpu_shard_end_enqueue.argtypes = [vp]
     lib.nemgpu_stats_words.argtypes = [vp]
@@ -299,12 +300,20 @@ class NemEngine:
 
     def profile_density(self, reps=50):
         """Average duration of the E1 density kernel (HIP events on the engine's stream) and its algorithmic bytes."""
-        ms, b = C.c_double(0), C.c_double(0)
-        self._chk(self.lib.nemgpu_profile_density(self._h, int(reps), C.byref(ms), C.byref(b)))
-        return dict(density_ms_avg=ms.value, density_launches=int(reps), algorithmic_bytes_per_launch=b.value)
+        ms, b, fused = C.c_double(0), C.c_double(0), C.c_int(0)
+        self._chk(self.lib.nemgpu_profile_density(self._h, int(reps), C.byref(ms), C.byref(b), C.byref(fused)))
+        return dict(density_ms_avg=ms.value, density_launches=int(reps), algorithmic_bytes_per_launch=b.value,
+                    kernel="k_density_fused" if fused.value else "k_density")
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+def calibrate_fetch(nbytes=1 << 30, reps=3):
+    """One known-size dword-per-lane read, for scaling rocprofv3's FETCH_SIZE (profiles/README.md)."""
+    rc = load_library().nemgpu_calibrate_fetch(int(nbytes), int(reps))
+    if rc != 0:
+        raise NemGpuError("nemgpu_calibrate_fetch failed (status %d)" % rc)
 
 
 def solve(x, nei, k, prop, center, disp, device=0, **cfg):
