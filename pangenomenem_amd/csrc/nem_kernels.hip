@@ -90,7 +90,26 @@ __global__ void k_layout_bits(const uint32_t* __restrict__ xw, int npad, int d, 
 //   "null density" bit when the mismatch is non-zero (nem_mod.c:662-666).
 // Padding organisms (d >= D) get all-zero entries: the chain step is then an exact no-op.
 // ------------------------------------------------------------------------------------------
-// one table entry t = k * dpad + dd; called by whole waves (dpad % 64 == 0)
+// does organism dd force class k onto the general (per-organism constants) chain?  cheap: no logs
+__device__ inline void table_flag_general(const FinishArgs& a, int t)
+{
+    const int D = a.D, dpad = a.dpad;
+    const int k = t / dpad, dd = t - k * dpad;
+    if (dd >= D) return;
+    const float eps = a.disp[k * D + dd];
+    const float mu = a.center[k * D + dd];
+    const int ad0 = abs((int)(0.0f - mu)), ad1 = abs((int)(1.0f - mu));
+    bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(a.disp[k * D])) ||
+                   !((double)eps > kEpsilonD);
+    if (!general && dd == 0) {
+        const double l1 = log((double)((1.0f - eps) / eps)), l0 = log((double)(1.0f - eps));
+        if (!isfinite(l1) || !isfinite(l0)) general = true;       // 0 * inf / NaN must propagate as in the reference
+    }
+    if (general) a.nonuni[k] = 1;
+}
+
+// one table entry t = k * dpad + dd; called by whole waves (dpad % 64 == 0).  Classes that stay on the
+// uniform chain (nonuni[k] == 0, decided by table_flag_general) need the mismatch masks and uni[k] only.
 __device__ inline void table_entry(const FinishArgs& a, int t)
 {
     const int K = a.K, D = a.D, dpad = a.dpad;
@@ -105,23 +124,23 @@ __device__ inline void table_entry(const FinishArgs& a, int t)
         const int ad0 = abs((int)(0.0f - mu));
         const int ad1 = abs((int)(1.0f - mu));
         a0 = (ad0 != 0); a1 = (ad1 != 0);
-        bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(a.disp[k * D]));
+        const bool need_tables = a.nonuni[k] != 0;
         if ((double)eps > kEpsilonD) {
-            const double l1 = log((double)((1.0f - eps) / eps));
-            l0 = log((double)(1.0f - eps));
-            t0 = (double)ad0 * l1;
-            t1 = (double)ad1 * l1;
-            if (dd == 0) a.uni[k] = make_double2(l1, l0);
-            if (!isfinite(l1) || !isfinite(l0)) general = true;   // 0 * inf / NaN must propagate as in the reference
+            if (need_tables || dd == 0) {
+                const double l1 = log((double)((1.0f - eps) / eps));
+                l0 = log((double)(1.0f - eps));
+                t0 = (double)ad0 * l1;
+                t1 = (double)ad1 * l1;
+                if (dd == 0) a.uni[k] = make_double2(l1, l0);
+            }
         } else {
             n0 = a0; n1 = a1;
-            general = true;
         }
-        // class k may use the uniform-dispersion chain only if every organism agrees
-        if (general) a.nonuni[k] = 1;
     }
-    a.tabT[t] = make_double2(t0, t1);
-    a.tabL0[t] = l0;
+    if (dd >= D || a.nonuni[k] != 0) {                   // (padding entries are always written: zeros)
+        a.tabT[t] = make_double2(t0, t1);
+        a.tabL0[t] = l0;
+    }
     const uint64_t m0 = __ballot(n0), m1 = __ballot(n1), b0 = __ballot(a0), b1 = __ballot(a1);
     if (lane == 0) {
         const int w = t >> 5;                            // word index inside [K][dpad/32]
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
 // across blocks is cheaper than a kernel boundary.  Block (0, k) also publishes class k's new
 // centre / dispersion / proportion / size; block (0, 0) the empty-class flag.
 // ------------------------------------------------------------------------------------------
-constexpr int FD_MAXD = 8192;     // organisms the fused kernel supports (iner/eps staged in LDS as floats)
+constexpr int FD_MAXD = kFusedMaxD; // organisms the fused kernel supports (iner/eps staged in LDS as floats)
 constexpr int FD_CH = 1024;       // organisms per general-path table chunk
 
 struct FusedDensityArgs {
@@ -487,11 +506,17 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
         for (int r = 0; r < a.n_ranks; r++) any |= a.flags_in[(size_t)r * a.slot_stride];
         if (!any) return;
     }
+    __shared__ int s_nzero, s_first;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n_local) return;
-    const int gi = a.lo + i;
+    const bool active = i < a.n_local;
+    const int gi = a.lo + (active ? i : 0);
     const int K = KT > 0 ? KT : a.K;
     constexpr int KA = KT > 0 ? KT : kMaxKernelK;
+    bool zero_density = false;
+    bool changed = false;
+    if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
+    __syncthreads();
+    if (active) {
 
     float ctx[KA];
 #pragma unroll
@@ -542,15 +567,9 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
         const float u = (float)(1.0 / K);
 #pragma unroll
         for (int k = 0; k < KA; k++) if (k < K) cf[k] = u;
-        // (lanes of a wave are consecutive sites: the first active lane here is the wave's lowest zero-density site)
-        const uint64_t zmask = __ballot(1);
-        if ((threadIdx.x & 63) == __ffsll((long long)zmask) - 1) {
-            atomicAdd(&a.flags[FLAG_NZERO], (int)__popcll(zmask));
-            atomicMax(&a.flags[FLAG_FIRSTZERO], a.n_total - gi);   // first site = n_total - max
-        }
+        zero_density = true;                             // counted by the caller, once per block
     }
 
-    bool changed = false;
     if (NCEM) {                                          // ComputeMAP, nem_alg.c:603-640
         int kmax = 0; float ukmax = cf[0];
 #pragma unroll
@@ -584,7 +603,19 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
             }
         }
     }
+    }   // active
     if (__any(changed) && (threadIdx.x & 63) == 0 && a.flags[FLAG_CHANGED] == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
+    // zero-density sites (nem_alg.c:2603-2613): count and first index, one pair of atomics per block
+    const uint64_t zmask = __ballot(zero_density);
+    if (zmask != 0ull && (threadIdx.x & 63) == 0) {
+        atomicAdd(&s_nzero, (int)__popcll(zmask));
+        atomicMax(&s_first, a.n_total - (gi + (int)__ffsll((long long)zmask) - 1));   // lanes are consecutive sites
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_nzero > 0) {
+        atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
+        atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);    // first site = n_total - max
+    }
 }
 
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
@@ -956,6 +987,8 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
         __syncthreads();
     }
     if (tid < a.K) a.nonuni[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < a.K * a.dpad; t += 1024) table_flag_general(a, t);
     __syncthreads();
     for (int t = tid; t < a.K * a.dpad; t += 1024) table_entry(a, t);     // K*dpad and 1024 are multiples of 64
 }
