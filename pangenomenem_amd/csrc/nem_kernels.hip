@@ -178,9 +178,17 @@ __device__ inline bool density_tile(int K, int ntiles, int& tile, int& k)
     return tile < ntiles;
 }
 
-__device__ inline float bern_step(float dk, bool b, double l1, double l0)
+// One organism of the uniform chain: dk <- (float)(((double)dk + m_b * l1) - l0)  (nem_mod.c:661), m_b = bit b
+// of the mismatch word m.  m_b * l1 is formed inside an fma as {2.0 | 0.0} * (l1 / 2): the product is exact
+// (a power-of-two scaling of l1, including the reference's 0 * l1 = -0 for negative l1), so the fma rounds
+// once, exactly where the reference's add does.  The 2.0 / 0.0 factor is the mismatch bit moved to bit 30 of
+// a double's high word -- a shift and an and instead of a compare and two 64-bit selects (6 VALU
+// instructions per organism instead of 9; the chain itself stays fma, add, cvt, cvt).
+__device__ inline float bern_step(float dk, uint32_t m, int b, double l1h, double l0)
 {
-    return (float)(((double)dk + (b ? l1 : 0.0)) - l0);              // nem_mod.c:661
+    const uint32_t hi = ((b <= 30) ? (m << (30 - b)) : (m >> 1)) & 0x40000000u;
+    const double f = __hiloint2double((int)hi, 0);
+    return (float)(fma(f, l1h, (double)dk) - l0);
 }
 
 struct DensityArgs {
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         // (An exact "fast-forward" of whole runs of steps inside one float binade -- integer adds on the
         // bit pattern + popcounts -- was built and is bit-identical, but lane divergence at the binade
         // crossings made it slower than this plain chain at D = 500)
-        const double l1 = a.uni[k].x, l0 = a.uni[k].y;
+        const double l1h = 0.5 * a.uni[k].x, l0 = a.uni[k].y;    // l1 is 0 or a normal double: halving is exact
         const int wlast = (a.D - 1) >> 5;                // padding organisms must not take a step here
         uint32_t xnext = a.xw[i];
         for (int w = 0; w <= wlast; w++) {
@@ -226,9 +234,9 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
             const int nb = (w < wlast) ? 32 : (a.D - (wlast << 5));
             if (nb == 32) {
 #pragma unroll
-                for (int b = 0; b < 32; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+                for (int b = 0; b < 32; b++) dk = bern_step(dk, m, b, l1h, l0);
             } else {
-                for (int b = 0; b < nb; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+                for (int b = 0; b < nb; b++) dk = bern_step(dk, m, b, l1h, l0);
             }
         }
     } else {
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         if (!isfinite(l1) || !isfinite(l0)) uniform = false;
     }
     if (uniform) {
+        const double l1h = 0.5 * l1;                     // l1 is 0 or a normal double: halving is exact
         const int wlast = (D - 1) >> 5;
         uint32_t xnext = a.xw[i];
         for (int w = 0; w <= wlast; w++) {
@@ -415,9 +424,9 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
             const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
             if (nb == 32) {
 #pragma unroll
-                for (int b = 0; b < 32; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+                for (int b = 0; b < 32; b++) dk = bern_step(dk, m, b, l1h, l0);
             } else {
-                for (int b = 0; b < nb; b++) dk = bern_step(dk, (m >> b) & 1u, l1, l0);
+                for (int b = 0; b < nb; b++) dk = bern_step(dk, m, b, l1h, l0);
             }
         }
     } else {
