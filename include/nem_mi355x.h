@@ -209,6 +209,17 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
    pattern); run under `rocprofv3 --pmc FETCH_SIZE` and compare with the known byte count (profiles/README.md). */
 int nemgpu_calibrate_fetch(size_t bytes, int reps);
 
+/* E1 fast-forward (pangenomenem_amd/csrc/nem_ff.hpp): inside one float binade the reference's chain
+   dk = (float)(((double)dk + |x-mu|*L1) - L0)  (nem_mod.c:661) adds a constant to the accumulator's bit pattern, so
+   whole 32-organism words advance with one popcount; bit-identical to stepping.  on: 1 always, 0 never,
+   -1 (default) automatic -- long chains (D > 768) or enough chains to fill the GPU more than once.  The
+   environment variable NEM_MI355X_FF=0|1 sets the mode at creation.  The tests compare the two code paths. */
+int nemgpu_set_fast_forward(nemgpu_engine* e, int on);
+/* The increment tables that fast-forward uses for class constants L1 = log((1-eps)/eps), L0 = log(1-eps):
+   q0[E] / q1[E] = bit-pattern increment of a match / mismatch step while the accumulator's exponent field is E
+   (2^23 = "step exactly").  Host-only, needs no GPU. */
+int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256);
+
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "nem_internal.hpp"
+#include "nem_ff.hpp"
 #include "nem_kernels.hpp"
 
 using namespace nemk;
@@ -49,6 +50,13 @@ struct nemgpu_engine {
     bool have_matrix = false, have_params = false, has_graph = false;
 
     uint32_t* xw = nullptr;
+    // E1's own copy of the matrix: word-major like xw, but lane i holds family perm[i].  Families are ordered by
+    // their number of present organisms, so the lanes of a wave run similar chains and cross float binades in
+    // the same words (what makes the fast-forward of nem_ff.hpp coherent across a wave).  Results are written
+    // back through perm, so nothing outside the density kernels sees the order.
+    uint32_t* xws = nullptr;
+    int* perm = nullptr;
+    bool use_sort = true;
     uint64_t* xt = nullptr;
     int *nei_ptr = nullptr, *nei_idx = nullptr;
     float* nei_w = nullptr;
@@ -94,6 +102,11 @@ struct nemgpu_engine {
     // captured batches of the pipelined loop, keyed by (current buffer, iterations in the batch)
     hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
     bool use_graphs = true;
+    int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
+    // auto: fast-forward pays when the chains are long or when there are enough of them to fill the SIMDs more
+    // than once (then the kernel is issue-bound and fewer instructions win); a short chain on a half-empty GPU is
+    // latency-bound and the binade crossings make it slower than plain stepping (measured: D=500, N=20k)
+    bool use_ff() const { return ff_mode < 0 ? (d > 768 || (long long)n * k > 131072) : ff_mode != 0; }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
 
@@ -150,6 +163,8 @@ FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
     t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni;
     t.pk = e->pk; t.logpk = e->logpk; t.flags = e->iter_flags();
     t.stop = e->stop_ptr;
+    t.use_ff = e->use_ff() ? 1 : 0;
+    t.perm = e->perm;
     return t;
 }
 
@@ -166,7 +181,7 @@ int do_tables(nemgpu_engine* e)
 
 int do_density(nemgpu_engine* e)
 {
-    launch_density(finish_args(e, 0, nullptr), e->xw, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
+    launch_density(finish_args(e, 0, nullptr), e->xws, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
                    1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = true;
@@ -376,7 +391,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
         // M-step counts, then ONE kernel: parameter update (per block, from the counts) + density
         if (!e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) { e->cur = saved; return r; } }
         launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
-        launch_density_fused(finish_args(e, 1, e->stats), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+        launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
                              e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { e->cur = saved; set_error(std::string("launch failed: ") + hipGetErrorString(le)); return NEMGPU_E_DEVICE; }
@@ -679,6 +694,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     e->cfg.cvtest = NEMGPU_CV_CLAS; e->cfg.cvthres = 1e-8f; e->cfg.it_max = 100; e->cfg.param_fix = 0;
     e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
     if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
+    if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
+    if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
         if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
@@ -688,6 +705,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     const size_t kd = (size_t)k * d, kdp = (size_t)k * e->dpad;
     auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
     A(dev_alloc(&e->xw, (size_t)e->W * e->npad));
+    A(dev_alloc(&e->xws, (size_t)((e->W + 3) / 4) * 4 * e->npad));   // uint4[ceil(W/4)][npad]
+    A(dev_alloc(&e->perm, (size_t)e->npad));
     A(dev_alloc(&e->xt, (size_t)d * e->nw64));
     A(dev_alloc(&e->prop, (size_t)k)); A(dev_alloc(&e->center, kd)); A(dev_alloc(&e->disp, kd));
     A(dev_alloc(&e->prop0, (size_t)k)); A(dev_alloc(&e->center0, kd)); A(dev_alloc(&e->disp0, kd));
@@ -714,7 +733,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* ptrs[] = {e->xw, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
+    void* ptrs[] = {e->xw, e->xws, e->perm, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
                     e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
                     e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->sweep_next, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
                     e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
@@ -734,10 +753,28 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
     HIPCHK(hipSetDevice(e->device));
     uint32_t* xf = nullptr;
     const size_t words = (size_t)e->n * e->wf;
+    // lane order of the density kernels: stable counting sort of the local families by popcount
+    std::vector<int> perm((size_t)e->npad);
+    for (int i = 0; i < e->npad; i++) perm[i] = i;
+    if (e->use_sort) {
+        std::vector<int> pc((size_t)e->n), start((size_t)e->d + 2, 0);
+        for (int i = 0; i < e->n; i++) {
+            const uint32_t* row = xbits_host + (size_t)i * e->wf;
+            int c = 0;
+            for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
+            if (c > e->d) c = e->d;                                // (stray bits above D in the last word)
+            pc[i] = c;
+            start[c + 1]++;
+        }
+        for (int c = 0; c <= e->d; c++) start[c + 1] += start[c];
+        for (int i = 0; i < e->n; i++) perm[start[pc[i]]++] = i;
+    }
     HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(e->perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess) {
-        launch_layout(xf, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->stream);
+        launch_layout(xf, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->perm, e->xws, e->stream);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
@@ -990,7 +1027,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
                        (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
     if (fused) {
         // parameter update (per block, from the summed counts) + density in one launch
-        launch_density_fused(finish_args(e, 1, stats_dev), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+        launch_density_fused(finish_args(e, 1, stats_dev), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
                              e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
         HIPCHK(hipGetLastError());
         e->tables_fresh = false;
@@ -1218,7 +1255,7 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
     for (int i = 0; i < reps; i++) {
         HIPCHK(hipEventRecord(e->ev0, e->stream));
         if (fused) {
-            launch_density_fused(finish_args(e, 1, e->stats), e->xw, e->n, e->npad, e->pkfki, e->logpkfki,
+            launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
                                  e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
             HIPCHK(hipGetLastError());
         } else if ((r = do_density(e))) return r;
@@ -1256,6 +1293,26 @@ int nemgpu_calibrate_fetch(size_t bytes, int reps)
 }
 
 // Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph).
+int nemgpu_set_fast_forward(nemgpu_engine* e, int on)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    const int mode = on < 0 ? -1 : (on != 0);
+    if (e->ff_mode != mode) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        drop_graphs(e);                                            // captured launches carry the old setting
+        e->ff_mode = mode;
+        e->density_fresh = false;
+    }
+    return NEMGPU_OK;
+}
+
+int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256)
+{
+    if (!q0_256 || !q1_256) return NEMGPU_E_FUNCARG;
+    for (int E = 0; E < 256; E++) nemk::ff_entry(l1, -l0, E, q0_256[E], q1_256[E]);
+    return NEMGPU_OK;
+}
+
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
 {
     if (!e || !hip_stream) return NEMGPU_E_FUNCARG;

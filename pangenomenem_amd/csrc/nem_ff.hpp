@@ -1,0 +1,70 @@
+// nem_ff.hpp -- exact "fast-forward" of the Bernoulli log-density chain inside one float binade.
+//
+// The chain of DensBernoulli (reference nem_mod.c:661) is, per organism,
+//     dk <- RN24( RN53( RN53(dk + t) + b0 ) ),   t = 0 (match) or A (mismatch),
+// with A = log((1-eps)/eps), b0 = -log(1-eps) doubles (uniform dispersion inside the class), RN53 / RN24 =
+// round-to-nearest-even to double / float.  While dk stays inside ONE float binade [2^e, 2^(e+1)) and A, b0 >= 0:
+//   * dk is a multiple M*u of the float spacing u = 2^(e-23); doubles in the same binade have spacing
+//     v = 2^(e-52) = u * 2^-29, and dk / v = M * 2^29 is an even integer;
+//   * RN53(dk + A) = dk + a*v with a = RNE(A / v): the tie rule sees the parity of dk/v + floor(A/v), i.e. of
+//     floor(A/v) alone;
+//   * RN53(dk + a*v + b0) = dk + (a + b)*v with b = RNE(b0 / v), where an exact tie of b0/v is broken towards an
+//     even a + b (the parity of the accumulated multiple, not of b);
+//   * RN24(dk + r*v) = dk + RNE(r / 2^29) * u, the same integer for every M -- unless r / 2^29 is an exact tie,
+//     in which case the result depends on the parity of M and the binade is marked unusable.
+// So inside the binade one organism adds a constant q0 (match) or q1 (mismatch) to the float's BIT PATTERN, and
+// a run of n organisms with p mismatches adds (n-p)*q0 + p*q1 -- an integer multiply-add and a popcount
+// instead of n dependent fma/add/cvt/cvt groups.  All intermediate sums are monotone (A, b0 >= 0), so if the
+// pattern after the run is still below the binade's end, every step of the run was inside the binade and the
+// identity holds step by step; the step that reaches or passes the end is redone with the reference's own
+// arithmetic.  Nothing here is approximate: tests/test_fastforward.py checks the table against step-by-step
+// float/double arithmetic on the CPU, tests/test_gpu_parity.py the kernels against the oracle.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define NEMFF_HD __host__ __device__
+#else
+#define NEMFF_HD
+#endif
+
+namespace nemk {
+
+// q value that makes a step "leave the binade" (pattern + 2^23 >= next exponent): forces exact stepping.
+// q0 and q1 are usable independently; all sums are taken modulo 2^32 and their true values stay below 2^32
+// (pattern < 2^31, at most 32 increments of at most 2^23), so q1 - q0 may wrap without harm.
+constexpr uint32_t kFFInvalid = 1u << 23;
+
+// Increments of the float bit pattern for exponent field E (value in [2^(E-127), 2^(E-126))).
+NEMFF_HD inline void ff_entry(double A, double b0, int E, uint32_t& q0, uint32_t& q1)
+{
+    q0 = q1 = kFFInvalid;
+    if (E < 1 || E > 253) return;                       // zero / denormals / top binade: always exact stepping
+    if (!(A >= 0.0) || !(b0 >= 0.0)) return;            // monotone chains only (also rejects NaN)
+    const int s = 179 - E;                              // x / v = x * 2^s
+    const double lim = 4503599627370496.0;              // 2^52: beyond it the increment is >= 2^23 anyway
+    const double xa = ldexp(A, s), xb = ldexp(b0, s);   // exact scalings (A, b0 are 0 or far from under/overflow)
+    if (!(xb < lim)) return;
+    const double fb = floor(xb);
+    const double frac = xb - fb;                        // exact (xb < 2^52)
+    const int64_t bfl = (int64_t)fb;
+    const int64_t half = (int64_t)1 << 28, mask = ((int64_t)1 << 29) - 1;
+    // match step: one rounding on the even base dk / v
+    const int64_t r0 = (frac > 0.5) ? bfl + 1 : (frac < 0.5) ? bfl : ((bfl & 1) ? bfl + 1 : bfl);
+    if ((r0 & mask) != half) {                          // (an exact float tie would depend on the parity of M)
+        const int64_t Q0 = (r0 + half) >> 29;
+        if (Q0 < (int64_t)kFFInvalid) q0 = (uint32_t)Q0;
+    }
+    // mismatch step: a = RNE(A / v) on the even base, then b0 on base dk/v + a (parity of a)
+    if (!(xa < lim)) return;
+    const int64_t ai = (int64_t)rint(xa);
+    const int64_t b1 = (frac > 0.5) ? bfl + 1 : (frac < 0.5) ? bfl : ((((ai + bfl) & 1) != 0) ? bfl + 1 : bfl);
+    const int64_t r1 = ai + b1;
+    if ((r1 & mask) != half) {
+        const int64_t Q1 = (r1 + half) >> 29;
+        if (Q1 < (int64_t)kFFInvalid) q1 = (uint32_t)Q1;
+    }
+}
+
+}  // namespace nemk

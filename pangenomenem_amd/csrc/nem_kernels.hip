@@ -14,6 +14,7 @@
 #include <cfloat>
 #include <cstdint>
 
+#include "nem_ff.hpp"
 #include "nem_kernels.hpp"
 
 namespace nemk {
@@ -163,7 +164,7 @@ __device__ inline void table_entry(const FinishArgs& a, int t)
 // (SURVEY.md §0-2).  grid = (ceil(n/256), K); the class's table slice is staged through LDS in
 // chunks of DCH organisms and read back as wave-uniform broadcasts.
 // ------------------------------------------------------------------------------------------
-constexpr int DCH = 2048;
+constexpr int DCH = 512;    // organisms per general-path table chunk (small: LDS per block bounds the occupancy)
 
 // XCD-aware tile mapping for the density kernels (1-D grid of ceil(tiles/8)*8*K blocks).  Blocks are dealt
 // round-robin over the 8 XCDs, so blocks b, b+8, b+16, ... share an XCD and its L2: the K class-blocks of one
@@ -191,20 +192,154 @@ __device__ inline float bern_step(float dk, uint32_t m, int b, double l1h, doubl
     return (float)(fma(f, l1h, (double)dk) - l0);
 }
 
+// The uniform chain of one (family, class) lane.  am0 / am1: mismatch masks of the class per 32-organism word.
+__device__ inline uint32_t word_of(const uint4& v, int c)
+{
+    return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+}
+
+// xw4: E1's matrix copy, uint4[W4][npad]: lane i reads words 4g .. 4g+3 of its family with one 16-byte load
+// (1 KB per wave and request), two groups ahead of the one being consumed.
+__device__ inline float chain_plain(const uint4* __restrict__ xw4, int npad, int i, int D,
+                                    const uint32_t* am0, const uint32_t* am1, double l1h, double l0)
+{
+    float dk = 0.0f;
+    const int wlast = (D - 1) >> 5;                      // padding organisms must not take a step here
+    const int glast = wlast >> 2;
+    uint4 xn = xw4[i];
+    for (int g = 0; g <= glast; g++) {
+        const uint4 xv = xn;
+        if (g < glast) xn = xw4[(size_t)(g + 1) * npad + i];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int w = 4 * g + c;
+            if (w > wlast) break;
+            const uint32_t x = word_of(xv, c);
+            const uint32_t m = (x & am1[w]) | (~x & am0[w]);
+            const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
+            if (nb == 32) {
+#pragma unroll
+                for (int b = 0; b < 32; b++) dk = bern_step(dk, m, b, l1h, l0);
+            } else {
+                for (int b = 0; b < nb; b++) dk = bern_step(dk, m, b, l1h, l0);
+            }
+        }
+    }
+    return dk;
+}
+
+// Same chain, fast-forwarded inside float binades (nem_ff.hpp): per 32-organism word ONE popcount and an integer
+// multiply-add on the accumulator's bit pattern; a lane whose accumulator would leave its binade inside the
+// word finds the last organism that still fits (5-step binary search over prefix popcounts), takes the
+// boundary step with the reference's own arithmetic, reloads the increments of the new binade and goes on.
+// sQ0 / sQ1: the class's 256-entry increment tables (LDS).  Bit-identical to chain_plain.
+constexpr int kFFPlainWords = 2;
+
+__device__ inline void ff_load(const uint32_t* sQ0, const uint32_t* sQ1, uint32_t bits, uint32_t& q0, uint32_t& dq,
+                               uint32_t& end)
+{
+    const uint32_t E = (bits >> 23) & 255u;
+    q0 = sQ0[E];
+    dq = sQ1[E] - q0;                                    // modulo 2^32 (nem_ff.hpp)
+    end = (E + 1u) << 23;
+}
+
+// one word (nb organisms, mismatch bits m) of the fast-forwarded chain
+__device__ inline void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& dq, uint32_t& end, uint32_t m, int nb,
+                               const uint32_t* sQ0, const uint32_t* sQ1, double l1h, double l0)
+{
+    const uint32_t cand = bits + (uint32_t)nb * q0 + (uint32_t)__popc(m) * dq;   // < 2^32: q <= 2^23, nb <= 32
+    const bool ok = cand < end;
+    if (ok) bits = cand;
+    if (__all(ok)) return;
+    if (!ok) {
+        uint32_t mm = m;
+        int rem = nb;
+        for (;;) {
+            int j = 0;                                   // organisms of this word that still fit in the binade
+#pragma unroll
+            for (int st = 16; st >= 1; st >>= 1) {
+                const int t = j + st;
+                const uint32_t f = bits + (uint32_t)t * q0 + (uint32_t)__popc(mm & ((1u << t) - 1u)) * dq;
+                if (f < end) j = t;                      // (f(t) >= f(rem) >= end for t >= rem: never accepted)
+            }
+            bits += (uint32_t)j * q0 + (uint32_t)__popc(mm & ((1u << j) - 1u)) * dq;
+            bits = __float_as_uint(bern_step(__uint_as_float(bits), mm, j, l1h, l0));
+            rem -= j + 1;
+            if (rem <= 0) break;
+            mm = mm >> (j + 1);                          // j + 1 <= 31 here
+            ff_load(sQ0, sQ1, bits, q0, dq, end);
+            const uint32_t c2 = bits + (uint32_t)rem * q0 + (uint32_t)__popc(mm) * dq;
+            if (c2 < end) { bits = c2; break; }
+        }
+        ff_load(sQ0, sQ1, bits, q0, dq, end);
+    }
+}
+
+__device__ inline float chain_ff(const uint4* __restrict__ xw4, int npad, int i, int D,
+                                 const uint32_t* am0, const uint32_t* am1, const uint32_t* sQ0, const uint32_t* sQ1,
+                                 double l1h, double l0)
+{
+    const int wlast = (D - 1) >> 5;
+    const int glast = wlast >> 2;
+    uint4 xa = xw4[i];
+    uint4 xb = make_uint4(0u, 0u, 0u, 0u);
+    if (glast >= 1) xb = xw4[(size_t)npad + i];
+    uint32_t bits = 0u;                                  // +0.0f (exponent field 0 is always stepped exactly)
+    uint32_t q0, dq, end;
+    ff_load(sQ0, sQ1, bits, q0, dq, end);
+    for (int g = 0; g <= glast; g++) {
+        const uint4 xv = xa;
+        xa = xb;
+        if (g + 2 <= glast) xb = xw4[(size_t)(g + 2) * npad + i];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int w = 4 * g + c;
+            if (w > wlast) break;
+            const uint32_t x = word_of(xv, c);
+            uint32_t m = (x & am1[w]) | (~x & am0[w]);
+            if (c < kFFPlainWords && g == 0 && w < wlast) {
+                // the first organisms run through small binades (a crossing every few steps): stepping is cheaper
+                float dk0 = __uint_as_float(bits);
+#pragma unroll
+                for (int b = 0; b < 32; b++) dk0 = bern_step(dk0, m, b, l1h, l0);
+                bits = __float_as_uint(dk0);
+                ff_load(sQ0, sQ1, bits, q0, dq, end);
+                continue;
+            }
+            const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
+            if (nb < 32) m &= (1u << nb) - 1u;
+            ff_word(bits, q0, dq, end, m, nb, sQ0, sQ1, l1h, l0);
+        }
+    }
+    return __uint_as_float(bits);
+}
+
+// the class's increment tables, one exponent per thread of a 256-thread block (caller synchronises)
+__device__ inline void ff_build(uint32_t* sQ0, uint32_t* sQ1, double l1, double l0, int tid)
+{
+    uint32_t q0, q1;
+    ff_entry(l1, -l0, tid, q0, q1);
+    sQ0[tid] = q0; sQ1[tid] = q1;
+}
+
 struct DensityArgs {
-    const uint32_t* xw; int n, npad, dpad, D, K;
+    const uint4* xw; int n, npad, dpad, D, K;
     const double2* tabT; const double* tabL0; const uint32_t* nz0; const uint32_t* nz1;
     const uint32_t* am0; const uint32_t* am1; const double2* uni; const int* nonuni;
     const double* pk; const float* logpk;
     double* pkfki; float* logpkfki;
     int* zero_flags; int n_zero_flags;
     const int* stop;
+    int use_ff;
+    const int* perm;
 };
 
 __global__ __launch_bounds__(256) void k_density(DensityArgs a)
 {
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
+    __shared__ uint32_t sQ0[256], sQ1[256];
     if (a.stop != nullptr && *a.stop) return;
     int k, tile;
     if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
@@ -221,23 +356,14 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
     if (a.nonuni[k] == 0) {
         // ---- uniform dispersion in this class (sk_, s__, the default .m): the step constants are two
         // wave-uniform doubles; which organisms mismatch comes from two bit masks per word.
-        // (An exact "fast-forward" of whole runs of steps inside one float binade -- integer adds on the
-        // bit pattern + popcounts -- was built and is bit-identical, but lane divergence at the binade
-        // crossings made it slower than this plain chain at D = 500)
-        const double l1h = 0.5 * a.uni[k].x, l0 = a.uni[k].y;    // l1 is 0 or a normal double: halving is exact
-        const int wlast = (a.D - 1) >> 5;                // padding organisms must not take a step here
-        uint32_t xnext = a.xw[i];
-        for (int w = 0; w <= wlast; w++) {
-            const uint32_t x = xnext;
-            if (w < wlast) xnext = a.xw[(size_t)(w + 1) * npad + i];
-            const uint32_t m = (x & a.am1[k * W + w]) | (~x & a.am0[k * W + w]);
-            const int nb = (w < wlast) ? 32 : (a.D - (wlast << 5));
-            if (nb == 32) {
-#pragma unroll
-                for (int b = 0; b < 32; b++) dk = bern_step(dk, m, b, l1h, l0);
-            } else {
-                for (int b = 0; b < nb; b++) dk = bern_step(dk, m, b, l1h, l0);
-            }
+        const double l1 = a.uni[k].x, l0 = a.uni[k].y;
+        const double l1h = 0.5 * l1;                     // l1 is 0 or a normal double: halving is exact
+        if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
+            ff_build(sQ0, sQ1, l1, l0, tid);
+            __syncthreads();
+            dk = chain_ff(a.xw, npad, i, a.D, a.am0 + k * W, a.am1 + k * W, sQ0, sQ1, l1h, l0);
+        } else {
+            dk = chain_plain(a.xw, npad, i, a.D, a.am0 + k * W, a.am1 + k * W, l1h, l0);
         }
     } else {
         // ---- general case (skd, s_d, hand-written .m files): per-(k,d) constants staged through LDS
@@ -249,18 +375,25 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
                 sL[t] = a.tabL0[(size_t)k * dpad + d0 + t];
             }
             __syncthreads();
-            const int w0 = d0 >> 5, wn = dn >> 5;
-            uint32_t xnext = a.xw[(size_t)w0 * npad + i];
-            for (int w = 0; w < wn; w++) {
-                const uint32_t x = xnext;
-                if (w + 1 < wn) xnext = a.xw[(size_t)(w0 + w + 1) * npad + i];
-                nul |= (x & a.nz1[k * W + w0 + w]) | (~x & a.nz0[k * W + w0 + w]);
+            const int w0 = d0 >> 5, wn = dn >> 5;        // DCH = 16 words: chunks start on a 4-word group
+            const int g0 = w0 >> 2, gn = (wn + 3) >> 2;
+            uint4 xnext = a.xw[(size_t)g0 * npad + i];
+            for (int g = 0; g < gn; g++) {
+                const uint4 xv = xnext;
+                if (g + 1 < gn) xnext = a.xw[(size_t)(g0 + g + 1) * npad + i];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int w = 4 * g + c;
+                    if (w >= wn) break;
+                    const uint32_t x = word_of(xv, c);
+                    nul |= (x & a.nz1[k * W + w0 + w]) | (~x & a.nz0[k * W + w0 + w]);
 #pragma unroll 8
-                for (int b = 0; b < 32; b++) {
-                    const double2 tt = sT[w * 32 + b];
-                    const double l0 = sL[w * 32 + b];
-                    const double add = ((x >> b) & 1u) ? tt.y : tt.x;
-                    dk = (float)(((double)dk + add) - l0);       // nem_mod.c:661
+                    for (int b = 0; b < 32; b++) {
+                        const double2 tt = sT[w * 32 + b];
+                        const double l0 = sL[w * 32 + b];
+                        const double add = ((x >> b) & 1u) ? tt.y : tt.x;
+                        dk = (float)(((double)dk + add) - l0);   // nem_mod.c:661
+                    }
                 }
             }
         }
@@ -269,8 +402,9 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         float logfk; double fk;
         if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
         else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
-        a.pkfki[(size_t)k * npad + i] = a.pk[k] * fk;            // nem_alg.c:2282
-        a.logpkfki[(size_t)k * npad + i] = a.logpk[k] + logfk;   // nem_alg.c:2283
+        const int io = a.perm[i];                                // lane i ran family perm[i]
+        a.pkfki[(size_t)k * npad + io] = a.pk[k] * fk;           // nem_alg.c:2282
+        a.logpkfki[(size_t)k * npad + io] = a.logpk[k] + logfk;  // nem_alg.c:2283
     }
 }
 
@@ -283,16 +417,18 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
 // centre / dispersion / proportion / size; block (0, 0) the empty-class flag.
 // ------------------------------------------------------------------------------------------
 constexpr int FD_MAXD = kFusedMaxD; // organisms the fused kernel supports (iner/eps staged in LDS as floats)
-constexpr int FD_CH = 1024;       // organisms per general-path table chunk
+constexpr int FD_CH = 256;        // organisms per general-path table chunk
 
 struct FusedDensityArgs {
-    const uint32_t* xw; int n, npad, dpad, D, K, n_total, disper, propor;
+    const uint4* xw; int n, npad, dpad, D, K, n_total, disper, propor;
     const int* stats;
     float* center; float* disp; float* prop; float* nbobs_k;
     int* iter_flags;
     double* pkfki; float* logpkfki;
     int* zero_flags; int n_zero_flags;
     const int* stop;
+    int use_ff;
+    const int* perm;
 };
 
 __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
@@ -301,6 +437,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     __shared__ double2 sT[FD_CH];
     __shared__ double sL[FD_CH];
     __shared__ uint32_t sAm0[FD_MAXD / 32], sAm1[FD_MAXD / 32], sNz0[FD_CH / 32], sNz1[FD_CH / 32];
+    __shared__ uint32_t sQ0[256], sQ1[256];
     __shared__ unsigned long long sTot2;
     __shared__ float sEps;
     __shared__ int sGeneral;
@@ -415,19 +552,12 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     }
     if (uniform) {
         const double l1h = 0.5 * l1;                     // l1 is 0 or a normal double: halving is exact
-        const int wlast = (D - 1) >> 5;
-        uint32_t xnext = a.xw[i];
-        for (int w = 0; w <= wlast; w++) {
-            const uint32_t x = xnext;
-            if (w < wlast) xnext = a.xw[(size_t)(w + 1) * npad + i];
-            const uint32_t m = (x & sAm1[w]) | (~x & sAm0[w]);
-            const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
-            if (nb == 32) {
-#pragma unroll
-                for (int b = 0; b < 32; b++) dk = bern_step(dk, m, b, l1h, l0);
-            } else {
-                for (int b = 0; b < nb; b++) dk = bern_step(dk, m, b, l1h, l0);
-            }
+        if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
+            ff_build(sQ0, sQ1, l1, l0, tid);
+            __syncthreads();
+            dk = chain_ff(a.xw, npad, i, D, sAm0, sAm1, sQ0, sQ1, l1h, l0);
+        } else {
+            dk = chain_plain(a.xw, npad, i, D, sAm0, sAm1, l1h, l0);
         }
     } else {
         // general chain: per-organism constants built chunk by chunk in LDS (table_entry's arithmetic)
@@ -459,18 +589,25 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
                 }
             }
             __syncthreads();
-            const int w0 = d0 >> 5, wn = dn >> 5;
-            uint32_t xnext = a.xw[(size_t)w0 * npad + i];
-            for (int w = 0; w < wn; w++) {
-                const uint32_t x = xnext;
-                if (w + 1 < wn) xnext = a.xw[(size_t)(w0 + w + 1) * npad + i];
-                nul |= (x & sNz1[w]) | (~x & sNz0[w]);
+            const int w0 = d0 >> 5, wn = dn >> 5;        // FD_CH = 8 words: chunks start on a 4-word group
+            const int g0 = w0 >> 2, gn = (wn + 3) >> 2;
+            uint4 xnext = a.xw[(size_t)g0 * npad + i];
+            for (int g = 0; g < gn; g++) {
+                const uint4 xv = xnext;
+                if (g + 1 < gn) xnext = a.xw[(size_t)(g0 + g + 1) * npad + i];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int w = 4 * g + c;
+                    if (w >= wn) break;
+                    const uint32_t x = word_of(xv, c);
+                    nul |= (x & sNz1[w]) | (~x & sNz0[w]);
 #pragma unroll 8
-                for (int b = 0; b < 32; b++) {
-                    const double2 tt = sT[w * 32 + b];
-                    const double c0 = sL[w * 32 + b];
-                    const double add = ((x >> b) & 1u) ? tt.y : tt.x;
-                    dk = (float)(((double)dk + add) - c0);       // nem_mod.c:661
+                    for (int b = 0; b < 32; b++) {
+                        const double2 tt = sT[w * 32 + b];
+                        const double c0 = sL[w * 32 + b];
+                        const double add = ((x >> b) & 1u) ? tt.y : tt.x;
+                        dk = (float)(((double)dk + add) - c0);   // nem_mod.c:661
+                    }
                 }
             }
         }
@@ -479,8 +616,9 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         float logfk; double fk;
         if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
         else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
-        a.pkfki[(size_t)k * npad + i] = pkd * fk;                // nem_alg.c:2282
-        a.logpkfki[(size_t)k * npad + i] = logpk + logfk;        // nem_alg.c:2283
+        const int io = a.perm[i];                                // lane i ran family perm[i]
+        a.pkfki[(size_t)k * npad + io] = pkd * fk;               // nem_alg.c:2282
+        a.logpkfki[(size_t)k * npad + io] = logpk + logfk;       // nem_alg.c:2283
     }
 }
 
@@ -488,10 +626,11 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
                           int* zero_flags, int n_zero_flags, hipStream_t s)
 {
     FusedDensityArgs a;
-    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
+    a.xw = (const uint4*)xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
     a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
     a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
+    a.use_ff = t.use_ff; a.perm = t.perm;
     hipLaunchKernelGGL(k_density_fused, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
 }
 
@@ -1209,10 +1348,24 @@ __global__ __launch_bounds__(256) void k_crit_reduce(int n, int K, float beta, c
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
+// same, lane i <- family perm[i] (E1's sorted copy)
+__global__ void k_layout_words_perm(const uint32_t* __restrict__ xf, const int* __restrict__ perm, int n, int wf, int W,
+                                    int npad, uint32_t* __restrict__ xws)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = blockIdx.y;
+    if (i >= npad) return;
+    uint32_t v = 0;
+    if (i < n && w < wf) v = xf[(size_t)perm[i] * wf + w];
+    xws[((size_t)(w >> 2) * npad + i) * 4 + (w & 3)] = v;          // uint4[W4][npad]: words 4g..4g+3 of lane i together
+}
+
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
-                   hipStream_t s)
+                   const int* perm, uint32_t* xws, hipStream_t s)
 {
     hipLaunchKernelGGL(k_layout_words, dim3((npad + 255) / 256, W), dim3(256), 0, s, xf, n, wf, W, npad, xw);
+    hipLaunchKernelGGL(k_layout_words_perm, dim3((npad + 255) / 256, ((W + 3) / 4) * 4), dim3(256), 0, s, xf, perm, n, wf,
+                       W, npad, xws);
     hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
 }
 
@@ -1222,11 +1375,11 @@ void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, do
                     int* zero_flags, int n_zero_flags, hipStream_t s)
 {
     DensityArgs a;
-    a.xw = xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K;
+    a.xw = (const uint4*)xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K;
     a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
     a.uni = t.uni; a.nonuni = t.nonuni; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
-    a.stop = t.stop;
+    a.stop = t.stop; a.use_ff = t.use_ff; a.perm = t.perm;
     hipLaunchKernelGGL(k_density, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
 }
 

@@ -57,7 +57,7 @@ void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new
 
 
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
-                   hipStream_t s);
+                   const int* perm, uint32_t* xws, hipStream_t s);
 // parameter update + density tables (k_finish); also carries the table pointers k_density reads
 struct FinishArgs {
     int mode;                      // 0: tables only; 1: NCEM centres from counts + dispersion + tables; 2: dispersion + tables
@@ -68,6 +68,8 @@ struct FinishArgs {
     uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni;
     double* pk; float* logpk; int* flags;
     const int* stop;
+    const int* perm;               // density kernels: lane i of the (sorted) matrix copy is family perm[i]
+    int use_ff;                    // density kernels: fast-forward the uniform chain inside float binades (nem_ff.hpp)
 };
 void launch_finish(const FinishArgs& a, hipStream_t s);
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,

@@ -75,6 +75,8 @@ def load_library():
     lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), ip]
     lib.nemgpu_calibrate_fetch.argtypes = [C.c_size_t, C.c_int]
     lib.nemgpu_set_stream.argtypes = [vp, vp]
+    lib.nemgpu_set_fast_forward.argtypes = [vp, C.c_int]
+    lib.nemgpu_ff_table.argtypes = [C.c_double, C.c_double, vp, vp]
     lib.nemgpu_shard_end_enqueue.argtypes = [vp]
     lib.nemgpu_stats_words.argtypes = [vp]
     lib.nemgpu_shard_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -305,6 +307,10 @@ class NemEngine:
         return dict(density_ms_avg=ms.value, density_launches=int(reps), algorithmic_bytes_per_launch=b.value,
                     kernel="k_density_fused" if fused.value else "k_density")
 
+    def set_fast_forward(self, mode):
+        """E1 binade fast-forward: 1 always, 0 never, -1 automatic (default); results are bit-identical."""
+        self._chk(self.lib.nemgpu_set_fast_forward(self._h, int(mode)))
+
     def set_stream(self, stream_ptr):
         self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
 
@@ -316,11 +322,13 @@ def calibrate_fetch(nbytes=1 << 30, reps=3):
         raise NemGpuError("nemgpu_calibrate_fetch failed (status %d)" % rc)
 
 
-def solve(x, nei, k, prop, center, disp, device=0, **cfg):
+def solve(x, nei, k, prop, center, disp, device=0, fast_forward=None, **cfg):
     """Convenience: build an engine, run the whole EM, return full-precision results."""
     n, d = x.shape
     eng = NemEngine(n, d, k, device=device)
     try:
+        if fast_forward is not None:
+            eng.set_fast_forward(fast_forward)
         eng.set_matrix(x)
         eng.set_graph(nei)
         eng.set_params(prop, center, disp)

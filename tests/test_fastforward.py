@@ -1,0 +1,190 @@
+"""CPU checks of the E1 fast-forward arithmetic (pangenomenem_amd/csrc/nem_ff.hpp).
+
+The increment tables come from the product library's host-only entry ``nemgpu_ff_table`` (no GPU needed);
+the ground truth is the reference's own step  dk = (float)(((double)dk + |x-mu|*L1) - L0)  (nem_mod.c:661)
+evaluated with numpy float32 / float64 scalars (IEEE round-to-nearest-even, no contraction).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from pangenomenem_amd.engine import load_library
+
+INVALID = 1 << 23
+
+
+def ff_table(l1, l0):
+    lib = load_library()
+    lib.nemgpu_ff_table.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_uint32),
+                                    ctypes.POINTER(ctypes.c_uint32)]
+    lib.nemgpu_ff_table.restype = ctypes.c_int
+    q0 = np.zeros(256, np.uint32)
+    q1 = np.zeros(256, np.uint32)
+    rc = lib.nemgpu_ff_table(l1, l0, q0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                             q1.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    assert rc == 0
+    return q0, q1
+
+
+def class_constants(eps):
+    """L1, L0 as table_entry / DensBernoulli form them from a float dispersion."""
+    eps = np.float32(eps)
+    l1 = np.log(np.float64(np.float32(np.float32(1.0) - eps) / eps))
+    l0 = np.log(np.float64(np.float32(np.float32(1.0) - eps)))
+    return float(l1), float(l0)
+
+
+def exact_step(bits, mismatch, l1, l0):
+    """vectorised reference step on float bit patterns (uint32 array) -> uint32 array"""
+    dk = bits.view(np.float32).astype(np.float64)
+    if mismatch:
+        s1 = dk + np.float64(1.0) * np.float64(l1)
+    else:
+        s1 = dk + np.float64(0.0) * np.float64(l1)
+    s2 = s1 - np.float64(l0)
+    return s2.astype(np.float32).view(np.uint32)
+
+
+def check_table(l1, l0, rng, per_binade=4000):
+    q0, q1 = ff_table(l1, l0)
+    checked = 0
+    for E in range(1, 254):
+        if q0[E] == INVALID and q1[E] == INVALID:
+            continue
+        lo, end = np.uint32(E << 23), np.uint32((E + 1) << 23)
+        m = rng.integers(0, 1 << 23, size=per_binade, dtype=np.uint32)
+        m[:4] = [0, 1, 2, 3]
+        m[4:8] = [(1 << 23) - 1, (1 << 23) - 2, (1 << 22), (1 << 22) + 1]
+        bits = (lo + m).astype(np.uint32)
+        for mism, q in ((False, q0[E]), (True, q1[E])):
+            if q == INVALID:
+                continue
+            fast = bits.astype(np.uint64) + np.uint64(q)
+            inside = fast < np.uint64(end)
+            if not inside.any():
+                continue
+            ex = exact_step(bits[inside], mism, l1, l0)
+            assert np.array_equal(ex.astype(np.uint64), fast[inside]), (E, mism, l1, l0)
+            checked += int(inside.sum())
+    return checked, q0, q1
+
+
+@pytest.mark.parametrize("eps", [0.1, 0.5, 0.03, 0.25, 1e-3, 1e-6, 0.4999, 0.3333333, 0.0123456, 0.2, 0.05])
+def test_increments_match_exact_stepping(eps):
+    rng = np.random.default_rng(int(eps * 1e9) % (2 ** 31))
+    l1, l0 = class_constants(eps)
+    checked, q0, q1 = check_table(l1, l0, rng)
+    assert checked > 100000
+    # the binades a real chain lives in (0.06 .. 10^4) must be usable, otherwise fast-forward is pointless
+    usable = [E for E in range(133, 142) if q0[E] != INVALID and q1[E] != INVALID]
+    assert len(usable) >= 8
+
+
+def test_random_dispersions():
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        eps = np.float32(rng.uniform(1e-4, 0.5))
+        l1, l0 = class_constants(eps)
+        check_table(l1, l0, rng, per_binade=600)
+
+
+def test_rejects_non_monotone_chains():
+    # eps > 0.5 makes L1 negative: no fast-forward at all (the kernels take the plain chain)
+    l1, l0 = class_constants(0.7)
+    assert l1 < 0
+    q0, q1 = ff_table(l1, l0)
+    assert (q0 == INVALID).all() and (q1 == INVALID).all()
+    q0, q1 = ff_table(float("nan"), -0.1)
+    assert (q0 == INVALID).all()
+
+
+def test_crafted_double_rounding_ties():
+    """Constants sitting exactly on rounding ties of the double adds (b0/v = n + 1/2) with even and odd a:
+    the tie must be broken by the parity of the accumulated multiple, as RN53 does."""
+    rng = np.random.default_rng(11)
+    for E in (125, 128, 130, 133):
+        v = 2.0 ** (E - 179)
+        for n_b in (12345678901, 12345678902, (1 << 40) + 1, (1 << 40) + 2):
+            b0 = (n_b + 0.5) * v                      # exact tie of the second add at this binade
+            for n_a in (987654321, 987654322):        # even / odd first multiple
+                for a_frac in (0.0, 0.5, 0.25):
+                    A = (n_a + a_frac) * v
+                    checked, q0, q1 = check_table(A, -b0, rng, per_binade=300)
+                    assert checked > 0
+
+
+def test_float_tie_marks_binade_unusable():
+    # r = (q + 1/2) * 2^29 exactly: the float rounding would depend on the parity of the accumulator
+    E = 130
+    v = 2.0 ** (E - 179)
+    b0 = (5 * (1 << 29) + (1 << 28)) * v
+    q0, q1 = ff_table(0.0, -b0)
+    assert q0[E] == INVALID and q1[E] == INVALID
+    assert q0[E + 1] != INVALID                      # the neighbouring binade is a plain (non-tie) case
+
+
+def emulate_chain_ff(m_words, D, l1, l0, q0, q1):
+    """Python transcription of chain_ff's control flow (one lane)."""
+    def step(bits, mism):
+        return int(exact_step(np.array([bits], np.uint32), bool(mism), l1, l0)[0])
+
+    def load(bits):
+        E = (bits >> 23) & 255
+        return int(q0[E]), int(q1[E]) - int(q0[E]), (E + 1) << 23     # (the kernel's unsigned wrap == this signed value)
+
+    bits = 0
+    a, dq, end = load(bits)
+    wlast = (D - 1) >> 5
+    slow = 0
+    for w in range(wlast + 1):
+        m = int(m_words[w])
+        nb = 32 if w < wlast else D - (wlast << 5)
+        if nb < 32:
+            m &= (1 << nb) - 1
+        cand = bits + nb * a + bin(m).count("1") * dq
+        if cand < end:
+            bits = cand
+            continue
+        mm, rem = m, nb
+        while True:
+            j = 0
+            for st in (16, 8, 4, 2, 1):
+                t = j + st
+                f = bits + t * a + bin(mm & ((1 << t) - 1)).count("1") * dq
+                if f < end:
+                    j = t
+            bits += j * a + bin(mm & ((1 << j) - 1)).count("1") * dq
+            bits = step(bits, (mm >> j) & 1)
+            slow += 1
+            rem -= j + 1
+            if rem <= 0:
+                break
+            mm >>= j + 1
+            a, dq, end = load(bits)
+            c2 = bits + rem * a + bin(mm).count("1") * dq
+            if c2 < end:
+                bits = c2
+                break
+        a, dq, end = load(bits)
+    return bits, slow
+
+
+@pytest.mark.parametrize("eps,p_mismatch,D", [(0.1, 0.03, 700), (0.1, 0.9, 333), (0.5, 0.5, 200), (0.02, 0.5, 1000),
+                                                (1e-5, 0.01, 500), (0.3, 0.3, 97)])
+def test_whole_chain_control_flow(eps, p_mismatch, D):
+    rng = np.random.default_rng(D)
+    l1, l0 = class_constants(eps)
+    q0, q1 = ff_table(l1, l0)
+    W = (D + 31) // 32
+    for _ in range(6):
+        mism = rng.random(D) < p_mismatch
+        words = np.zeros(W, np.uint64)
+        for d in np.flatnonzero(mism):
+            words[d >> 5] |= np.uint64(1) << np.uint64(d & 31)
+        bits = np.zeros(1, np.uint32)
+        for d in range(D):
+            bits = exact_step(bits, bool(mism[d]), l1, l0)
+        got, slow = emulate_chain_ff(words, D, l1, l0, q0, q1)
+        assert got == int(bits[0])
+        assert slow < D // 2 + 40                     # it really fast-forwards

@@ -58,12 +58,52 @@ def test_density_uniform_dispersion_fast_forward(gpu_lib, oracle, n, d, seed):
         center[0] = 1.0
         disp = np.repeat(eps[:, None], d, axis=1)
         prop = np.full(k, 1.0 / k, np.float32)
-        eng = make_engine(x, None, k, prop, center, disp)
-        pk, lp = eng.density()
         opk, olp, _ = oracle.density(x, prop, center, disp)
-        assert bits_equal(lp, olp), (trial, eps)
-        assert ulp_diff64(pk, opk) <= 2
-        eng.close()
+        for mode in (1, 0):                           # fast-forward forced on / plain stepping
+            eng = make_engine(x, None, k, prop, center, disp)
+            eng.set_fast_forward(mode)
+            pk, lp = eng.density()
+            assert bits_equal(lp, olp), (trial, mode, eps)
+            assert ulp_diff64(pk, opk) <= 2
+            eng.close()
+
+
+def test_density_fast_forward_falls_back_for_dispersions_above_half(gpu_lib, oracle):
+    """eps > 1/2 makes log((1-eps)/eps) negative: the chain is no longer monotone, the kernel must step it."""
+    n, d = 600, 900
+    x, _ = synth.bernoulli_pa_matrix(n, d, 21)
+    eps = np.array([0.7, 0.1, 0.9999], np.float32)
+    center = np.stack([np.ones(d), np.zeros(d), np.full(d, 0.5)]).astype(np.float32)
+    disp = np.repeat(eps[:, None], d, axis=1)
+    prop = np.full(3, 1.0 / 3, np.float32)
+    opk, olp, _ = oracle.density(x, prop, center, disp)
+    eng = make_engine(x, None, 3, prop, center, disp)
+    eng.set_fast_forward(1)
+    pk, lp = eng.density()
+    assert bits_equal(lp, olp)
+    assert ulp_diff64(pk, opk) <= 2
+    eng.close()
+
+
+@pytest.mark.parametrize("algo,disper", [("ncem", "sk_"), ("nem", "sk_"), ("ncem", "s__")])
+def test_full_run_with_fast_forward_forced(gpu_lib, oracle, algo, disper):
+    """Whole EM with the fast-forwarded E1 (the automatic mode would step a problem this small)."""
+    from pangenomenem_amd.engine import solve
+    n, d = 3000, 420
+    x, _ = synth.bernoulli_pa_matrix(n, d, 33)
+    nei = synth.contiguity_graph(n, 33)
+    prop, center, disp = synth.default_init(d)
+    cfg = dict(algo=algo, beta=0.5, disper=disper, propor="pk", it_max=12, tie="hash", seed=5)
+    ref = oracle.run(x, nei, 3, prop, center, disp, **cfg)
+    for mode in (1, 0):
+        got = solve(x, nei, 3, prop, center, disp, fast_forward=mode, **cfg)
+        assert got["iters"] == ref["iters"]
+        if algo == "ncem":
+            assert np.array_equal(got["c"], ref["c"])
+        else:
+            assert maxdiff(got["c"], ref["c"]) <= TOL
+        assert maxdiff(got["disp"], ref["disp"]) <= TOL and maxdiff(got["prop"], ref["prop"]) <= TOL
+        assert bits_equal(got["center"], ref["center"])
 
 
 def test_density_null_dispersion_and_half_centres(gpu_lib, oracle):
