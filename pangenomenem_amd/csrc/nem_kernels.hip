@@ -978,27 +978,19 @@ __device__ inline void centers_ncem_entry(int K, int D, const int* __restrict__ 
 // M4/M5: dispersion model + proportions (InerToDisp*, nem_mod.c:965-1174; EstimPara :456-465).
 // MissMode is MISSING_IGNORE for Bernoulli (nem_mod.c:446-448) and N_KD[k][d] == N_K[k] (no NaN).
 // The d- / k-ordered float sums are order-dependent (values exceed 2^24) and stay sequential.
-__device__ inline void seq_sum_pair(const float4* __restrict__ v4, int n4, float nk, float& sn, float& si)
-{
-    // d-ordered float accumulators (InerToDispK_, nem_mod.c:1054-1058); padding entries are -0.0f / handled by caller
-#pragma unroll 4
-    for (int t = 0; t < n4; t++) {
-        const float4 v = v4[t];
-        si = (((si + v.x) + v.y) + v.z) + v.w;
-        sn = (((sn + nk) + nk) + nk) + nk;
-    }
-}
-
 // `exact_half_ints`: the inertia values are non-negative multiples of 1/2 and N_K is an integer (NCEM).
 // Then a d-ordered float chain whose total stays below 2^24 half-units never rounds, and equals the
 // closed form; only larger totals (e.g. 50 000 x 1 000) take the sequential chain.
 __device__ inline void disp_body(int K, int D, int n_total, int disper, int propor, int exact_half_ints,
                                  const float* __restrict__ nbobs_k, const float* __restrict__ iner,
-                                 float* __restrict__ disp, float* __restrict__ prop, int* __restrict__ flags)
+                                 float* __restrict__ disp, float* __restrict__ prop, int* __restrict__ flags,
+                                 int kb, int ke)
 {
-    constexpr int CAP = 12288;                           // staged inertia values (48 KB)
+    // classes [kb, ke) are this block's (one block per class for the class-separable models sk_ / skd,
+    // all classes in one block for s__ / s_d)
+    constexpr int CAP = 16000;                           // staged inertia values (64 000 B)
     __shared__ float4 s_in4[CAP / 4];
-    __shared__ float s_disp[kMaxKernelK];
+    __shared__ float s_disp[kMaxKernelK], s_si[kMaxKernelK], s_sn[kMaxKernelK];
     __shared__ int s_valid[kMaxKernelK];
     __shared__ float s_vol;
     float* s_in = reinterpret_cast<float*>(s_in4);
@@ -1010,14 +1002,14 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
         if (tid < K) { s_tot2[tid] = 0ull; s_seq[tid] = 1; s_valid[tid] = 0; }
         __syncthreads();
         if (exact_half_ints) {
-            for (int k = 0; k < K; k++) {
+            for (int k = kb; k < ke; k++) {
                 long long acc = 0;
                 for (int d = tid; d < D; d += 1024) acc += (long long)(2.0f * iner[k * D + d]);
                 acc = wave_reduce_add_ll(acc);
                 if ((tid & 63) == 0 && acc != 0) atomicAdd(&s_tot2[k], (unsigned long long)acc);
             }
             __syncthreads();
-            if (tid < K) {
+            if (tid >= kb && tid < ke) {
                 const float nk = nbobs_k[tid];
                 const long long cap = 1ll << 24;
                 if ((long long)s_tot2[tid] <= cap && (long long)nk * (long long)D <= cap) {
@@ -1029,41 +1021,57 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
             __syncthreads();
         }
         bool any_seq = false;
-        for (int k = 0; k < K; k++) any_seq |= (s_seq[k] != 0);
-        // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains.  Classes run on
-        // different waves; a class's D values are staged in LDS (D4 = D rounded down to 4, tail scalar).
-        const int dq = D & ~3;
-        const int per = max(1, min(K, CAP / max(D, 1)));          // classes staged per pass
+        for (int k = kb; k < ke; k++) any_seq |= (s_seq[k] != 0);
+        // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains (InerToDispK_,
+        // nem_mod.c:1054-1058).  Every chain gets a wave of its own (lane 0): the class's D inertia values are
+        // staged in LDS, the N_KD chain adds a constant and needs no memory at all.
+        const int Dp = (D + 3) & ~3;
+        const int per = max(1, min(ke - kb, CAP / max(Dp, 1)));    // classes staged per pass
         if (!any_seq) {
             // nothing left for the sequential chains
-        } else if (per >= 1 && D <= CAP) {
-            for (int k0 = 0; k0 < K; k0 += per) {
-                const int kn = min(per, K - k0);
+        } else if (Dp <= CAP) {
+            for (int k0 = kb; k0 < ke; k0 += per) {
+                const int kn = min(per, ke - k0);
                 __syncthreads();
-                for (int t = tid; t < kn * D; t += 1024) {
-                    const int kk = t / D, d = t - kk * D;
-                    s_in[kk * ((D + 3) & ~3) + d] = iner[(k0 + kk) * D + d];
-                }
+                for (int kk = 0; kk < kn; kk++)
+                    for (int d = tid; d < D; d += 1024) s_in[kk * Dp + d] = iner[(k0 + kk) * D + d];
                 __syncthreads();
-                const int wv = tid >> 6;
                 if ((tid & 63) == 0) {
-                    for (int kk = wv; kk < kn; kk += 16) {
-                        const int k = k0 + kk;
+                    for (int c = tid >> 6; c < 2 * kn; c += 16) {
+                        const int kk = c >> 1, k = k0 + kk;
                         if (!s_seq[k]) continue;
                         const float nk = nbobs_k[k];
-                        s_valid[k] = (nk > 0);
-                        if (nk > 0) {
-                            float sn = 0.0f, si = 0.0f;
-                            const float* base = s_in + kk * ((D + 3) & ~3);
-                            seq_sum_pair(reinterpret_cast<const float4*>(base), dq >> 2, nk, sn, si);
-                            for (int d = dq; d < D; d++) { sn += nk; si += base[d]; }
-                            s_disp[k] = si / sn;
+                        if (!(nk > 0)) continue;
+                        if (c & 1) {
+                            float sn = 0.0f;
+#pragma unroll 8
+                            for (int d = 0; d < D; d++) sn += nk;
+                            s_sn[k] = sn;
+                        } else {
+                            float si = 0.0f;
+                            const float* base = s_in + kk * Dp;
+                            const float4* b4 = reinterpret_cast<const float4*>(base);
+                            const int dq = D & ~3;
+#pragma unroll 8
+                            for (int t = 0; t < (dq >> 2); t++) {
+                                const float4 v = b4[t];
+                                si = (((si + v.x) + v.y) + v.z) + v.w;
+                            }
+                            for (int d = dq; d < D; d++) si += base[d];
+                            s_si[k] = si;
                         }
                     }
                 }
+                __syncthreads();
+                if (tid < kn && s_seq[k0 + tid]) {
+                    const int k = k0 + tid;
+                    const float nk = nbobs_k[k];
+                    s_valid[k] = (nk > 0);
+                    if (nk > 0) s_disp[k] = s_si[k] / s_sn[k];
+                }
             }
         } else {                                                   // very wide matrices: straight from global
-            if (tid < K && s_seq[tid]) {
+            if (tid >= kb && tid < ke && s_seq[tid]) {
                 const int k = tid;
                 const float nk = nbobs_k[k];
                 s_valid[k] = (nk > 0);
@@ -1075,7 +1083,7 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
             }
         }
         __syncthreads();
-        for (int t = tid; t < K * D; t += 1024) {
+        for (int t = kb * D + tid; t < ke * D; t += 1024) {
             const int k = t / D;
             if (s_valid[k]) disp[t] = s_disp[k];
         }
@@ -1102,16 +1110,16 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
             for (int k = 0; k < K; k++) disp[k * D + d] = dd;
         }
     } else {
-        for (int t = tid; t < K * D; t += 1024) {
+        for (int t = kb * D + tid; t < ke * D; t += 1024) {
             const int k = t / D;
             if ((double)nbobs_k[k] > kEpsilonD) disp[t] = iner[t] / nbobs_k[k];
         }
     }
-    if (tid < K) {
+    if (tid >= kb && tid < ke) {
         if (propor == NEMGPU_PROP_K) prop[tid] = nbobs_k[tid] / (float)n_total;
         else prop[tid] = (float)(1.0 / K);
     }
-    if (tid == 0) {                                      // EstimLaplaceCenters :1404-1408
+    if (tid == 0 && kb == 0) {                           // EstimLaplaceCenters :1404-1408
         int ek = 0;
         for (int k = 0; k < K; k++) if (!((double)nbobs_k[k] > kEpsilonD)) ek = k + 1;
         flags[FLAG_EMPTYK] = ek;
@@ -1126,19 +1134,25 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
 {
     if (a.stop != nullptr && *a.stop) return;
     const int tid = threadIdx.x;
+    // grid = K blocks (one class each) for the class-separable dispersion models, else one block for all classes
+    const int kb = (gridDim.x > 1) ? blockIdx.x : 0;
+    const int ke = (gridDim.x > 1) ? kb + 1 : a.K;
     if (a.mode == 1) {
-        for (int t = tid; t < a.K * a.D; t += 1024) centers_ncem_entry(a.K, a.D, a.stats, a.center, a.nbobs_k, a.iner, t);
+        // (every block needs every class size for the empty-class flag; its own class's entries otherwise)
+        if (tid < a.K) a.nbobs_k[tid] = (float)a.stats[tid];
+        for (int t = kb * a.D + tid; t < ke * a.D; t += 1024)
+            centers_ncem_entry(a.K, a.D, a.stats, a.center, a.nbobs_k, a.iner, t);
         __syncthreads();
     }
     if (a.mode != 0) {
-        disp_body(a.K, a.D, a.n_total, a.disper, a.propor, a.mode == 1, a.nbobs_k, a.iner, a.disp, a.prop, a.flags);
+        disp_body(a.K, a.D, a.n_total, a.disper, a.propor, a.mode == 1, a.nbobs_k, a.iner, a.disp, a.prop, a.flags, kb, ke);
         __syncthreads();
     }
-    if (tid < a.K) a.nonuni[tid] = 0;
+    if (tid >= kb && tid < ke) a.nonuni[tid] = 0;
     __syncthreads();
-    for (int t = tid; t < a.K * a.dpad; t += 1024) table_flag_general(a, t);
+    for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_flag_general(a, t);
     __syncthreads();
-    for (int t = tid; t < a.K * a.dpad; t += 1024) table_entry(a, t);     // K*dpad and 1024 are multiples of 64
+    for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_entry(a, t);   // dpad and 1024 are multiples of 64
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1369,7 +1383,12 @@ void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, in
     hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
 }
 
-void launch_finish(const FinishArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, s, a); }
+void launch_finish(const FinishArgs& a, hipStream_t s)
+{
+    // tables only (mode 0) and the models whose dispersion is per class (sk_, skd): one block per class
+    const bool separable = a.mode == 0 || a.disper == NEMGPU_DISP_K_ || a.disper == NEMGPU_DISP_KD;
+    hipLaunchKernelGGL(k_finish, dim3(separable ? a.K : 1), dim3(1024), 0, s, a);
+}
 
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                     int* zero_flags, int n_zero_flags, hipStream_t s)
