@@ -11,6 +11,7 @@
 // denormals preserved.  Where a sum is order-independent (NCEM: c in {0,1} => integer
 // counts < 2^24) it is computed with popcounts over bit-packed rows instead.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 
@@ -644,8 +645,8 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
 // solution, bit for bit.  Round r reads guess_r and writes out_r; rounds after the first
 // unchanged one exit immediately (prev_changed == 0).
 // ------------------------------------------------------------------------------------------
-template <int KT, bool NCEM>
-__global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
+template <int KT, bool NCEM, int BS>
+__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
 {
     if (a.stop != nullptr && *a.stop) return;
     if (a.prev_changed != nullptr && *a.prev_changed == 0) return;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
         if (!any) return;
     }
     __shared__ int s_nzero, s_first;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * BS + threadIdx.x;
     const bool active = i < a.n_local;
     const int gi = a.lo + (active ? i : 0);
     const int K = KT > 0 ? KT : a.K;
@@ -762,23 +763,32 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a)
     __syncthreads();
     if (threadIdx.x == 0 && s_nzero > 0) {
         atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
-        atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);    // first site = n_total - max
+        if (a.flags[FLAG_FIRSTZERO] < s_first) atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);   // first site = n_total - max
     }
 }
 
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
 {
-    dim3 grid((a.n_local + 255) / 256), block(256);
-#define NEM_SW(KT_)                                                                  \
-    case KT_:                                                                        \
-        if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true>), grid, block, 0, s, a);   \
-        else hipLaunchKernelGGL((k_sweep<KT_, false>), grid, block, 0, s, a);       \
+    // large shards run 1024-site blocks: the per-block flag atomics (one address) are what a round costs when
+    // every site reports something (e.g. all densities underflow at D = 5000)
+    const bool big = a.n_local >= 65536;
+    dim3 grid((a.n_local + (big ? 1023 : 255)) / (big ? 1024 : 256)), block(big ? 1024 : 256);
+#define NEM_SW(KT_)                                                                            \
+    case KT_:                                                                                  \
+        if (big) {                                                                             \
+            if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true, 1024>), grid, block, 0, s, a);   \
+            else hipLaunchKernelGGL((k_sweep<KT_, false, 1024>), grid, block, 0, s, a);       \
+        } else {                                                                               \
+            if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true, 256>), grid, block, 0, s, a);    \
+            else hipLaunchKernelGGL((k_sweep<KT_, false, 256>), grid, block, 0, s, a);        \
+        }                                                                                      \
         break;
     switch (a.K) {
         NEM_SW(1) NEM_SW(2) NEM_SW(3) NEM_SW(4) NEM_SW(5) NEM_SW(6) NEM_SW(7) NEM_SW(8) NEM_SW(9) NEM_SW(10)
     default:
-        if (ncem) hipLaunchKernelGGL((k_sweep<0, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_sweep<0, false>), grid, block, 0, s, a);
+        grid = dim3((a.n_local + 255) / 256); block = dim3(256);
+        if (ncem) hipLaunchKernelGGL((k_sweep<0, true, 256>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_sweep<0, false, 256>), grid, block, 0, s, a);
     }
 #undef NEM_SW
 }
@@ -905,10 +915,12 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
                               int* __restrict__ flags, const int* __restrict__ stop, CtrlArgs ca)
 {
     if (stop != nullptr && *stop) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave = i >> 6;
-    if (wave < nw64) {
+    // grid-stride over 64-family groups: the grid is capped (launch_labels_post) so that the last-block ticket
+    // and the "moved" flag cost a bounded number of same-address atomics however many families there are
+    int any_moved = 0;
+    for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < nw64; wave += (gridDim.x * blockDim.x) >> 6) {
+        const int i = wave * 64 + lane;
         int lab = 255, moved = 0;
         if (i < n_local) {
             lab = lab_new[lo + i];
@@ -918,8 +930,9 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
             uint64_t m = __ballot(lab == k);
             if (lane == 0) mask[(size_t)k * nw64 + wave] = m;
         }
-        if (__any(moved) && lane == 0 && flags[FLAG_MOVED] == 0) atomicOr(&flags[FLAG_MOVED], 1);
+        any_moved |= __any(moved);
     }
+    if (any_moved && lane == 0 && flags[FLAG_MOVED] == 0) atomicOr(&flags[FLAG_MOVED], 1);
     if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
 }
 
@@ -929,22 +942,31 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
                                                       const uint64_t* __restrict__ mask, int* __restrict__ stats,
                                                       const int* __restrict__ stop)
 {
-    __shared__ int red[4];
+    __shared__ int red[4][4];
     if (stop != nullptr && *stop) return;
     const int d = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k = 0; k < K; k++) {
-        int acc = 0;
+    const uint64_t* __restrict__ row = xt + (size_t)(d < D ? d : 0) * nw64;
+    // four classes per pass over the organism's bit row (K = 3: the row is read once)
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int kn = min(4, K - k0);
+        int acc[4] = {0, 0, 0, 0};
         for (int j = threadIdx.x; j < nw64; j += 256) {
-            const uint64_t xv = (d < D) ? xt[(size_t)d * nw64 + j] : ~0ull;
-            acc += __popcll(xv & mask[(size_t)k * nw64 + j]);
+            const uint64_t xv = (d < D) ? row[j] : ~0ull;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c < kn) acc[c] += __popcll(xv & mask[(size_t)(k0 + c) * nw64 + j]);
         }
-        acc = wave_reduce_add(acc);
         __syncthreads();
-        if (lane == 0) red[wv] = acc;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int v = wave_reduce_add(acc[c]);
+            if (lane == 0) red[c][wv] = v;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const int v = red[0] + red[1] + red[2] + red[3];
+        if (threadIdx.x < kn) {
+            const int c = threadIdx.x, k = k0 + c;
+            const int v = red[c][0] + red[c][1] + red[c][2] + red[c][3];
             if (d < D) stats[K + k * D + d] = v; else stats[k] = v;
         }
     }
@@ -1407,8 +1429,9 @@ void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab
 {
     CtrlArgs ca{};
     if (ctrl != nullptr) ca = *ctrl;
-    hipLaunchKernelGGL(k_labels_post, dim3((nw64 * 64 + 255) / 256), dim3(256), 0, s, n_local, lo, K, nw64, lab_new,
-                       lab_old, mask, flags, stop, ca);
+    const int blocks = std::min((nw64 * 64 + 255) / 256, 128);
+    hipLaunchKernelGGL(k_labels_post, dim3(blocks), dim3(256), 0, s, n_local, lo, K, nw64, lab_new, lab_old, mask,
+                       flags, stop, ca);
 }
 
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
