@@ -212,7 +212,7 @@ int nemgpu_calibrate_fetch(size_t bytes, int reps);
 /* E1 fast-forward (pangenomenem_amd/csrc/nem_ff.hpp): inside one float binade the reference's chain
    dk = (float)(((double)dk + |x-mu|*L1) - L0)  (nem_mod.c:661) adds a constant to the accumulator's bit pattern, so
    whole 32-organism words advance with one popcount; bit-identical to stepping.  on: 1 always, 0 never,
-   -1 (default) automatic -- long chains (D > 768) or enough chains to fill the GPU more than once.  The
+   -1 (default) automatic -- on from 256 organisms.  The
    environment variable NEM_MI355X_FF=0|1 sets the mode at creation.  The tests compare the two code paths. */
 int nemgpu_set_fast_forward(nemgpu_engine* e, int on);
 /* The increment tables that fast-forward uses for class constants L1 = log((1-eps)/eps), L0 = log(1-eps):

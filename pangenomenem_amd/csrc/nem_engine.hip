@@ -103,10 +103,10 @@ struct nemgpu_engine {
     hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
     bool use_graphs = true;
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
-    // auto: fast-forward pays when the chains are long or when there are enough of them to fill the SIMDs more
-    // than once (then the kernel is issue-bound and fewer instructions win); a short chain on a half-empty GPU is
-    // latency-bound and the binade crossings make it slower than plain stepping (measured: D=500, N=20k)
-    bool use_ff() const { return ff_mode < 0 ? (d > 768 || (long long)n * k > 131072) : ff_mode != 0; }
+    // auto: on from 256 organisms (below that the chain is mostly the small-binade prefix that is stepped anyway
+    // and the table build is pure overhead).  Measured on MI355X: 20k x 500 on par with plain stepping
+    // (latency-bound, one wave per SIMD), 50k x 1000 1.7x, 200k x 5000 9x faster.
+    bool use_ff() const { return ff_mode < 0 ? d >= 256 : ff_mode != 0; }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
 

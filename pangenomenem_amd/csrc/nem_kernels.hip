@@ -92,6 +92,8 @@ __global__ void k_layout_bits(const uint32_t* __restrict__ xw, int npad, int d, 
 //   "null density" bit when the mismatch is non-zero (nem_mod.c:662-666).
 // Padding organisms (d >= D) get all-zero entries: the chain step is then an exact no-op.
 // ------------------------------------------------------------------------------------------
+constexpr int kDensMaskWords = 1024;   // class mismatch masks staged in LDS by k_density (2 x 4 KB): D <= 32768
+
 // does organism dd force class k onto the general (per-organism constants) chain?  cheap: no logs
 __device__ inline void table_flag_general(const FinishArgs& a, int t)
 {
@@ -102,7 +104,7 @@ __device__ inline void table_flag_general(const FinishArgs& a, int t)
     const float mu = a.center[k * D + dd];
     const int ad0 = abs((int)(0.0f - mu)), ad1 = abs((int)(1.0f - mu));
     bool general = (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps) != __float_as_uint(a.disp[k * D])) ||
-                   !((double)eps > kEpsilonD);
+                   !((double)eps > kEpsilonD) || (dpad >> 5) > kDensMaskWords;   // (the uniform chain keeps its masks in LDS)
     if (!general && dd == 0) {
         const double l1 = log((double)((1.0f - eps) / eps)), l0 = log((double)(1.0f - eps));
         if (!isfinite(l1) || !isfinite(l0)) general = true;       // 0 * inf / NaN must propagate as in the reference
@@ -171,7 +173,7 @@ constexpr int DCH = 512;    // organisms per general-path table chunk (small: LD
 // round-robin over the 8 XCDs, so blocks b, b+8, b+16, ... share an XCD and its L2: the K class-blocks of one
 // family tile are placed 8 apart and pull the tile's matrix words through ONE L2 instead of K
 // (speed only: any placement computes the same thing).
-__device__ inline bool density_tile(int K, int ntiles, int& tile, int& k)
+__device__ __forceinline__ bool density_tile(int K, int ntiles, int& tile, int& k)
 {
     const int b = blockIdx.x;
     const int g = b / (8 * K), r = b - g * (8 * K);
@@ -186,7 +188,7 @@ __device__ inline bool density_tile(int K, int ntiles, int& tile, int& k)
 // once, exactly where the reference's add does.  The 2.0 / 0.0 factor is the mismatch bit moved to bit 30 of
 // a double's high word -- a shift and an and instead of a compare and two 64-bit selects (6 VALU
 // instructions per organism instead of 9; the chain itself stays fma, add, cvt, cvt).
-__device__ inline float bern_step(float dk, uint32_t m, int b, double l1h, double l0)
+__device__ __forceinline__ float bern_step(float dk, uint32_t m, int b, double l1h, double l0)
 {
     const uint32_t hi = ((b <= 30) ? (m << (30 - b)) : (m >> 1)) & 0x40000000u;
     const double f = __hiloint2double((int)hi, 0);
@@ -194,14 +196,14 @@ __device__ inline float bern_step(float dk, uint32_t m, int b, double l1h, doubl
 }
 
 // The uniform chain of one (family, class) lane.  am0 / am1: mismatch masks of the class per 32-organism word.
-__device__ inline uint32_t word_of(const uint4& v, int c)
+__device__ __forceinline__ uint32_t word_of(const uint4& v, int c)
 {
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }
 
 // xw4: E1's matrix copy, uint4[W4][npad]: lane i reads words 4g .. 4g+3 of its family with one 16-byte load
 // (1 KB per wave and request), two groups ahead of the one being consumed.
-__device__ inline float chain_plain(const uint4* __restrict__ xw4, int npad, int i, int D,
+__device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int npad, int i, int D,
                                     const uint32_t* am0, const uint32_t* am1, double l1h, double l0)
 {
     float dk = 0.0f;
@@ -236,20 +238,26 @@ __device__ inline float chain_plain(const uint4* __restrict__ xw4, int npad, int
 // sQ0 / sQ1: the class's 256-entry increment tables (LDS).  Bit-identical to chain_plain.
 constexpr int kFFPlainWords = 2;
 
-__device__ inline void ff_load(const uint32_t* sQ0, const uint32_t* sQ1, uint32_t bits, uint32_t& q0, uint32_t& dq,
-                               uint32_t& end)
+__device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sQ1, uint32_t bits, uint32_t& q0, uint32_t& q1,
+                                        uint32_t& end)
 {
     const uint32_t E = (bits >> 23) & 255u;
     q0 = sQ0[E];
-    dq = sQ1[E] - q0;                                    // modulo 2^32 (nem_ff.hpp)
+    q1 = sQ1[E];
     end = (E + 1u) << 23;
 }
 
-// one word (nb organisms, mismatch bits m) of the fast-forwarded chain
-__device__ inline void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& dq, uint32_t& end, uint32_t m, int nb,
-                               const uint32_t* sQ0, const uint32_t* sQ1, double l1h, double l0)
+// pattern after n organisms of which p mismatch (counts <= 32, increments <= 2^23: 24-bit multiplies, sum < 2^32)
+__device__ __forceinline__ uint32_t ff_advance(uint32_t bits, uint32_t n, uint32_t p, uint32_t q0, uint32_t q1)
 {
-    const uint32_t cand = bits + (uint32_t)nb * q0 + (uint32_t)__popc(m) * dq;   // < 2^32: q <= 2^23, nb <= 32
+    return bits + __umul24(n - p, q0) + __umul24(p, q1);
+}
+
+// one word (nb organisms, mismatch bits m) of the fast-forwarded chain
+__device__ __forceinline__ void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& q1, uint32_t& end, uint32_t m, int nb,
+                                        const uint32_t* sQ0, const uint32_t* sQ1, double l1h, double l0)
+{
+    const uint32_t cand = ff_advance(bits, (uint32_t)nb, (uint32_t)__popc(m), q0, q1);
     const bool ok = cand < end;
     if (ok) bits = cand;
     if (__all(ok)) return;
@@ -261,63 +269,94 @@ __device__ inline void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& dq, uint3
 #pragma unroll
             for (int st = 16; st >= 1; st >>= 1) {
                 const int t = j + st;
-                const uint32_t f = bits + (uint32_t)t * q0 + (uint32_t)__popc(mm & ((1u << t) - 1u)) * dq;
+                const uint32_t f = ff_advance(bits, (uint32_t)t, (uint32_t)__popc(mm & ((1u << t) - 1u)), q0, q1);
                 if (f < end) j = t;                      // (f(t) >= f(rem) >= end for t >= rem: never accepted)
             }
-            bits += (uint32_t)j * q0 + (uint32_t)__popc(mm & ((1u << j) - 1u)) * dq;
+            bits = ff_advance(bits, (uint32_t)j, (uint32_t)__popc(mm & ((1u << j) - 1u)), q0, q1);
             bits = __float_as_uint(bern_step(__uint_as_float(bits), mm, j, l1h, l0));
             rem -= j + 1;
             if (rem <= 0) break;
             mm = mm >> (j + 1);                          // j + 1 <= 31 here
-            ff_load(sQ0, sQ1, bits, q0, dq, end);
-            const uint32_t c2 = bits + (uint32_t)rem * q0 + (uint32_t)__popc(mm) * dq;
+            ff_load(sQ0, sQ1, bits, q0, q1, end);
+            const uint32_t c2 = ff_advance(bits, (uint32_t)rem, (uint32_t)__popc(mm), q0, q1);
             if (c2 < end) { bits = c2; break; }
         }
-        ff_load(sQ0, sQ1, bits, q0, dq, end);
+        ff_load(sQ0, sQ1, bits, q0, q1, end);
     }
 }
 
-__device__ inline float chain_ff(const uint4* __restrict__ xw4, int npad, int i, int D,
-                                 const uint32_t* am0, const uint32_t* am1, const uint32_t* sQ0, const uint32_t* sQ1,
-                                 double l1h, double l0)
+// four full words (128 organisms) of the fast-forwarded chain
+__device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint32_t* am0, const uint32_t* am1, uint32_t& bits,
+                                         uint32_t& q0, uint32_t& q1, uint32_t& end, const uint32_t* sQ0,
+                                         const uint32_t* sQ1, double l1h, double l0)
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int w = 4 * g + c;
+        const uint32_t x = word_of(xv, c);
+        const uint32_t m = (x & am1[w]) | (~x & am0[w]);
+        if (c < kFFPlainWords && g == 0) {
+            // the first organisms run through small binades (a crossing every few steps): stepping is cheaper
+            float dk0 = __uint_as_float(bits);
+#pragma unroll
+            for (int b = 0; b < 32; b++) dk0 = bern_step(dk0, m, b, l1h, l0);
+            bits = __float_as_uint(dk0);
+            ff_load(sQ0, sQ1, bits, q0, q1, end);
+        } else {
+            ff_word(bits, q0, q1, end, m, 32, sQ0, sQ1, l1h, l0);
+        }
+    }
+}
+
+__device__ __forceinline__ float chain_ff(const uint4* __restrict__ xw4, int npad, int i, int D,
+                                          const uint32_t* am0, const uint32_t* am1, const uint32_t* sQ0,
+                                          const uint32_t* sQ1, double l1h, double l0)
 {
     const int wlast = (D - 1) >> 5;
-    const int glast = wlast >> 2;
-    uint4 xa = xw4[i];
-    uint4 xb = make_uint4(0u, 0u, 0u, 0u);
-    if (glast >= 1) xb = xw4[(size_t)npad + i];
+    const int gfull = wlast >> 2;                        // groups 0 .. gfull-1 hold four full words each
     uint32_t bits = 0u;                                  // +0.0f (exponent field 0 is always stepped exactly)
-    uint32_t q0, dq, end;
-    ff_load(sQ0, sQ1, bits, q0, dq, end);
-    for (int g = 0; g <= glast; g++) {
-        const uint4 xv = xa;
-        xa = xb;
-        if (g + 2 <= glast) xb = xw4[(size_t)(g + 2) * npad + i];
+    uint32_t q0, q1, end;
+    ff_load(sQ0, sQ1, bits, q0, q1, end);
+    // four register buffers, refilled right after use: three loads stay in flight while a group is consumed.
+    // Every load is issued unconditionally (indices clamped to the last group, which always exists) so that the
+    // compiler can count outstanding loads exactly and wait for the oldest one only.
+    const uint4* p = xw4 + i;
+    uint4 x0 = p[(size_t)min(0, gfull) * npad];
+    uint4 x1 = p[(size_t)min(1, gfull) * npad];
+    uint4 x2 = p[(size_t)min(2, gfull) * npad];
+    uint4 x3 = p[(size_t)min(3, gfull) * npad];
+    int g = 0;
+    for (; g + 4 <= gfull; g += 4) {
+        ff_group(x0, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x0 = p[(size_t)min(g + 4, gfull) * npad];
+        ff_group(x1, g + 1, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x1 = p[(size_t)min(g + 5, gfull) * npad];
+        ff_group(x2, g + 2, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x2 = p[(size_t)min(g + 6, gfull) * npad];
+        ff_group(x3, g + 3, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x3 = p[(size_t)min(g + 7, gfull) * npad];
+    }
+    // 0..3 full groups left, then the last group (1..4 words, the last one possibly partial): after the loop
+    // x0, x1, x2, x3 hold groups g, g+1, g+2, g+3 (clamped to gfull)
+    uint4 xt = x0;
+    if (g < gfull) { ff_group(x0, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x1; g++; }
+    if (g < gfull) { ff_group(x1, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x2; g++; }
+    if (g < gfull) { ff_group(x2, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x3; g++; }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int w = 4 * g + c;
-            if (w > wlast) break;
-            const uint32_t x = word_of(xv, c);
-            uint32_t m = (x & am1[w]) | (~x & am0[w]);
-            if (c < kFFPlainWords && g == 0 && w < wlast) {
-                // the first organisms run through small binades (a crossing every few steps): stepping is cheaper
-                float dk0 = __uint_as_float(bits);
-#pragma unroll
-                for (int b = 0; b < 32; b++) dk0 = bern_step(dk0, m, b, l1h, l0);
-                bits = __float_as_uint(dk0);
-                ff_load(sQ0, sQ1, bits, q0, dq, end);
-                continue;
-            }
-            const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
-            if (nb < 32) m &= (1u << nb) - 1u;
-            ff_word(bits, q0, dq, end, m, nb, sQ0, sQ1, l1h, l0);
-        }
+    for (int c = 0; c < 4; c++) {
+        const int w = 4 * gfull + c;
+        if (w > wlast) break;
+        const uint32_t x = word_of(xt, c);
+        uint32_t m = (x & am1[w]) | (~x & am0[w]);
+        const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
+        if (nb < 32) m &= (1u << nb) - 1u;
+        ff_word(bits, q0, q1, end, m, nb, sQ0, sQ1, l1h, l0);
     }
     return __uint_as_float(bits);
 }
 
 // the class's increment tables, one exponent per thread of a 256-thread block (caller synchronises)
-__device__ inline void ff_build(uint32_t* sQ0, uint32_t* sQ1, double l1, double l0, int tid)
+__device__ __forceinline__ void ff_build(uint32_t* sQ0, uint32_t* sQ1, double l1, double l0, int tid)
 {
     uint32_t q0, q1;
     ff_entry(l1, -l0, tid, q0, q1);
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
     __shared__ uint32_t sQ0[256], sQ1[256];
+    __shared__ uint32_t sAm0[kDensMaskWords], sAm1[kDensMaskWords];
     if (a.stop != nullptr && *a.stop) return;
     int k, tile;
     if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
@@ -359,12 +399,17 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         // wave-uniform doubles; which organisms mismatch comes from two bit masks per word.
         const double l1 = a.uni[k].x, l0 = a.uni[k].y;
         const double l1h = 0.5 * l1;                     // l1 is 0 or a normal double: halving is exact
+        // the class's mismatch masks go through LDS: read from global inside the chain they would share the
+        // vector-memory counter with the matrix prefetch and drain it at every word
+        // (W <= kDensMaskWords here: table_flag_general sends wider matrices down the general path)
+        for (int w = tid; w < W; w += 256) { sAm0[w] = a.am0[k * W + w]; sAm1[w] = a.am1[k * W + w]; }
         if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
             ff_build(sQ0, sQ1, l1, l0, tid);
             __syncthreads();
-            dk = chain_ff(a.xw, npad, i, a.D, a.am0 + k * W, a.am1 + k * W, sQ0, sQ1, l1h, l0);
+            dk = chain_ff(a.xw, npad, i, a.D, sAm0, sAm1, sQ0, sQ1, l1h, l0);
         } else {
-            dk = chain_plain(a.xw, npad, i, a.D, a.am0 + k * W, a.am1 + k * W, l1h, l0);
+            __syncthreads();
+            dk = chain_plain(a.xw, npad, i, a.D, sAm0, sAm1, l1h, l0);
         }
     } else {
         // ---- general case (skd, s_d, hand-written .m files): per-(k,d) constants staged through LDS
