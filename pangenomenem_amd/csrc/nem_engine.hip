@@ -199,6 +199,8 @@ struct SweepCtx {
     bool use_nei = false;
     int r = 0;           // rounds launched so far
     int checked = 0;     // rounds whose flags the host has examined
+    // NCEM pipelined loop: fold the iteration's bookkeeping into the last round of the first batch
+    bool post = false; bool post_moved = false; CtrlArgs post_ctrl{};
 };
 
 int clear_sweep_flags(nemgpu_engine* e)
@@ -222,15 +224,22 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         c.a.flags = e->round_flags(r);
         c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
         c.a.stop = e->stop_ptr;
+        c.a.post_on = 0;
+        if (c.post && ncem && r0 == 0 && b == count - 1) {
+            c.a.post_on = 1; c.a.post_from_guess = (r > 0) ? 1 : 0; c.a.post_moved = c.post_moved ? 1 : 0;
+            c.a.post_nw64 = e->nw64; c.a.post_mask = e->mask; c.a.post_flags = e->iter_flags(); c.a.post_ctrl = c.post_ctrl;
+        }
         launch_sweep(c.a, ncem, e->stream);
     }
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
 
-int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false)
+int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false, const CtrlArgs* post_ctrl = nullptr,
+                  bool post_moved = false)
 {
     c = SweepCtx();
+    if (post_ctrl != nullptr && e->ncem()) { c.post = true; c.post_moved = post_moved; c.post_ctrl = *post_ctrl; }
     c.use_nei = e->has_graph && beta != 0.0f;
     SweepArgs& a = c.a;
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
@@ -407,12 +416,14 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     }
     SweepCtx c;
     e->sweep_counter = sweep_id;
-    if ((r = sweep_enqueue(e, e->cfg.beta, c))) { e->cur = saved; return r; }
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
-    ca.param_fix = e->cfg.param_fix; ca.use_nei = c.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
-    if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; }
+    // NCEM: the bookkeeping (masks, "moved", loop tests) rides in the last relaxation round's launch
+    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? &ca : nullptr, true))) { e->cur = saved; return r; }
+    if (!e->ncem()) { if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; } }
+    else e->masks_valid = true;
     e->cur = saved;
     return NEMGPU_OK;
 }
@@ -430,13 +441,13 @@ int enqueue_init(nemgpu_engine* e)
     e->sweep_counter = 0;
     if ((r = sweep_enqueue(e, 0.0f, c0, true))) return r;          // blind sweep: one round, 0 -> 1
     e->cur = 1;
-    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true))) return r;   // 1 -> 2 (and 0 as the pong buffer)
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
-    ca.param_fix = e->cfg.param_fix; ca.use_nei = c1.use_nei ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
     ca.is_init = 1;
-    if (e->ncem()) { if ((r = do_labels_post(e, 2, -1, &ca))) return r; }
+    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? &ca : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    if (e->ncem()) e->masks_valid = true;
     else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }
     e->cur = 2;
     return NEMGPU_OK;

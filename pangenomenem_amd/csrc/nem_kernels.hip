@@ -681,6 +681,75 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-side loop control (one thread, once per EM iteration).  The host enqueues several
+// iterations ahead; every loop kernel returns at once when ctrl[C_STOP] is set, so the host only
+// has to look at `ctrl` once per batch instead of once per iteration (NemAlgo's loop test,
+// nem_alg.c:1789-1840: convergence, empty class; plus "the sweep needs more relaxation rounds").
+// Runs in the last block to finish of the iteration's bookkeeping kernel (k_labels_post /
+// k_conv_fuzzy), or as its own tiny launch when there is no such kernel.
+// ------------------------------------------------------------------------------------------
+__device__ inline void ctrl_logic(const CtrlArgs& a)
+{
+    int* c = a.ctrl;
+    if (c[C_STOP]) return;
+    if (a.is_init) *a.sweep_next = 2;                             // sweeps 0 and 1 are the two initial ones
+    else { c[C_ITERS] += 1; *a.sweep_next += 1; }                 // the tie-break hash is keyed by the sweep number
+    const int emptyk = a.iter_flags[FLAG_EMPTYK];
+    int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
+    if (a.q_flags != nullptr) {                                   // sharded: any rank's flag byte
+        ch0 = 0; ch1 = 0;
+        for (int r = 0; r < a.n_ranks; r++) ch0 |= a.q_flags[(size_t)r * a.flag_stride];
+        if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
+    }
+    if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
+        if (a.use_nei && ch0 != 0 && ch1 != 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
+        const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
+        c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one
+        if (fi[FLAG_NZERO] > 0) { c[C_NZERO] += fi[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = fi[FLAG_FIRSTZERO]; }
+        return;
+    }
+    const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!a.param_fix && emptyk != 0) {                            // nem_alg.c:1831-1838: E-step "not run"
+        c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
+        c[C_EMPTYK] = emptyk;
+        c[C_STOP] = 1;
+        return;
+    }
+    const int* f = a.round0;
+    int rounds = 1;
+    if (a.use_nei && ch0 != 0) {
+        if (ch1 != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
+        f = a.round1; rounds = 2;
+    }
+    c[C_SWEEP_ROUNDS] += rounds;
+    if (f[FLAG_NZERO] > 0) {
+        c[C_NZERO] += f[FLAG_NZERO];
+        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
+    }
+    c[C_COMMITS] += 1;
+    if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
+        const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
+        if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
+    }
+}
+
+// last-block-done ticket: returns true in exactly one thread of the grid, after every block's global
+// writes (made before its call) are visible to it
+__device__ inline bool last_block_ticket(int* ticket, int nblocks)
+{
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket, 1);
+        s_last = (t == nblocks - 1);
+        if (s_last) { *ticket = 0; __threadfence(); }
+    }
+    __syncthreads();
+    return s_last && threadIdx.x == 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // E2: one relaxation round of the Gauss-Seidel site sweep.
 //
 // The reference updates sites in index order, in place (UPDATE_SEQ): site i sees the NEW rows
@@ -694,12 +763,13 @@ template <int KT, bool NCEM, int BS>
 __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
 {
     if (a.stop != nullptr && *a.stop) return;
-    if (a.prev_changed != nullptr && *a.prev_changed == 0) return;
+    bool skip = (a.prev_changed != nullptr && *a.prev_changed == 0);   // the previous round was already the fixed point
     if (a.flags_in != nullptr) {                         // sharded: did ANY rank change a label last round?
         int any = 0;
         for (int r = 0; r < a.n_ranks; r++) any |= a.flags_in[(size_t)r * a.slot_stride];
-        if (!any) return;
+        if (!any) skip = true;
     }
+    if (skip && !(NCEM && a.post_on)) return;
     __shared__ int s_nzero, s_first;
     const int i = blockIdx.x * BS + threadIdx.x;
     const bool active = i < a.n_local;
@@ -710,7 +780,7 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     bool changed = false;
     if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
     __syncthreads();
-    if (active) {
+    if (active && !skip) {
 
     float ctx[KA];
 #pragma unroll
@@ -810,6 +880,22 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
         if (a.flags[FLAG_FIRSTZERO] < s_first) atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);   // first site = n_total - max
     }
+    if (NCEM && a.post_on) {                             // k_labels_post's work, see SweepArgs
+        int lab = 255, moved = 0;
+        if (active) {
+            lab = a.post_from_guess ? a.lab_guess[gi] : a.lab_out[gi];   // (lab_out[gi]: this thread's own store)
+            if (a.post_moved) moved = (lab != (int)a.lab_old[gi]);
+        }
+        const int wave = i >> 6;
+        if (wave < a.post_nw64) {
+            for (int k = 0; k < K; k++) {
+                const uint64_t m = __ballot(lab == k);
+                if ((threadIdx.x & 63) == 0) a.post_mask[(size_t)k * a.post_nw64 + wave] = m;
+            }
+        }
+        if (__any(moved) && (threadIdx.x & 63) == 0 && a.post_flags[FLAG_MOVED] == 0) atomicOr(&a.post_flags[FLAG_MOVED], 1);
+        if (a.post_ctrl.ctrl != nullptr && last_block_ticket(a.post_ctrl.ticket, gridDim.x)) ctrl_logic(a.post_ctrl);
+    }
 }
 
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
@@ -836,75 +922,6 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
         else hipLaunchKernelGGL((k_sweep<0, false, 256>), grid, block, 0, s, a);
     }
 #undef NEM_SW
-}
-
-// ------------------------------------------------------------------------------------------
-// Device-side loop control (one thread, once per EM iteration).  The host enqueues several
-// iterations ahead; every loop kernel returns at once when ctrl[C_STOP] is set, so the host only
-// has to look at `ctrl` once per batch instead of once per iteration (NemAlgo's loop test,
-// nem_alg.c:1789-1840: convergence, empty class; plus "the sweep needs more relaxation rounds").
-// Runs in the last block to finish of the iteration's bookkeeping kernel (k_labels_post /
-// k_conv_fuzzy), or as its own tiny launch when there is no such kernel.
-// ------------------------------------------------------------------------------------------
-__device__ inline void ctrl_logic(const CtrlArgs& a)
-{
-    int* c = a.ctrl;
-    if (c[C_STOP]) return;
-    if (a.is_init) *a.sweep_next = 2;                             // sweeps 0 and 1 are the two initial ones
-    else { c[C_ITERS] += 1; *a.sweep_next += 1; }                 // the tie-break hash is keyed by the sweep number
-    const int emptyk = a.iter_flags[FLAG_EMPTYK];
-    int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
-    if (a.q_flags != nullptr) {                                   // sharded: any rank's flag byte
-        ch0 = 0; ch1 = 0;
-        for (int r = 0; r < a.n_ranks; r++) ch0 |= a.q_flags[(size_t)r * a.flag_stride];
-        if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
-    }
-    if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
-        if (a.use_nei && ch0 != 0 && ch1 != 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
-        const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
-        c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one
-        if (fi[FLAG_NZERO] > 0) { c[C_NZERO] += fi[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = fi[FLAG_FIRSTZERO]; }
-        return;
-    }
-    const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!a.param_fix && emptyk != 0) {                            // nem_alg.c:1831-1838: E-step "not run"
-        c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
-        c[C_EMPTYK] = emptyk;
-        c[C_STOP] = 1;
-        return;
-    }
-    const int* f = a.round0;
-    int rounds = 1;
-    if (a.use_nei && ch0 != 0) {
-        if (ch1 != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
-        f = a.round1; rounds = 2;
-    }
-    c[C_SWEEP_ROUNDS] += rounds;
-    if (f[FLAG_NZERO] > 0) {
-        c[C_NZERO] += f[FLAG_NZERO];
-        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
-    }
-    c[C_COMMITS] += 1;
-    if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
-        const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
-        if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
-    }
-}
-
-// last-block-done ticket: returns true in exactly one thread of the grid, after every block's global
-// writes (made before its call) are visible to it
-__device__ inline bool last_block_ticket(int* ticket, int nblocks)
-{
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int t = atomicAdd(ticket, 1);
-        s_last = (t == nblocks - 1);
-        if (s_last) { *ticket = 0; __threadfence(); }
-    }
-    __syncthreads();
-    return s_last && threadIdx.x == 0;
 }
 
 __global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }

@@ -50,6 +50,13 @@ struct SweepArgs {
     // sharded runs: label arrays are laid out in per-rank blocks of `slot_stride` bytes (labels + flag tail);
     // flags_in = previous round's all-gathered flag bytes (round exits when none is set)
     const uint8_t* flags_in; int n_ranks, slot_stride, slot_pad;
+    // NCEM, pipelined loop: the iteration's bookkeeping (k_labels_post: class masks, "moved" flag, loop control in
+    // the last block) folded into the last enqueued round.  post_from_guess: the final labels are this round's
+    // guess (a verification round: if it changes anything the loop control stops the pipeline and the host redoes
+    // the bookkeeping), else this round's output.
+    int post_on, post_from_guess, post_moved, post_nw64;
+    uint64_t* post_mask; int* post_flags;
+    CtrlArgs post_ctrl;
 };
 void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s);
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
