@@ -163,6 +163,8 @@ FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
     t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni;
     t.pk = e->pk; t.logpk = e->logpk; t.flags = e->iter_flags();
     t.stop = e->stop_ptr;
+    t.reset_prop = nullptr; t.reset_center = nullptr; t.reset_disp = nullptr;
+    t.reset_ctrl = nullptr; t.reset_ctrl_words = 0; t.reset_sweep_next = nullptr;
     t.use_ff = e->use_ff() ? 1 : 0;
     t.perm = e->perm;
     return t;
@@ -199,6 +201,7 @@ struct SweepCtx {
     bool use_nei = false;
     int r = 0;           // rounds launched so far
     int checked = 0;     // rounds whose flags the host has examined
+    int slot_base = 0;   // first flag slot of the round window (the blind initial sweep takes a slot of its own)
     // NCEM pipelined loop: fold the iteration's bookkeeping into the last round of the first batch
     bool post = false; bool post_moved = false; CtrlArgs post_ctrl{};
 };
@@ -221,8 +224,8 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         const int ob = (r % 2 == 0) ? Q : R;
         if (ncem) { c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[gb]; c.a.lab_out = e->lab[ob]; }
         else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
-        c.a.flags = e->round_flags(r);
-        c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(r - 1) + FLAG_CHANGED);
+        c.a.flags = e->round_flags(c.slot_base + r);
+        c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(c.slot_base + r - 1) + FLAG_CHANGED);
         c.a.stop = e->stop_ptr;
         c.a.post_on = 0;
         if (c.post && ncem && r0 == 0 && b == count - 1) {
@@ -236,9 +239,10 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
 }
 
 int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false, const CtrlArgs* post_ctrl = nullptr,
-                  bool post_moved = false)
+                  bool post_moved = false, int slot_base = 0)
 {
     c = SweepCtx();
+    c.slot_base = slot_base;
     if (post_ctrl != nullptr && e->ncem()) { c.post = true; c.post_moved = post_moved; c.post_ctrl = *post_ctrl; }
     c.use_nei = e->has_graph && beta != 0.0f;
     SweepArgs& a = c.a;
@@ -432,14 +436,22 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
 int enqueue_init(nemgpu_engine* e)
 {
     int r;
-    if ((r = reset_device(e))) return r;
-    e->tables_fresh = false; e->density_fresh = false;
+    // one launch: initial parameters back in place, loop control cleared, density tables built
+    {
+        FinishArgs t = finish_args(e, 0, nullptr);
+        t.reset_prop = e->prop0; t.reset_center = e->center0; t.reset_disp = e->disp0;
+        t.reset_ctrl = e->ctrl(); t.reset_ctrl_words = C_WORDS; t.reset_sweep_next = e->sweep_next;
+        launch_finish(t, e->stream);
+        HIPCHK(hipGetLastError());
+    }
+    e->tables_fresh = true; e->density_fresh = false;
     e->cur = 0;
-    if ((r = do_tables(e))) return r;
-    if ((r = do_density(e))) return r;
+    if ((r = do_density(e))) return r;                             // (also clears every sweep flag slot)
     SweepCtx c0, c1;
     e->sweep_counter = 0;
-    if ((r = sweep_enqueue(e, 0.0f, c0, true))) return r;          // blind sweep: one round, 0 -> 1
+    // blind sweep: one round, 0 -> 1, on a flag slot of its own so that no clear is needed before the next sweep
+    if ((r = sweep_enqueue(e, 0.0f, c0, true, nullptr, false, kRoundCap - 1))) return r;
+    e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
@@ -480,7 +492,8 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         if (exec == nullptr) {
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             r = NEMGPU_OK;
-            hipError_t herr = hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
+            hipError_t herr = first ? hipSuccess                   // (the restart launch clears the loop control itself)
+                                    : hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
             e->stop_ptr = e->ctrl() + C_STOP;
             if (first && herr == hipSuccess) r = enqueue_init(e);
             for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)

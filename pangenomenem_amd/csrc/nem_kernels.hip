@@ -1216,11 +1216,21 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
 // d-ordered float chain of the sk_/s__ models.
 __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
 {
-    if (a.stop != nullptr && *a.stop) return;
     const int tid = threadIdx.x;
     // grid = K blocks (one class each) for the class-separable dispersion models, else one block for all classes
     const int kb = (gridDim.x > 1) ? blockIdx.x : 0;
     const int ke = (gridDim.x > 1) ? kb + 1 : a.K;
+    if (a.reset_prop != nullptr) {
+        // restart: initial parameters back in place, loop control cleared (the stop word may still be set from
+        // the run before; every later kernel of the batch reads it after this launch)
+        for (int t = kb * a.D + tid; t < ke * a.D; t += 1024) { a.center[t] = a.reset_center[t]; a.disp[t] = a.reset_disp[t]; }
+        if (tid >= kb && tid < ke) { a.prop[tid] = a.reset_prop[tid]; a.nbobs_k[tid] = 0.0f; }
+        if (blockIdx.x == 0) {
+            if (tid < a.reset_ctrl_words) a.reset_ctrl[tid] = 0;
+            if (tid == 0) a.reset_sweep_next[0] = 0;
+        }
+        __syncthreads();
+    } else if (a.stop != nullptr && *a.stop) return;
     if (a.mode == 1) {
         // (every block needs every class size for the empty-class flag; its own class's entries otherwise)
         if (tid < a.K) a.nbobs_k[tid] = (float)a.stats[tid];

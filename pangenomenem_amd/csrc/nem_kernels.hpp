@@ -75,6 +75,10 @@ struct FinishArgs {
     uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni;
     double* pk; float* logpk; int* flags;
     const int* stop;
+    // head of a restart batch (mode 0, reset_prop != nullptr): reload the initial parameters and clear the loop
+    // control words in this launch instead of five copy / fill operations
+    const float* reset_prop; const float* reset_center; const float* reset_disp;
+    int* reset_ctrl; int reset_ctrl_words; int* reset_sweep_next;
     const int* perm;               // density kernels: lane i of the (sorted) matrix copy is family perm[i]
     int use_ff;                    // density kernels: fast-forward the uniform chain inside float binades (nem_ff.hpp)
 };
