@@ -82,8 +82,9 @@ def pmc_traffic(kernel, n_loc, d):
     try:
         with open(path) as f:
             rec = json.load(f)
-        if rec.get("families") == n_loc and rec.get("organisms") == d and kernel in rec.get("kernels", {}):
-            return rec["kernels"][kernel]["traffic_bytes_per_launch"]
+        for w in rec.get("workloads", []):
+            if w.get("families") == n_loc and w.get("organisms") == d and kernel in w.get("kernels", {}):
+                return w["kernels"][kernel]["traffic_bytes_per_launch"]
     except (OSError, ValueError):
         pass
     return None
@@ -184,8 +185,11 @@ def main():
             "dtype": "f32 chains with f64 intermediates (reference arithmetic); int32 popcounts in the M-step",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] per GPU: %d families x %d organisms, K=3, beta=0.5, contiguity graph "
-                            "(path + 5%% chords, weights 1..8), %s/sk_/pk, default .m init" % (n_loc, d, args.algo),
+                "workload": "%s per GPU: %d families x %d organisms, K=3, beta=0.5, contiguity graph "
+                            "(path + 5%% chords, weights 1..8), %s/sk_/pk, default .m init"
+                            % ({(20000, 500): "BASELINE configs[1]", (50000, 1000): "BASELINE configs[2] shape",
+                                (200000, 5000): "BASELINE configs[3] shape"}.get((n_loc, d), "custom shape"),
+                               n_loc, d, args.algo),
                 "families_total": n_tot, "organisms": d, "K": k, "beta": beta,
                 "cycle_iterations": cycle,
                 "parallelism": "1 GPU" if world == 1 else "families sharded over %d GPUs; all-reduce(int32 stats) "
@@ -203,6 +207,9 @@ def main():
                 "avg_launch_ms": prof["density_ms_avg"],
                 "launches_timed": prof["density_launches"],
                 "whole_iteration_algorithmic_GBps": None,
+                "note": "HBM is the nominal bound (SURVEY.md 8d: bit scans, no dense contraction, no MFMA). The kernel is a "
+                        "dependent chain per (family, class) that the reference's float rounding forbids re-associating; "
+                        "at configs[1] one launch moves 2 MB (0.26 us at peak) and is latency-bound, see DESIGN.md section 4",
             },
         }
         # whole-iteration algorithmic traffic (SURVEY.md §8d formula), for context

@@ -205,7 +205,7 @@ int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, in
    algorithmic bytes one launch moves. */
 int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch,
                            int* used_fused_kernel);
-/* FETCH_SIZE calibration helper: `reps` launches reading `bytes` of device memory one dword per lane (E1's
+/* FETCH_SIZE calibration helper: `reps` launches reading `bytes` of device memory 16 bytes per lane (E1's
    pattern); run under `rocprofv3 --pmc FETCH_SIZE` and compare with the known byte count (profiles/README.md). */
 int nemgpu_calibrate_fetch(size_t bytes, int reps);
 

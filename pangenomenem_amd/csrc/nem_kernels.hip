@@ -1537,18 +1537,21 @@ void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)
 }
 
 // FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): a read of a KNOWN byte count with E1's access
-// pattern -- one dword per lane, lanes consecutive, row after row -- so that the counter can be scaled.
-__global__ __launch_bounds__(256) void k_calib_read_dwords(const uint32_t* __restrict__ buf, size_t words,
-                                                           uint32_t* __restrict__ sink)
+// pattern -- 16 bytes per lane, lanes consecutive, row after row -- so that the counter can be scaled.
+__global__ __launch_bounds__(256) void k_calib_read16(const uint4* __restrict__ buf, size_t quads,
+                                                      uint32_t* __restrict__ sink)
 {
     uint32_t acc = 0;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < words; t += (size_t)gridDim.x * 256) acc ^= buf[t];
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < quads; t += (size_t)gridDim.x * 256) {
+        const uint4 v = buf[t];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
     if (acc == 0x9E3779B9u) sink[0] = acc;               // keeps the loads alive; practically never taken
 }
 
 void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_calib_read_dwords, dim3(256 * 16), dim3(256), 0, s, buf, words, sink);
+    hipLaunchKernelGGL(k_calib_read16, dim3(256 * 16), dim3(256), 0, s, (const uint4*)buf, words / 4, sink);
 }
 
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,

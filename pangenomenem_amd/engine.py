@@ -316,7 +316,7 @@ class NemEngine:
 
 
 def calibrate_fetch(nbytes=1 << 30, reps=3):
-    """One known-size dword-per-lane read, for scaling rocprofv3's FETCH_SIZE (profiles/README.md)."""
+    """One known-size 16-bytes-per-lane read, for scaling rocprofv3's FETCH_SIZE (profiles/README.md)."""
     rc = load_library().nemgpu_calibrate_fetch(int(nbytes), int(reps))
     if rc != 0:
         raise NemGpuError("nemgpu_calibrate_fetch failed (status %d)" % rc)
