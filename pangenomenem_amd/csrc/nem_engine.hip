@@ -50,10 +50,12 @@ struct nemgpu_engine {
     bool have_matrix = false, have_params = false, has_graph = false;
 
     uint32_t* xw = nullptr;
-    // E1's own copy of the matrix: word-major like xw, but lane i holds family perm[i].  Families are ordered by
-    // their number of present organisms, so the lanes of a wave run similar chains and cross float binades in
-    // the same words (what makes the fast-forward of nem_ff.hpp coherent across a wave).  Results are written
-    // back through perm, so nothing outside the density kernels sees the order.
+    // E1's own copy of the matrix: uint4[ceil(W/4)][npad], lane i holds family perm[i].  Inside every 256-family
+    // tile (one block of the density kernels) the families are ordered by their number of present organisms, so
+    // the lanes of a wave run similar chains and cross float binades in the same words (what keeps the
+    // fast-forward of nem_ff.hpp coherent across a wave; a global sort gains almost nothing over the tile-local
+    // one).  The block puts its 256 results back in family order through LDS, so its stores are contiguous and
+    // nothing outside the density kernels sees the order.
     uint32_t* xws = nullptr;
     int* perm = nullptr;
     bool use_sort = true;
@@ -777,21 +779,21 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
     HIPCHK(hipSetDevice(e->device));
     uint32_t* xf = nullptr;
     const size_t words = (size_t)e->n * e->wf;
-    // lane order of the density kernels: stable counting sort of the local families by popcount
+    // lane order of the density kernels: inside each 256-family tile, families by popcount (stable)
     std::vector<int> perm((size_t)e->npad);
     for (int i = 0; i < e->npad; i++) perm[i] = i;
     if (e->use_sort) {
-        std::vector<int> pc((size_t)e->n), start((size_t)e->d + 2, 0);
+        std::vector<int> pc((size_t)e->n);
         for (int i = 0; i < e->n; i++) {
             const uint32_t* row = xbits_host + (size_t)i * e->wf;
             int c = 0;
             for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
-            if (c > e->d) c = e->d;                                // (stray bits above D in the last word)
             pc[i] = c;
-            start[c + 1]++;
         }
-        for (int c = 0; c <= e->d; c++) start[c + 1] += start[c];
-        for (int i = 0; i < e->n; i++) perm[start[pc[i]]++] = i;
+        for (int t0 = 0; t0 < e->n; t0 += 256) {
+            const int t1 = std::min(t0 + 256, e->n);
+            std::stable_sort(perm.begin() + t0, perm.begin() + t1, [&](int a, int b) { return pc[a] < pc[b]; });
+        }
     }
     HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);

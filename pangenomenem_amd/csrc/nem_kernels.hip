@@ -363,6 +363,28 @@ __device__ __forceinline__ void ff_build(uint32_t* sQ0, uint32_t* sQ1, double l1
     sQ0[tid] = q0; sQ1[tid] = q1;
 }
 
+// Epilogue of both density kernels: lane tid of the tile ran family perm[tile*256 + tid], which lies in the same
+// tile; the block hands its 256 results back in family order through LDS and stores them contiguously.
+__device__ __forceinline__ void density_store(const int* __restrict__ perm, int tile, int tid, int n, int npad, int k,
+                                              float dk, uint32_t nul, double pk, float logpk,
+                                              double* __restrict__ pkfki, float* __restrict__ logpkfki)
+{
+    __shared__ double sPk[256];
+    __shared__ float sLp[256];
+    float logfk; double fk;
+    if (!nul) { logfk = -dk; fk = exp((double)logfk); }          // nem_mod.c:679-680
+    else { logfk = -FLT_MAX; fk = 0.0; }                         // nem_mod.c:685-686
+    const int slot = perm[tile * 256 + tid] - tile * 256;
+    sPk[slot] = pk * fk;                                         // nem_alg.c:2282
+    sLp[slot] = logpk + logfk;                                   // nem_alg.c:2283
+    __syncthreads();
+    const int io = tile * 256 + tid;
+    if (io < n) {
+        pkfki[(size_t)k * npad + io] = sPk[tid];
+        logpkfki[(size_t)k * npad + io] = sLp[tid];
+    }
+}
+
 struct DensityArgs {
     const uint4* xw; int n, npad, dpad, D, K;
     const double2* tabT; const double* tabL0; const uint32_t* nz0; const uint32_t* nz1;
@@ -444,14 +466,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
             }
         }
     }
-    if (i < a.n) {
-        float logfk; double fk;
-        if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
-        else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
-        const int io = a.perm[i];                                // lane i ran family perm[i]
-        a.pkfki[(size_t)k * npad + io] = a.pk[k] * fk;           // nem_alg.c:2282
-        a.logpkfki[(size_t)k * npad + io] = a.logpk[k] + logfk;  // nem_alg.c:2283
-    }
+    density_store(a.perm, tile, tid, a.n, npad, k, dk, nul, a.pk[k], a.logpk[k], a.pkfki, a.logpkfki);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,14 +673,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
             }
         }
     }
-    if (i < a.n) {
-        float logfk; double fk;
-        if (!nul) { logfk = -dk; fk = exp((double)logfk); }      // nem_mod.c:679-680
-        else { logfk = -FLT_MAX; fk = 0.0; }                     // nem_mod.c:685-686
-        const int io = a.perm[i];                                // lane i ran family perm[i]
-        a.pkfki[(size_t)k * npad + io] = pkd * fk;               // nem_alg.c:2282
-        a.logpkfki[(size_t)k * npad + io] = logpk + logfk;       // nem_alg.c:2283
-    }
+    density_store(a.perm, tile, tid, a.n, npad, k, dk, nul, pkd, logpk, a.pkfki, a.logpkfki);
 }
 
 void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
