@@ -150,16 +150,23 @@ int nemgpu_criteria(nemgpu_engine* e, float crit6[6]);    /* C1 only */
    nemgpu_shard_end the loop tests run on the device, as in the single-GPU pipelined loop.
 
    Label arrays are uint8[world * stride]: rank r owns slots [r*stride, r*stride + blk) (its families,
-   in order) and the byte at r*stride + blk carries its "a label changed in this round" flag, so ONE
-   all-gather per relaxation round moves labels and flags together.  The engine is created with
-   n_total = world*stride, site_lo = rank*stride, site_hi = site_lo + (families of the shard) and the
-   graph's neighbour indices are slot indices.
-   stats: int32[k + k*d] = { N_k, S1[k][j] = #{i in shard : label_i = k, x_ij = 1} }.                  */
+   in order); the byte at r*stride + blk carries its "a label changed in this round" flag and, further
+   behind (4-byte aligned, the driver picks the offset), its partial M-step statistics, so ONE
+   all-gather per relaxation round moves labels, flags and statistics together -- there is no separate
+   all-reduce.  The engine is created with n_total = world*stride, site_lo = rank*stride,
+   site_hi = site_lo + (families of the shard) and the graph's neighbour indices are slot indices.
+   stats: int32[k + k*d] = { N_k, S1[k][j] = #{i in shard : label_i = k, x_ij = 1} } per rank; readers
+   sum the world partial arrays (stride bytes apart), integer sums being exact in any order.          */
 int nemgpu_stats_words(const nemgpu_engine* e);
 int nemgpu_shard_layout(nemgpu_engine* e, int world, int rank, int blk, int stride, int n_families_total);
 int nemgpu_shard_begin(nemgpu_engine* e);
+/* partial counts of this rank's families under the given labels -> stats_dev (own statistics tail) */
 int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, int32_t* stats_dev);
-/* stats_dev (all-reduced) -> parameters, or NULL to keep them; density; round 0; sweep_id < 0 = device counter */
+/* the same for the labels the last nemgpu_shard_estep_round0 produced (their class masks already exist) */
+int nemgpu_shard_counts(nemgpu_engine* e, int32_t* stats_dev);
+/* stats_dev = rank 0's partial statistics inside an all-gathered label array (rank r's are r*stride bytes
+   further) -> parameters, or NULL to keep them; density; round 0 (+ class masks of its output, + this rank's
+   flag byte); sweep_id < 0 = device counter */
 int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float beta, int sweep_id,
                               const uint8_t* labels_old_dev, uint8_t* labels_out_dev);
 int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,

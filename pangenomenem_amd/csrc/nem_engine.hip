@@ -159,7 +159,7 @@ FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
     FinishArgs t;
     t.mode = mode;
     t.K = e->k; t.D = e->d; t.dpad = e->dpad; t.n_total = e->n_true; t.disper = e->cfg.disper; t.propor = e->cfg.propor;
-    t.stats = stats;
+    t.stats = stats; t.stats_ranks = 1; t.stats_rank_stride = 0;
     t.prop = e->prop; t.center = e->center; t.disp = e->disp; t.nbobs_k = e->nbobs_k; t.iner = e->iner;
     t.tabT = e->tabT; t.tabL0 = e->tabL0; t.nz0 = e->nz0; t.nz1 = e->nz1;
     t.am0 = e->am0; t.am1 = e->am1; t.uni = e->uni; t.nonuni = e->nonuni;
@@ -996,6 +996,7 @@ int nemgpu_shard_layout(nemgpu_engine* e, int world, int rank, int blk, int stri
         set_error("shard layout does not match the engine's slot range");
         return NEMGPU_E_ARG;
     }
+    if (stride % 4 != 0) { set_error("shard layout: stride must be a multiple of 4 bytes"); return NEMGPU_E_ARG; }
     e->sh_world = world; e->sh_rank = rank; e->sh_blk = blk; e->sh_stride = stride; e->n_true = n_true;
     return NEMGPU_OK;
 }
@@ -1028,7 +1029,18 @@ int nemgpu_shard_begin(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-// local class masks of the current labels + popcounts -> stats_dev (then: all-reduce(sum))
+// this rank's partial counts of the labels relaxation round 0 just produced (its class masks were built by that
+// launch) -> stats_dev, normally the statistics tail of this rank's block in the label array gathered next
+int nemgpu_shard_counts(nemgpu_engine* e, int32_t* stats_dev)
+{
+    if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+// local class masks of the given labels + popcounts -> stats_dev (the explicit form of the above)
 int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, int32_t* stats_dev)
 {
     if (!e || !labels_cur_dev || !stats_dev) return NEMGPU_E_FUNCARG;
@@ -1053,7 +1065,9 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
                        (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
     if (fused) {
         // parameter update (per block, from the summed counts) + density in one launch
-        launch_density_fused(finish_args(e, 1, stats_dev), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
+        FinishArgs t = finish_args(e, 1, stats_dev);
+        t.stats_ranks = e->sh_world; t.stats_rank_stride = e->sh_stride / 4;
+        launch_density_fused(t, e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
                              e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
         HIPCHK(hipGetLastError());
         e->tables_fresh = false;
@@ -1061,7 +1075,9 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
         e->flags_clean = true;
     } else {
         if (stats_dev != nullptr) {
-            launch_finish(finish_args(e, 1, stats_dev), e->stream);
+            FinishArgs t = finish_args(e, 1, stats_dev);
+            t.stats_ranks = e->sh_world; t.stats_rank_stride = e->sh_stride / 4;
+            launch_finish(t, e->stream);
             HIPCHK(hipGetLastError());
             e->tables_fresh = true;
             e->density_fresh = false;
@@ -1073,8 +1089,11 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
     shard_sweep_args(e, a, beta, sweep_id);
     a.lab_old = labels_old_dev; a.lab_guess = labels_old_dev; a.lab_out = labels_out_dev;
     a.flags = e->round_flags(0);
+    // the same launch builds the class masks of its output (for nemgpu_shard_counts) and publishes the flag byte
+    a.post_on = 1; a.post_from_guess = 0; a.post_moved = 0; a.post_nw64 = e->nw64; a.post_mask = e->mask;
+    a.post_flags = e->iter_flags();
+    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 1;
     launch_sweep(a, true, e->stream);
-    launch_publish_flag(e->round_flags(0), own_flag_byte(e, labels_out_dev), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = false;
     return NEMGPU_OK;
@@ -1092,8 +1111,8 @@ int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const 
     a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
     a.flags = e->round_flags(1);
     a.flags_in = labels_guess_dev + e->sh_blk;                     // rank 0's flag byte; stride = slot_stride
+    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 1;
     launch_sweep(a, true, e->stream);
-    launch_publish_flag(e->round_flags(1), own_flag_byte(e, labels_out_dev), e->stop_ptr, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }

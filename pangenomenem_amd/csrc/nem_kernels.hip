@@ -34,6 +34,14 @@ __host__ __device__ inline uint32_t mix32(uint32_t seed, uint32_t sweep, uint32_
     return h;
 }
 
+// NCEM statistic `idx`, summed over the ranks' partial arrays (integer sums: any order is exact)
+__device__ __forceinline__ int stat_sum(const int* __restrict__ stats, int idx, int ranks, int stride)
+{
+    int s = stats[idx];
+    for (int r = 1; r < ranks; r++) s += stats[idx + r * stride];
+    return s;
+}
+
 __device__ inline int wave_reduce_add(int v)
 {
 #pragma unroll
@@ -482,7 +490,7 @@ constexpr int FD_CH = 256;        // organisms per general-path table chunk
 
 struct FusedDensityArgs {
     const uint4* xw; int n, npad, dpad, D, K, n_total, disper, propor;
-    const int* stats;
+    const int* stats; int stats_ranks, stats_rank_stride;
     float* center; float* disp; float* prop; float* nbobs_k;
     int* iter_flags;
     double* pkfki; float* logpkfki;
@@ -513,7 +521,8 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         for (int t = tid; t < a.n_zero_flags; t += 256) a.zero_flags[t] = 0;
         if (tid == 0) {                                  // EstimLaplaceCenters, nem_mod.c:1404-1408
             int ek = 0;
-            for (int c = 0; c < K; c++) if (!((double)(float)a.stats[c] > kEpsilonD)) ek = c + 1;
+            for (int c = 0; c < K; c++)
+                if (!((double)(float)stat_sum(a.stats, c, a.stats_ranks, a.stats_rank_stride) > kEpsilonD)) ek = c + 1;
             a.iter_flags[FLAG_EMPTYK] = ek;
         }
     }
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     __syncthreads();
 
     // ---- centres + inertia of class k from the counts (k_finish's centers_ncem_entry, per block)
-    const int nkI = a.stats[k];
+    const int nkI = stat_sum(a.stats, k, a.stats_ranks, a.stats_rank_stride);
     const float nkf = (float)nkI;
     const bool nonempty = (double)nkf > kEpsilonD;
     long long acc2 = 0;
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         if (d < D) {
             if (nonempty) {
                 const float half = nkf / 2;
-                const int s1 = a.stats[K + k * D + d];
+                const int s1 = stat_sum(a.stats, K + k * D + d, a.stats_ranks, a.stats_rank_stride);
                 const float s0f = (float)(nkI - s1);
                 if (s0f > half) { mu = 0.0f; in = (float)s1; }
                 else if (s0f == half) { mu = 0.5f; in = 0.5f * nkf; }
@@ -682,6 +691,7 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
     FusedDensityArgs a;
     a.xw = (const uint4*)xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
     a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
+    a.stats_ranks = t.stats_ranks; a.stats_rank_stride = t.stats_rank_stride;
     a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
     a.use_ff = t.use_ff; a.perm = t.perm;
@@ -777,7 +787,10 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         for (int r = 0; r < a.n_ranks; r++) any |= a.flags_in[(size_t)r * a.slot_stride];
         if (!any) skip = true;
     }
-    if (skip && !(NCEM && a.post_on)) return;
+    if (skip && !(NCEM && a.post_on)) {
+        if (a.publish_byte != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *a.publish_byte = 0;
+        return;
+    }
     __shared__ int s_nzero, s_first;
     const int i = blockIdx.x * BS + threadIdx.x;
     const bool active = i < a.n_local;
@@ -902,7 +915,15 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
             }
         }
         if (__any(moved) && (threadIdx.x & 63) == 0 && a.post_flags[FLAG_MOVED] == 0) atomicOr(&a.post_flags[FLAG_MOVED], 1);
-        if (a.post_ctrl.ctrl != nullptr && last_block_ticket(a.post_ctrl.ticket, gridDim.x)) ctrl_logic(a.post_ctrl);
+    }
+    const bool post_ctrl = NCEM && a.post_on && a.post_ctrl.ctrl != nullptr;
+    if (a.publish_byte != nullptr || post_ctrl) {
+        int* ticket = a.publish_byte != nullptr ? a.publish_ticket : a.post_ctrl.ticket;
+        if (last_block_ticket(ticket, gridDim.x)) {
+            if (a.publish_byte != nullptr)
+                *a.publish_byte = (uint8_t)(__hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+            if (post_ctrl) ctrl_logic(a.post_ctrl);
+        }
     }
 }
 
@@ -1046,17 +1067,18 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
 //   N_K = count (EstimSizes, nem_mod.c:1293-1315);  halfwei = N_K/2;  zeros-side weight S0 = N_K - S1;
 //   ComputeMedian (nem_mod.c:1439-1477) gives mu = 0 if S0 > half, 0.5 if S0 == half, 1 otherwise;
 //   EstimLaplaceIner (nem_mod.c:1669-1686) gives S1, S0 or N_K/2 for mu = 0, 1, 0.5 (all exact).
-__device__ inline void centers_ncem_entry(int K, int D, const int* __restrict__ stats, float* __restrict__ center,
-                                          float* __restrict__ nbobs_k, float* __restrict__ iner, int t)
+__device__ inline void centers_ncem_entry(int K, int D, const int* __restrict__ stats, int ranks, int rstride,
+                                          float* __restrict__ center, float* __restrict__ nbobs_k,
+                                          float* __restrict__ iner, int t)
 {
     const int k = t / D;
-    const int nk = stats[k];
+    const int nk = stat_sum(stats, k, ranks, rstride);
     const float nkf = (float)nk;
     if (t - k * D == 0) nbobs_k[k] = nkf;
     float in = 0.0f;
     if ((double)nkf > kEpsilonD) {
         const float half = nkf / 2;
-        const int s1 = stats[K + t];
+        const int s1 = stat_sum(stats, K + t, ranks, rstride);
         const float s0f = (float)(nk - s1);
         float mu;
         if (s0f > half) { mu = 0.0f; in = (float)s1; }
@@ -1241,9 +1263,9 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
     } else if (a.stop != nullptr && *a.stop) return;
     if (a.mode == 1) {
         // (every block needs every class size for the empty-class flag; its own class's entries otherwise)
-        if (tid < a.K) a.nbobs_k[tid] = (float)a.stats[tid];
+        if (tid < a.K) a.nbobs_k[tid] = (float)stat_sum(a.stats, tid, a.stats_ranks, a.stats_rank_stride);
         for (int t = kb * a.D + tid; t < ke * a.D; t += 1024)
-            centers_ncem_entry(a.K, a.D, a.stats, a.center, a.nbobs_k, a.iner, t);
+            centers_ncem_entry(a.K, a.D, a.stats, a.stats_ranks, a.stats_rank_stride, a.center, a.nbobs_k, a.iner, t);
         __syncthreads();
     }
     if (a.mode != 0) {

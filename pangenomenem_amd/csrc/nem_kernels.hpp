@@ -57,6 +57,9 @@ struct SweepArgs {
     int post_on, post_from_guess, post_moved, post_nw64;
     uint64_t* post_mask; int* post_flags;
     CtrlArgs post_ctrl;
+    // sharded runs: the last block to finish stores this rank's "some label changed in this round" byte behind
+    // its label block (the label all-gather then carries it to every rank)
+    uint8_t* publish_byte; int* publish_ticket;
 };
 void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s);
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
@@ -69,7 +72,8 @@ void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, in
 struct FinishArgs {
     int mode;                      // 0: tables only; 1: NCEM centres from counts + dispersion + tables; 2: dispersion + tables
     int K, D, dpad, n_total, disper, propor;
-    const int* stats;
+    const int* stats;              // NCEM counts {N_k, S1[k][d]}: stats_ranks partial arrays, stats_rank_stride ints apart
+    int stats_ranks, stats_rank_stride;   // (1, 0 on a single GPU; sharded: every rank's partial counts, summed on read)
     float* prop; float* center; float* disp; float* nbobs_k; float* iner;
     double2* tabT; double* tabL0; uint32_t* nz0; uint32_t* nz1;
     uint32_t* am0; uint32_t* am1; double2* uni; int* nonuni;

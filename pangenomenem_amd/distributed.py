@@ -5,8 +5,6 @@ organism chunks, ppanggolin/ppanggolin.py:1039-1095); this module shards ONE NEM
 SURVEY.md §8(e) lays out, for NCEM (hard labels), where every M-step sum is an integer count and
 therefore exact under any reduction order:
 
-  * M-step: each rank popcounts its shard -> int32 statistics {N_k, S1[k][d]} ->
-    ONE all-reduce(sum) over RCCL/xGMI -> every rank derives mu, epsilon, pi locally.
   * E-step density (E1): embarrassingly parallel over the shard.
   * E-step sweep (E2): the Gauss-Seidel sweep is solved by relaxation rounds (k_sweep in
     csrc/nem_kernels.hip); a round only needs the other shards' labels of the previous round, so each
@@ -14,6 +12,13 @@ therefore exact under any reduction order:
     rank's "a label changed" byte, so the same all-gather tells every rank whether another round is
     needed -- no separate flag collective and no host round trip.  The fixed point is the global
     sequential sweep of the reference, so labels are bit-identical to a single-GPU run.
+  * M-step: each rank popcounts its shard -> int32 statistics {N_k, S1[k][d]}, stored behind the flag
+    byte in the block's tail; the all-gather that closes the iteration's LAST relaxation round carries
+    them, and every rank sums the world partial arrays while deriving mu, epsilon, pi (integer sums:
+    exact in any order).  They are counted from the labels of the round before (while the last,
+    verifying round runs), which are final exactly when that round changes nothing -- and when it does,
+    the pipeline stops anyway and the host redoes the statistics.  So an EM iteration costs TWO
+    collectives (one with beta = 0) and no all-reduce.
   * Loop control runs on the device (k_ctrl logic, identical data on every rank => identical
     decisions); the host enqueues a batch of whole iterations, collectives included, and synchronises
     once per batch.
@@ -26,7 +31,7 @@ backend (tests/test_distributed.py plugs the CPU oracle in as the stepper).
 import numpy as np
 
 STATUS_OK, STATUS_W_EMPTYCLASS = 0, 2
-FLAG_TAIL = 16          # bytes behind every rank's label block (byte 0 = "changed" flag), keeps 16-B alignment
+FLAG_TAIL = 16          # bytes between a rank's label block (rounded up to 16) and its statistics (byte `blk` = "changed" flag)
 
 
 def shard_bounds(n_total, world, rank):
@@ -37,11 +42,17 @@ def shard_bounds(n_total, world, rank):
     return lo, hi, blk
 
 
-def slot_layout(n_total, world):
-    """Label arrays: rank r owns slots [r*stride, r*stride+blk); stride = blk rounded up to 16 + FLAG_TAIL."""
+def slot_layout(n_total, world, stats_words=0):
+    """Label arrays: rank r owns slots [r*stride, r*stride+blk); behind them the flag byte (at blk) and, from
+    stats_offset(blk) on, the rank's int32 statistics; stride is a multiple of 16."""
     blk = (n_total + world - 1) // world
-    stride = (blk + 15) // 16 * 16 + FLAG_TAIL
+    stride = stats_offset(blk) + (4 * stats_words + 15) // 16 * 16
     return blk, stride
+
+
+def stats_offset(blk):
+    """Byte offset of a rank's statistics inside its block of a label array."""
+    return (blk + 15) // 16 * 16 + FLAG_TAIL
 
 
 def family_to_slot(idx, blk, stride):
@@ -108,7 +119,8 @@ class GpuStepper:
         self.torch = torch
         self.device = torch.device("cuda", device)
         d = x_local.shape[1]
-        blk, stride = slot_layout(n_total, world)
+        blk, stride = slot_layout(n_total, world, k + k * d)
+        self.rank, self.blk, self.stride = rank, blk, stride
         # one dedicated (non-default) stream carries this rank's kernels AND the collectives torch issues for
         # it, so everything is stream-ordered and the whole batch can be captured into a graph
         self.stream = torch.cuda.Stream(self.device)
@@ -137,12 +149,21 @@ class GpuStepper:
     def begin(self):
         self.eng.shard_begin()
 
-    def mstep_partial(self, labels, stats):
-        self.eng.shard_mstep_partial(labels.data_ptr(), stats.data_ptr())
+    def _own_stats_ptr(self, buf):
+        return buf.data_ptr() + self.rank * self.stride + stats_offset(self.blk)
 
-    def estep_round0(self, stats, beta, sweep_id, old, out):
-        self.eng.shard_estep_round0(stats.data_ptr() if stats is not None else None, beta, sweep_id, old.data_ptr(),
-                                    out.data_ptr())
+    def mstep_partial(self, labels, dst):
+        """partial counts of this rank's families under `labels` -> own statistics tail of label array `dst`"""
+        self.eng.shard_mstep_partial(labels.data_ptr(), self._own_stats_ptr(dst))
+
+    def counts(self, dst):
+        """the same for the labels the last estep_round0 produced (their class masks already exist)"""
+        self.eng.shard_counts(self._own_stats_ptr(dst))
+
+    def estep_round0(self, stats_src, beta, sweep_id, old, out):
+        """stats_src: all-gathered label array whose tails hold every rank's partial statistics, or None"""
+        ptr = stats_src.data_ptr() + stats_offset(self.blk) if stats_src is not None else None
+        self.eng.shard_estep_round0(ptr, beta, sweep_id, old.data_ptr(), out.data_ptr())
 
     def estep_round1(self, beta, sweep_id, old, guess, out):
         self.eng.shard_estep_round1(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr())
@@ -197,13 +218,16 @@ class ShardedNem:
     def __init__(self, stepper, comm, n_total, beta, cvtest="clas", cvthres=1e-8, param_fix=False):
         self.st, self.comm = stepper, comm
         self.n_total = n_total
-        self.blk, self.stride = slot_layout(n_total, comm.world)
+        self.blk, self.stride = slot_layout(n_total, comm.world, stepper.stats_words())
         self.lo, self.hi, _ = shard_bounds(n_total, comm.world, comm.rank)
         self.beta, self.cvtest, self.cvthres, self.param_fix = float(beta), cvtest, float(cvthres), param_fix
         self.labels = [stepper.alloc(self.stride * comm.world, "uint8") for _ in range(3)]
-        self.stats = stepper.alloc(stepper.stats_words(), "int32")
         import os
-        self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", "1") != "0"
+        # whole-batch graph capture (kernels + collectives): on by default for a 1-rank group; with more ranks it
+        # is opt-in (NEM_DIST_GRAPHS=1) because captured RCCL collectives could not be rehearsed on the one-GPU
+        # development box and a wedged replay would cost the whole job, while eager launches are only ~1.7x slower
+        default = "1" if comm.world == 1 else "0"
+        self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", default) != "0"
         self._graphs, self._seen = {}, set()
         self.reset()
 
@@ -223,30 +247,49 @@ class ShardedNem:
         return t.reshape(self.comm.world, self.stride)[:, :self.blk]
 
     # ---- enqueue helpers (no host synchronisation)
+    def _stats_buf(self, cur):
+        """Which label array's tails hold the statistics of the partition in buffer `cur`: the array gathered
+        last in the iteration that produced it (its R buffer with a graph, the partition's own buffer without)."""
+        return (cur + 1) % 3 if self.beta != 0.0 else cur
+
     def _enqueue_init(self):
-        L, use_nei = self.labels, self.beta != 0.0
+        L, use_nei, want_stats = self.labels, self.beta != 0.0, not self.param_fix
         self.st.estep_round0(None, 0.0, 0, L[0], L[1])                    # blind beta = 0 sweep (nem_alg.c:1972-1976)
         self.comm.allgather_blocks_(L[1], self.stride)
         self.st.estep_round0(None, self.beta, 1, L[1], L[2])              # the sweep with the real beta (:1980)
+        if want_stats and not use_nei:
+            self.st.counts(L[2])
         self.comm.allgather_blocks_(L[2], self.stride)
         if use_nei:
             self.st.estep_round1(self.beta, 1, L[1], L[2], L[0])
+            if want_stats:
+                self.st.counts(L[0])                                      # statistics of L[2], riding with L[0]
             self.comm.allgather_blocks_(L[0], self.stride)
         self.st.finish_iteration(self.beta, 1, L[1], L[2], L[0])
 
     def _enqueue_iteration(self, P):
         L, Q, R = self.labels, (P + 1) % 3, (P + 2) % 3
-        stats = None
-        if not self.param_fix:                                            # nem_alg.c:1806
-            self.st.mstep_partial(L[P], self.stats)
-            self.comm.allreduce_sum_(self.stats)
-            stats = self.stats
-        self.st.estep_round0(stats, self.beta, -1, L[P], L[Q])
+        use_nei, want_stats = self.beta != 0.0, not self.param_fix        # (parameters fixed: nem_alg.c:1806)
+        self.st.estep_round0(L[self._stats_buf(P)] if want_stats else None, self.beta, -1, L[P], L[Q])
+        if want_stats and not use_nei:
+            self.st.counts(L[Q])
         self.comm.allgather_blocks_(L[Q], self.stride)
-        if self.beta != 0.0:
+        if use_nei:
             self.st.estep_round1(self.beta, -1, L[P], L[Q], L[R])
+            if want_stats:
+                self.st.counts(L[R])                                      # statistics of L[Q], riding with L[R]
             self.comm.allgather_blocks_(L[R], self.stride)
         self.st.finish_iteration(self.beta, 0, L[P], L[Q], L[R])
+
+    def _publish_stats(self, cur):
+        """Statistics of the partition in buffer `cur`, recomputed and gathered explicitly (after the host had
+        to finish a sweep, i.e. when the speculative ones of the pipeline were counted on non-final labels)."""
+        if self.param_fix:
+            return
+        dst = self.labels[self._stats_buf(cur)]
+        with self.st.on_stream():
+            self.st.mstep_partial(self.labels[cur], dst)
+            self.comm.allgather_blocks_(dst, self.stride)
 
     def _finish_sweep_on_host(self, P, sweep_id):
         """A sweep that needed more than two relaxation rounds: continue them with a host check per round."""
@@ -280,6 +323,9 @@ class ShardedNem:
         graph = self._graphs.get(key)
         if graph is None and self.use_graphs and getattr(self.st, "can_capture", False) and key in self._seen:
             graph = self.st.capture(lambda: self._enqueue_batch(with_init, g, base))
+            # every rank must take the same route: captured only if the capture worked everywhere
+            if self.comm.world > 1 and self.comm.allreduce_max_int(0 if graph is not None else 1) != 0:
+                graph = None
             if graph is None:
                 self.use_graphs = False
             else:
@@ -298,6 +344,7 @@ class ShardedNem:
             self._finish_sweep_on_host(1, 1)
             self.cur, self.sweep_id = 2, 2
             self.st.set_sweep_number(2)
+            self._publish_stats(2)
             return 0
         self.iters += res["iters"]
         self.cur = (base + res["commits"]) % 3
@@ -310,6 +357,7 @@ class ShardedNem:
             P = self.cur
             new = self._finish_sweep_on_host(P, s0 + res["iters"] - 1)
             self.cur = new
+            self._publish_stats(new)
             if self.cvtest == "clas":                                     # HasConverged, nem_alg.c:2075-2089
                 with self.st.on_stream():
                     moved = not bool((self._block_view(self.labels[new]) == self._block_view(self.labels[P])).all().item())
@@ -370,7 +418,7 @@ class ShardedNem:
             raise ValueError("the sharded path is NCEM-only (fuzzy sums are order-dependent, SURVEY.md §8e)")
         n_total = n_loc * world
         lo, hi, _ = shard_bounds(n_total, world, rank)
-        blk, stride = slot_layout(n_total, world)
+        blk, stride = slot_layout(n_total, world, k + k * d)
         x_local, _ = synth.bernoulli_pa_matrix(hi - lo, d, 2 + 1000 * rank)
         nei = slice_graph(synth.contiguity_graph(n_total, 2), lo, hi, blk, stride)
         prop, center, disp = synth.default_init(d)

@@ -82,6 +82,7 @@ def load_library():
     lib.nemgpu_shard_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.nemgpu_shard_begin.argtypes = [vp]
     lib.nemgpu_shard_mstep_partial.argtypes = [vp, vp, vp]
+    lib.nemgpu_shard_counts.argtypes = [vp, vp]
     lib.nemgpu_shard_estep_round0.argtypes = [vp, vp, C.c_float, C.c_int, vp, vp]
     lib.nemgpu_shard_estep_round1.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
     lib.nemgpu_shard_finish_iteration.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
@@ -268,6 +269,9 @@ class NemEngine:
 
     def shard_mstep_partial(self, labels_ptr, stats_ptr):
         self._chk(self.lib.nemgpu_shard_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
+
+    def shard_counts(self, stats_ptr):
+        self._chk(self.lib.nemgpu_shard_counts(self._h, C.c_void_p(stats_ptr)))
 
     def shard_estep_round0(self, stats_ptr, beta, sweep_id, old_ptr, out_ptr):
         self._chk(self.lib.nemgpu_shard_estep_round0(self._h, C.c_void_p(stats_ptr) if stats_ptr else None,

@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: world_size-2 (and 3) torch.distributed/gloo runs of the sharded EM driver
 (pangenomenem_amd/distributed.py) with the CPU oracle plugged in as the local stepper.  Checks the
-protocol -- shard bounds, label all-gather per relaxation round, integer statistics all-reduce,
-convergence / empty-class handling -- against the single-process oracle on the global problem."""
+protocol -- shard bounds, label all-gather per relaxation round, integer statistics riding in the label
+blocks' tails, convergence / empty-class handling -- against the single-process oracle on the global problem."""
 import os
 import sys
 import tempfile
@@ -20,13 +20,14 @@ class OracleStepper:
     def __init__(self, oracle, x_local, nei_slots, k, n_total, world, rank, prop, center, disp, beta, seed=0,
                  cvtest="clas", cvthres=1e-8):
         import torch
-        from pangenomenem_amd.distributed import slot_layout
+        from pangenomenem_amd.distributed import slot_layout, stats_offset
         self.torch, self.o = torch, oracle
         self.x, self.nei, self.k, self.n_total, self.world, self.rank = x_local, nei_slots, k, n_total, world, rank
-        self.blk, self.stride = slot_layout(n_total, world)
-        self.lo = rank * self.stride
         self.n = x_local.shape[0]
         self.d = x_local.shape[1]
+        self.blk, self.stride = slot_layout(n_total, world, k + k * self.d)
+        self.soff = stats_offset(self.blk)
+        self.lo = rank * self.stride
         self.p0 = (np.array(prop, np.float32), np.array(center, np.float32), np.array(disp, np.float32))
         self.seed, self.cvtest, self.cvthres, self.beta = seed, cvtest, cvthres, beta
         self.reset()
@@ -65,6 +66,7 @@ class OracleStepper:
     def end(self):
         out = dict(self.c)
         out["converged"] = bool(out["converged"])
+        self.c["stop"] = 0                      # (the engine's stop word only gates kernels of the batch)
         return out
 
     def _onehot(self, lab):
@@ -73,19 +75,32 @@ class OracleStepper:
         c[np.flatnonzero(valid), lab[valid]] = 1.0
         return c
 
-    def mstep_partial(self, labels, stats):
-        if self.c["stop"]:
-            return
-        lab = labels.numpy()[self.lo:self.lo + self.n]
-        s = stats.numpy()
+    def _tail(self, buf, rank):
+        """int32 view of rank's statistics inside label array `buf`"""
+        words = self.k + self.k * self.d
+        off = rank * self.stride + self.soff
+        return buf.numpy()[off:off + 4 * words].view(np.int32)
+
+    def _counts_into(self, lab, dst):
+        s = self._tail(dst, self.rank)
         for c in range(self.k):
             m = lab == c
             s[c] = int(m.sum())
             s[self.k + c * self.d:self.k + (c + 1) * self.d] = self.x[m].sum(0)
 
-    def _finalize(self, stats):
-        """k_finish mode 1 (sk_/pk) restated in numpy on the GLOBAL counts."""
-        s = stats.numpy()
+    def mstep_partial(self, labels, dst):
+        if self.c["stop"]:
+            return
+        self._counts_into(labels.numpy()[self.lo:self.lo + self.n], dst)
+
+    def counts(self, dst):
+        if self.c["stop"]:
+            return
+        self._counts_into(self.last_out, dst)
+
+    def _finalize(self, stats_src):
+        """k_finish mode 1 (sk_/pk) restated in numpy on the GLOBAL counts (sum of every rank's tail)."""
+        s = sum(self._tail(stats_src, r).astype(np.int64) for r in range(self.world))
         k, d = self.k, self.d
         ek = 0
         iner = np.zeros((k, d), np.float32)
@@ -133,6 +148,7 @@ class OracleStepper:
             self.pk, _, _ = self.o.density(self.x, self.prop, self.center, self.disp)
         self.changed = [self._round(beta, sweep_id, old, old, out), 0]
         out.numpy()[self.lo + self.blk] = self.changed[0]
+        self.last_out = out.numpy()[self.lo:self.lo + self.n].copy()
 
     def estep_round1(self, beta, sweep_id, old, guess, out):
         if self.c["stop"]:
@@ -200,7 +216,7 @@ def _worker(rank, world, initfile, n, d, beta, kind, outdir):
         nei = synth.contiguity_graph(n, 1)
         prop, center, disp = synth.default_init(d)
         lo, hi, _ = shard_bounds(n, world, rank)
-        blk, stride = slot_layout(n, world)
+        blk, stride = slot_layout(n, world, 3 + 3 * d)
         st = OracleStepper(Oracle(), x[lo:hi], slice_graph(nei, lo, hi, blk, stride), 3, n, world, rank, prop, center,
                            disp, beta, seed=11)
         job = ShardedNem(st, Comm(), n, beta, cvtest="clas", cvthres=1e-8)

@@ -27,7 +27,7 @@ def _worker(rank, world, backend, initfile, n, d, beta, outdir):
         nei = synth.contiguity_graph(n, 1)
         prop, center, disp = synth.default_init(d)
         lo, hi, _ = shard_bounds(n, world, rank)
-        blk, stride = slot_layout(n, world)
+        blk, stride = slot_layout(n, world, 3 + 3 * d)
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="clas", seed=11)
         st = GpuStepper(x[lo:hi], slice_graph(nei, lo, hi, blk, stride), 3, n, world, rank, prop, center, disp, 0, cfg)
         job = ShardedNem(st, Comm(), n, beta, cvtest="clas", cvthres=1e-8)
