@@ -101,7 +101,8 @@ def main():
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
-    nem_build.build()
+    if world == 1:
+        nem_build.build()                          # no-op when the in-tree library is up to date
     n_loc, d, k, beta = args.families, args.organisms, 3, 0.5
     n_tot = n_loc * world
 
@@ -148,6 +149,10 @@ def main():
         if "RANK" not in os.environ:              # plain `python bench.py --dist`: a 1-rank group
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1:                             # one rank checks / rebuilds the library, the others wait for it
+            if rank == 0:
+                nem_build.build()
+            dist.barrier()
         job = nd.ShardedNem.synthetic(n_loc, d, k, beta, rank, world, local_rank, algo=args.algo)
         cycle = job.iters_to_converge()
         job.run_steps(args.warmup, cycle)
