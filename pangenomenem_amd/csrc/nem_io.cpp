@@ -115,9 +115,27 @@ int read_dat_file(const std::string& base, NemInputs& in, std::string& err)
     const int n = in.n, d = in.d, wf = (d + 31) / 32;
     in.xbits.assign((size_t)n * wf, 0u);
     const char* p = buf.data();
+    const char* const bend = buf.data() + buf.size() - 1;        // the terminating NUL slurp() appended
     for (int i = 0; i < n; i++) {
         uint32_t* row = in.xbits.data() + (size_t)i * wf;
-        for (int j = 0; j < d; j++) {
+        int j = 0;
+        // Row fast path for the text ppanggolin.py:850 writes -- one character per value, one tab between values,
+        // a newline at the end ("0\t1\t...\t1\n"): 4 values per 8-byte load, validated and packed with integer
+        // arithmetic.  Anything else in the row (spaces, "1.0", blank lines) leaves the rest to the tokeniser below.
+        if ((size_t)(bend - p) >= 2 * (size_t)d) {
+            for (; j + 4 <= d; j += 4) {
+                uint64_t w;
+                memcpy(&w, p + 2 * (size_t)j, 8);
+                const bool last = (j + 4 == d);
+                const uint64_t seps = last ? 0x0A00090009000900ull : 0x0900090009000900ull;
+                if ((w & 0xFFFEFFFEFFFEFFFEull) != (0x0030003000300030ull | seps)) break;
+                const uint32_t nib = (uint32_t)(((w & 0x0001000100010001ull) * 0x0001000200040008ull) >> 48) & 0xFu;
+                row[j >> 5] |= nib << (j & 31);                 // j % 4 == 0: the nibble never straddles a word
+            }
+            if (j == d) { p += 2 * (size_t)d; continue; }
+            p += 2 * (size_t)j;                                  // values [0, j) are consumed (each "v\t")
+        }
+        for (; j < d; j++) {
             while (is_space(*p)) p++;
             if (!*p) {
                 char msg[256];

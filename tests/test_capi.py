@@ -140,3 +140,39 @@ def test_reader_quirks_and_errors(lib, tmp_path):
     open(base + ".dat", "w").write("1 0 2\n0 0 1\n1 1 0\n0 0 0\n")
     with pytest.raises(engine.NemGpuError, match="0/1"):
         engine.read_inputs(base, 3)
+
+
+def test_dat_reader_fast_path_agrees_with_the_tokeniser(lib, tmp_path):
+    """The .dat reader packs 4 values per 8-byte load when a row is the text ppanggolin.py:850 writes
+    ("0\\t1\\t...\\n"); every other spelling of the same numbers must fall back and give the same bits."""
+    from pangenomenem_amd import engine
+    rng = np.random.default_rng(5)
+    base = str(tmp_path / "f")
+    m = "1 0.3 0.3 " + " ".join(["1"] * 9 + ["0.5"] * 9 + ["0"] * 9) + " " + " ".join(["0.1"] * 27)
+    for d in (1, 2, 3, 4, 5, 7, 8, 9, 33, 64, 67):
+        n = 23
+        x = (rng.random((n, d)) < 0.5).astype(np.uint8)
+        open(base + ".str", "w").write("S\t%d\t%d\n" % (n, d))
+        open(base + ".nei", "w").write("1\n" + "".join("%d\t0\n" % (i + 1) for i in range(n)))
+        k3 = "1 0.3 0.3 " + " ".join(["1"] * d + ["0.5"] * d + ["0"] * d) + " " + " ".join(["0.1"] * (3 * d))
+        open(base + ".m", "w").write(k3)
+        rows = ["\t".join(str(v) for v in r) for r in x]
+        variants = {
+            "tabs": "\n".join(rows) + "\n",
+            "no final newline": "\n".join(rows),
+            "crlf": "\r\n".join(rows) + "\r\n",
+            "spaces": "\n".join(r.replace("\t", " ") for r in rows) + "\n",
+            "mixed": "\n".join((r if i % 2 else r.replace("\t", "  ")) for i, r in enumerate(rows)) + "\n",
+            "floats in one row": "\n".join((r if i != 3 else r.replace("1", "1.0")) for i, r in enumerate(rows)) + "\n",
+            "one long line": "\t".join(rows) + "\n",
+            "blank lines": "\n\n".join(rows) + "\n\n",
+        }
+        for name, text in variants.items():
+            open(base + ".dat", "w", newline="").write(text)
+            got = engine.read_inputs(base, 3)
+            assert np.array_equal(got["x"], x), (d, name)
+    # a 2 hidden behind the fast path's mask must still be rejected
+    open(base + ".dat", "w").write("\n".join("\t".join("2" if (i, j) == (5, 1) else "0" for j in range(67)) for i in range(23)) + "\n")
+    with pytest.raises(engine.NemGpuError, match="0/1"):
+        engine.read_inputs(base, 3)
+    del m

@@ -1,0 +1,71 @@
+"""The drop-in `nem()` at BASELINE configs[1] size, called the way ppanggolin.py:1814-1826 calls it, next to the
+compiled reference's own `nem()` on the same five ASCII files (oracle/_ref travels to the GPU box).  Checks the
+files byte for byte and records both whole-call times (parse + EM + write) under gpurun_out/ when it can."""
+import json
+import os
+import shutil
+import time
+
+import numpy as np
+import pytest
+
+from pangenomenem_amd import nemfiles, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _call(fn, base, k):
+    t0 = time.perf_counter()
+    rc = fn(base.encode(), k, b"ncem", 0.5, b"clas", 1e-8, b"fuzzy", 100, True, b"bern", b"pk", b"sk_", 2)
+    return rc, time.perf_counter() - t0
+
+
+def test_dropin_whole_call_at_configs1(gpu_lib, tmp_path):
+    from oracle import pyoracle
+    if not pyoracle.have_reference():
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    import nem as nem_module
+    cfg = synth.make_config("C2")
+    ours_dir, ref_dir = str(tmp_path / "ours"), str(tmp_path / "ref")
+    t0 = time.perf_counter()
+    base = nemfiles.write_nem_inputs(ours_dir, cfg["x"], cfg["nei"], cfg["prop"], cfg["center"], cfg["disp"])
+    t_write = time.perf_counter() - t0
+    shutil.copytree(ours_dir, ref_dir)
+    ref_base = os.path.join(ref_dir, "nem_file")
+
+    _call(nem_module.nem, base, 3)                            # first call: library load, context creation
+    rc, t_ours = _call(nem_module.nem, base, 3)
+    assert rc == 0
+    ref = pyoracle.Reference()
+    rc_ref, t_ref = _call(ref.nem, ref_base, 3)
+    assert rc_ref == 0
+
+    # tie-free data: the reference's time-seeded random() never fires, the files must agree
+    assert open(base + ".uf", "rb").read() == open(ref_base + ".uf", "rb").read()
+    got, want = open(base + ".mf", "rb").read().split(b"\n"), open(ref_base + ".mf", "rb").read().split(b"\n")
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        if i == 2:                                            # criteria line: print precision, device exp/log
+            ta, tb = a.split(), b.split()
+            assert len(ta) == len(tb)
+            for u, v in zip(ta[:4], tb[:4]):
+                assert abs(float(u) - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (a, b)
+        else:
+            assert a == b, (i, a[:80], b[:80])
+    labels, params, _, _ = nemfiles.read_nem_outputs(ours_dir, cfg["x"].shape[1], q=3)
+    assert len(labels) == cfg["x"].shape[0]
+
+    rec = dict(workload="BASELINE configs[1] files: 20000 x 500, K=3, beta=0.5, ncem/sk_/pk, dolog=1",
+               input_bytes=sum(os.path.getsize(base + e) for e in (".str", ".dat", ".nei", ".m")),
+               reference_nem_whole_call_s=t_ref, this_library_nem_whole_call_s=t_ours,
+               speedup_whole_call=t_ref / t_ours, python_input_write_s=t_write, host_cores_used=1)
+    print(json.dumps(rec))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r01_dropin_whole_call.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+    assert t_ours < t_ref
