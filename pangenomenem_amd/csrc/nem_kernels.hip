@@ -1331,8 +1331,18 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
     const uint32_t* col = xw + (size_t)dw * npad;
     const float nk = nbobs_k[k];
     const int t = k * D + dc;
-    if (!((double)nk > kEpsilonD)) {                     // empty class: centre kept, inertia of an all-zero column
-        if (d < D) iner[t] = 0.0f;                       // (c == 0 everywhere for practical purposes)
+    if (!((double)nk > kEpsilonD)) {
+        // "empty" class (nem_mod.c:1404-1408): the centre is kept, and EstimLaplaceIner (:1669-1686) still runs
+        // against that old centre -- the class may hold weights between 0 and EPSILON, which InerToDisp* then
+        // turns into a dispersion (they test N_K > 0, not > EPSILON)
+        const float mu = center[t];
+        float in = 0.0f;
+        for (int i = 0; i < n; i++) {
+            const float ci = c[(size_t)i * K + k];
+            const float xij = ((col[i] >> db) & 1u) ? 1.0f : 0.0f;
+            in = (float)((double)in + (double)ci * fabs((double)(xij - mu)));     // :1683
+        }
+        if (d < D) iner[t] = in;
         return;
     }
     const float half = nk / 2;                           // nem_mod.c:1439

@@ -1,0 +1,114 @@
+"""Edge cases of the hot path on the GPU against the oracle: ragged and tiny sizes (tile / wave / word boundaries),
+many classes (the run-time-K kernels), wide matrices on every dispersion model, graph-less smoothing, fixed
+parameters, isolated families."""
+import numpy as np
+import pytest
+
+from pangenomenem_amd import synth
+from tests.util import maxdiff
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def same_run(got, want, algo):
+    assert got["status"] == want["status"], (got["status"], want["status"])
+    assert got["iters"] == want["iters"]
+    assert got["converged"] == want["converged"]
+    if want["status"] == 2:
+        assert got["emptyk"] == want["emptyk"]
+    assert np.array_equal(got["c"].argmax(1), want["c"].argmax(1))
+    if algo == "ncem":
+        assert np.array_equal(got["c"], want["c"])
+    assert maxdiff(got["c"], want["c"]) <= TOL
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, key
+    assert np.array_equal(got["center"], want["center"])
+
+
+def run_both(oracle, x, nei, k, prop, center, disp, **cfg):
+    from pangenomenem_amd.engine import solve
+    got = solve(x, nei, k, prop, center, disp, tie="hash", seed=3, **cfg)
+    want = oracle.run(x, nei, k, prop, center, disp, tie="hash", seed=3, **cfg)
+    same_run(got, want, cfg.get("algo", "ncem"))
+    return got
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1025])
+@pytest.mark.parametrize("algo", ["ncem", "nem"])
+def test_ragged_family_counts(gpu_lib, oracle, n, algo):
+    d = 40
+    x, _ = synth.bernoulli_pa_matrix(n, d, 100 + n)
+    nei = synth.contiguity_graph(n, 7) if n > 1 else None
+    prop, center, disp = synth.default_init(d)
+    run_both(oracle, x, nei, 3, prop, center, disp, algo=algo, beta=0.5, disper="sk_", it_max=8)
+
+
+@pytest.mark.parametrize("d", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257])
+def test_ragged_organism_counts(gpu_lib, oracle, d):
+    n = 700
+    x, _ = synth.bernoulli_pa_matrix(n, d, 200 + d)
+    nei = synth.contiguity_graph(n, 9)
+    prop, center, disp = synth.default_init(d)
+    for disper in ("sk_", "skd"):
+        run_both(oracle, x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper=disper, it_max=6)
+
+
+@pytest.mark.parametrize("k", [11, 12, 17])
+@pytest.mark.parametrize("algo", ["ncem", "nem"])
+def test_many_classes_take_the_runtime_k_kernels(gpu_lib, oracle, k, algo):
+    n, d = 3000, 60
+    x, _ = synth.grouped_pa_matrix(n, d, 31, groups=20)
+    nei = synth.contiguity_graph(n, 31)
+    prop, center, disp = synth.kclass_init(x, k)
+    run_both(oracle, x, nei, k, prop, center, disp, algo=algo, beta=0.3, disper="skd", it_max=5)
+
+
+@pytest.mark.parametrize("disper", ["sk_", "skd", "s__", "s_d"])
+@pytest.mark.parametrize("algo", ["ncem", "nem"])
+def test_wide_matrix_every_dispersion_model(gpu_lib, oracle, disper, algo):
+    # D > 1024: parameter update in k_finish, density in k_density (uniform and per-organism chains)
+    n, d = 600, 1300
+    x, _ = synth.bernoulli_pa_matrix(n, d, 77)
+    nei = synth.contiguity_graph(n, 77)
+    prop, center, disp = synth.default_init(d, low_disp=0.3)          # high dispersions: densities stay above underflow
+    run_both(oracle, x, nei, 3, prop, center, disp, algo=algo, beta=0.5, disper=disper, it_max=4)
+
+
+def test_no_graph_with_positive_beta_and_isolated_families(gpu_lib, oracle):
+    n, d = 900, 25
+    x, _ = synth.bernoulli_pa_matrix(n, d, 5)
+    prop, center, disp = synth.default_init(d)
+    run_both(oracle, x, None, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=10)
+    # a graph in which most families have no neighbour at all
+    ptr = np.zeros(n + 1, np.int32)
+    idx, w = [], []
+    for i in range(0, n - 1, 50):
+        idx += [i + 1]; w += [2.0]
+        ptr[i + 1:] += 1
+    nei = (ptr, np.array(idx, np.int32), np.array(w, np.float32))
+    run_both(oracle, x, nei, 3, prop, center, disp, algo="ncem", beta=1.5, disper="sk_", it_max=10)
+    run_both(oracle, x, nei, 3, prop, center, disp, algo="nem", beta=1.5, disper="skd", it_max=6)
+
+
+@pytest.mark.parametrize("algo", ["ncem", "nem"])
+def test_fixed_parameters(gpu_lib, oracle, algo):
+    # .m flag 2: parameters are never re-estimated (nem_alg.c:1806); only the E-step iterates
+    n, d = 1500, 33
+    x, _ = synth.bernoulli_pa_matrix(n, d, 8)
+    nei = synth.contiguity_graph(n, 8)
+    prop, center, disp = synth.default_init(d)
+    run_both(oracle, x, nei, 3, prop, center, disp, algo=algo, beta=0.8, disper="sk_", it_max=7, param_fix=True)
+
+
+def test_all_identical_families_and_constant_columns(gpu_lib, oracle):
+    n, d = 500, 48
+    x = np.zeros((n, d), np.uint8)
+    x[:, ::3] = 1                                                        # every family the same row
+    nei = synth.contiguity_graph(n, 2)
+    prop, center, disp = synth.default_init(d)
+    for tie in ("hash", "first"):
+        from pangenomenem_amd.engine import solve
+        got = solve(x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=6, tie=tie, seed=9)
+        want = oracle.run(x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=6, tie=tie, seed=9)
+        same_run(got, want, "ncem")
