@@ -124,18 +124,27 @@ struct nemgpu_engine {
 
 namespace {
 
+// Every memory operation of an engine is ordered on ITS stream (a non-blocking one) and never touches the legacy
+// default stream: several engines may run on different host threads at once (pangenomenem_amd/batch.py), and a
+// legacy-stream operation of one thread would collide with a graph capture in progress on another.
+thread_local hipStream_t g_alloc_stream = nullptr;      // stream of the engine whose buffers are being allocated
+
 template <typename T>
 int dev_alloc(T** p, size_t count)
 {
     *p = nullptr;
     if (count == 0) count = 1;
     HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
-    HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+    HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), g_alloc_stream));   // (every later use is on the same stream)
     return NEMGPU_OK;
 }
 
+// blocking copy on the engine's stream
+hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+
 int ensure_state_buffers(nemgpu_engine* e)
 {
+    g_alloc_stream = e->stream;
     if (e->ncem()) {
         for (int b = 0; b < 3; b++)
             if (!e->lab[b]) { int r = dev_alloc(&e->lab[b], (size_t)e->n_total); if (r) return r; }
@@ -152,6 +161,13 @@ int ensure_state_buffers(nemgpu_engine* e)
         }
     }
     return NEMGPU_OK;
+}
+
+hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    hipError_t err = hipMemcpyAsync(dst, src, bytes, kind, e->stream);
+    if (err != hipSuccess) return err;
+    return hipStreamSynchronize(e->stream);
 }
 
 FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
@@ -609,6 +625,7 @@ void drop_graphs(nemgpu_engine* e)
 
 int ensure_crit_buffers(nemgpu_engine* e)
 {
+    g_alloc_stream = e->stream;
     int r;
     size_t nk = (size_t)e->n * e->k;
     if (!e->crit_dik) {
@@ -724,11 +741,12 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
-        if (hipStreamCreate(&e->stream) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
         e->own_stream = true;
     }
     int r = NEMGPU_OK;
     const size_t kd = (size_t)k * d, kdp = (size_t)k * e->dpad;
+    g_alloc_stream = e->stream;
     auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
     A(dev_alloc(&e->xw, (size_t)e->W * e->npad));
     A(dev_alloc(&e->xws, (size_t)((e->W + 3) / 4) * 4 * e->npad));   // uint4[ceil(W/4)][npad]
@@ -814,14 +832,21 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
 {
     if (!e || !x_host) return NEMGPU_E_FUNCARG;
     std::vector<uint32_t> bits((size_t)e->n * e->wf, 0u);
+    uint64_t bad = 0;
     for (int i = 0; i < e->n; i++) {
         const uint8_t* row = x_host + (size_t)i * e->d;
         uint32_t* out = bits.data() + (size_t)i * e->wf;
-        for (int j = 0; j < e->d; j++) {
-            if (row[j] > 1) { set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
-            out[j >> 5] |= (uint32_t)row[j] << (j & 31);
+        int j = 0;
+        for (; j + 8 <= e->d; j += 8) {                            // 8 values per load: bit 0 of each byte -> one byte
+            uint64_t w;
+            memcpy(&w, row + j, 8);
+            bad |= w;
+            const uint32_t b8 = (uint32_t)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            out[j >> 5] |= b8 << (j & 31);                         // j % 8 == 0: the byte never straddles a word
         }
+        for (; j < e->d; j++) { bad |= row[j]; out[j >> 5] |= (uint32_t)(row[j] & 1u) << (j & 31); }
     }
+    if (bad & 0xFEFEFEFEFEFEFEFEull) { set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
     return nemgpu_set_matrix_bits(e, bits.data());
 }
 
@@ -834,15 +859,17 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     for (int i = 0; i < e->n; i++) if (ptr[i + 1] < ptr[i]) { set_error("graph: ptr not monotone"); return NEMGPU_E_ARG; }
     for (int t = 0; t < nnz; t++)
         if (idx[t] < 0 || idx[t] >= e->n_total) { set_error("graph: neighbour index out of range"); return NEMGPU_E_ARG; }
+    HIPCHK(hipStreamSynchronize(e->stream));
     if (e->nei_ptr) { (void)hipFree(e->nei_ptr); (void)hipFree(e->nei_idx); (void)hipFree(e->nei_w); e->nei_ptr = nullptr; e->nei_idx = nullptr; e->nei_w = nullptr; }
     int r;
+    g_alloc_stream = e->stream;
     if ((r = dev_alloc(&e->nei_ptr, (size_t)e->n + 1))) return r;
     if ((r = dev_alloc(&e->nei_idx, (size_t)nnz))) return r;
     if ((r = dev_alloc(&e->nei_w, (size_t)nnz))) return r;
-    HIPCHK(hipMemcpy(e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(e, e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
-        HIPCHK(hipMemcpy(e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
     }
     e->nnz = nnz;
     e->has_graph = nnz > 0;
@@ -855,9 +882,9 @@ int nemgpu_set_params(nemgpu_engine* e, const float* prop, const float* center, 
     if (!e || !prop || !center || !disp) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     const size_t kd = (size_t)e->k * e->d;
-    HIPCHK(hipMemcpy(e->prop0, prop, sizeof(float) * e->k, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(e, e->prop0, prop, sizeof(float) * e->k, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(e, e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(e, e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
     e->have_params = true;
     return reset_state(e);
 }
@@ -1212,9 +1239,9 @@ int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)
             for (int k = 1; k < e->k; k++) if (c_nk[(size_t)i * e->k + k] > c_nk[(size_t)i * e->k + best]) best = k;
             lab[i] = (uint8_t)best;
         }
-        HIPCHK(hipMemcpy(e->lab[e->cur], lab.data(), lab.size(), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->lab[e->cur], lab.data(), lab.size(), hipMemcpyHostToDevice));
     } else {
-        HIPCHK(hipMemcpy(e->cbuf[e->cur], c_nk, sizeof(float) * (size_t)e->n_total * e->k, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->cbuf[e->cur], c_nk, sizeof(float) * (size_t)e->n_total * e->k, hipMemcpyHostToDevice));
     }
     e->masks_valid = false;
     return NEMGPU_OK;
@@ -1226,7 +1253,7 @@ int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels)
     if (!e->ncem() || !e->lab[e->cur]) { set_error("labels exist only for ncem runs"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(labels, e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(e, labels, e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
     return NEMGPU_OK;
 }
 
@@ -1238,12 +1265,12 @@ int nemgpu_get_partition(nemgpu_engine* e, float* c_nk)
     if (e->ncem()) {
         if (!e->lab[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
         std::vector<uint8_t> lab((size_t)e->n);
-        HIPCHK(hipMemcpy(lab.data(), e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(e, lab.data(), e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
         for (int i = 0; i < e->n; i++)                             // LabelToClassVector, nem_alg.c:649-664
             for (int k = 0; k < e->k; k++) c_nk[(size_t)i * e->k + k] = (lab[i] == k) ? 1.0f : 0.0f;
     } else {
         if (!e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
-        HIPCHK(hipMemcpy(c_nk, e->cbuf[e->cur] + (size_t)e->lo * e->k, sizeof(float) * (size_t)e->n * e->k,
+        HIPCHK(copy_sync(e, c_nk, e->cbuf[e->cur] + (size_t)e->lo * e->k, sizeof(float) * (size_t)e->n * e->k,
                          hipMemcpyDeviceToHost));
     }
     return NEMGPU_OK;
@@ -1255,10 +1282,10 @@ int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp,
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t kd = (size_t)e->k * e->d;
-    if (prop) HIPCHK(hipMemcpy(prop, e->prop, sizeof(float) * e->k, hipMemcpyDeviceToHost));
-    if (center) HIPCHK(hipMemcpy(center, e->center, sizeof(float) * kd, hipMemcpyDeviceToHost));
-    if (disp) HIPCHK(hipMemcpy(disp, e->disp, sizeof(float) * kd, hipMemcpyDeviceToHost));
-    if (nbobs_k) HIPCHK(hipMemcpy(nbobs_k, e->nbobs_k, sizeof(float) * e->k, hipMemcpyDeviceToHost));
+    if (prop) HIPCHK(copy_sync(e, prop, e->prop, sizeof(float) * e->k, hipMemcpyDeviceToHost));
+    if (center) HIPCHK(copy_sync(e, center, e->center, sizeof(float) * kd, hipMemcpyDeviceToHost));
+    if (disp) HIPCHK(copy_sync(e, disp, e->disp, sizeof(float) * kd, hipMemcpyDeviceToHost));
+    if (nbobs_k) HIPCHK(copy_sync(e, nbobs_k, e->nbobs_k, sizeof(float) * e->k, hipMemcpyDeviceToHost));
     return NEMGPU_OK;
 }
 
@@ -1271,12 +1298,12 @@ int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
     const size_t m = (size_t)e->k * e->npad;
     if (pkfki_nk) {
         std::vector<double> t(m);
-        HIPCHK(hipMemcpy(t.data(), e->pkfki, sizeof(double) * m, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(e, t.data(), e->pkfki, sizeof(double) * m, hipMemcpyDeviceToHost));
         for (int i = 0; i < e->n; i++) for (int k = 0; k < e->k; k++) pkfki_nk[(size_t)i * e->k + k] = t[(size_t)k * e->npad + i];
     }
     if (logpkfki_nk) {
         std::vector<float> t(m);
-        HIPCHK(hipMemcpy(t.data(), e->logpkfki, sizeof(float) * m, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(e, t.data(), e->logpkfki, sizeof(float) * m, hipMemcpyDeviceToHost));
         for (int i = 0; i < e->n; i++) for (int k = 0; k < e->k; k++) logpkfki_nk[(size_t)i * e->k + k] = t[(size_t)k * e->npad + i];
     }
     return NEMGPU_OK;

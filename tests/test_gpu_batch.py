@@ -1,0 +1,49 @@
+"""Several engines at once from worker threads of one process (pangenomenem_amd/batch.py):
+same answers as one at a time, through the in-memory API and through the drop-in nem()."""
+import numpy as np
+import pytest
+
+from pangenomenem_amd import nemfiles, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(count, n=3000, d=120):
+    out = []
+    for p in range(count):
+        x, _ = synth.bernoulli_pa_matrix(n + 17 * p, d + p, 50 + p)          # different shapes on purpose
+        nei = synth.contiguity_graph(n + 17 * p, 50 + p)
+        prop, center, disp = synth.default_init(d + p)
+        out.append((x, nei, 3, prop, center, disp))
+    return out
+
+
+def test_concurrent_engines_give_the_single_engine_answers(gpu_lib, oracle):
+    from pangenomenem_amd.batch import solve_many
+    probs = _problems(12)
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", tie="hash", seed=4)
+    alone = solve_many(probs, workers=1, **cfg)
+    crowd = solve_many(probs, workers=6, **cfg)
+    for a, b, p in zip(alone, crowd, probs):
+        assert a["iters"] == b["iters"] and a["status"] == b["status"]
+        assert np.array_equal(a["c"], b["c"]) and np.array_equal(a["disp"], b["disp"])
+    want = oracle.run(*probs[3], **cfg)
+    assert np.array_equal(crowd[3]["c"], want["c"]) and crowd[3]["iters"] == want["iters"]
+
+
+def test_concurrent_dropin_calls(gpu_lib, tmp_path):
+    from pangenomenem_amd.batch import nem_many
+    probs = _problems(8, n=1500, d=60)
+    calls = []
+    for p, (x, nei, k, prop, center, disp) in enumerate(probs):
+        base = nemfiles.write_nem_inputs(str(tmp_path / str(p)), x, nei, prop, center, disp)
+        calls.append(dict(Fname=base.encode(), nk=3, algo=b"ncem", beta=0.5, convergence=b"clas", convergence_th=1e-8,
+                          format=b"fuzzy", it_max=100, dolog=True, model_family=b"bern", proportion=b"pk",
+                          dispersion=b"sk_", init_mode=2))
+    assert nem_many(calls, workers=1) == [0] * len(calls)
+    alone = [open(c["Fname"].decode() + ".uf", "rb").read() for c in calls]
+    alone_mf = [open(c["Fname"].decode() + ".mf", "rb").read() for c in calls]
+    assert nem_many(calls, workers=8) == [0] * len(calls)
+    for c, uf, mf in zip(calls, alone, alone_mf):
+        assert open(c["Fname"].decode() + ".uf", "rb").read() == uf
+        assert open(c["Fname"].decode() + ".mf", "rb").read() == mf
