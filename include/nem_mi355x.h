@@ -42,7 +42,9 @@ extern "C" {
  *   model_family   "bern" (the only family PPanGGOLiN uses; "norm"/"lapl" rejected)
  *   proportion     "p_" | "pk"
  *   dispersion     "s__" | "sk_" | "s_d" | "skd"
- *   init_mode      2 (INIT_PARAM_FILE, nem_typ.h:218); other modes rejected
+ *   init_mode      2 (INIT_PARAM_FILE, nem_typ.h:218: start from <Fname>.m) or 1 (INIT_RANDOM, :217: 50 random
+ *                  starts, best by criterion M, <Fname>.m not read; what PPanGGOLiN's partition_shell uses,
+ *                  ppanggolin.py:1207); modes 0, 3, 4 rejected
  *
  * Return value (ExitET, lib_io.h:22-34): 0 ok, 1 empty class (no output files, like the
  * reference), 2 bad arguments, 3 file error, 4 memory, 5 GPU/system error, 6 internal error.
@@ -132,6 +134,15 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg);
 
 /* Whole run: INIT_PARAM_FILE start + EM loop + final criteria (single-GPU engines only). */
 int nemgpu_run(nemgpu_engine* e, nemgpu_result* res);
+
+/* Whole run from random starts (the reference's init_mode = INIT_RANDOM, RandNemAlgo nem_alg.c:1574-1742): n_starts
+   starts (the reference uses 50), centres drawn from the data with the reference's generator -- glibc random()
+   after srandom(seed), restated in csrc/nem_rng.hpp -- best start by criterion M, EstimPara on the best partition.
+   With the same seed and tie-free data the result equals the reference's (which seeds with time(NULL)).
+   best_start: 0-based index of the chosen start, -1 if every start ended with an empty class. */
+int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
+/* Test hook: the first `count` values random() returns after srandom(seed), from the restated generator. */
+int nemgpu_glibc_random(uint32_t seed, int count, int32_t* out);
 
 /* Step-level entry points (same kernels; used by tests, bench.py and the multi-GPU host driver). */
 int nemgpu_init_partition(nemgpu_engine* e);              /* ComputePartitionFromPara(Needinit=1) */

@@ -354,7 +354,80 @@ int orc_converged(int n, int k, const float* c_nk, const float* cold_nk, float t
 }
 
 /* ----------------------------------------------------------------- loop */
+static int run_from_params(const orc_problem* p, orc_state* s, int reseed);
+
 int orc_run(const orc_problem* p, orc_state* s)
+{
+    return run_from_params(p, s, 1);
+}
+
+/* INIT_RANDOM: RandNemAlgo (nem_alg.c:1574-1742) = InitPara (:1200-1281) + n_starts x { MakeRandomPara
+   (:1381-1473), ComputePartitionFromPara, NemAlgo }, best start by the chosen criterion (DEFAULT_CRIT = M,
+   nem_typ.h:80), then EstimPara on the best partition.  The draws are libc random() after ONE srandom(seed)
+   (nem_exe.c:621), shared with the TIE_RANDOM tie-breaks exactly as in the reference. */
+int orc_run_random(const orc_problem* p, orc_state* s, int n_starts, unsigned seed, int* best_start)
+{
+    int n = p->n, d = p->d, k = p->k, h, j, i, irandom, nbsucc = 0, best = -1, err = ORC_STS_OK;
+    size_t nk = (size_t)n * k;
+    float* dispsam = (float*)malloc(sizeof(float) * d);
+    float* c1 = (float*)calloc(nk, sizeof(float));
+    float* bestc = (float*)malloc(sizeof(float) * nk);
+    float bestcrit[6] = {0, 0, 0, 0, 0, 0};
+    int best_iters = 0, best_conv = 0, ek = 0;
+
+    srandom(seed);
+    /* InitPara: dispersion of the whole sample = class 0 of an M-step with everything in class 0 */
+    for (i = 0; i < n; i++) c1[(size_t)i * k] = 1.0f;
+    orc_mstep(n, d, k, p->x, c1, p->disper, p->propor, s->prop_k, s->center_kd, s->disp_kd, s->nbobs_k,
+              s->nbobs_kd, s->iner_kd, &ek);
+    for (j = 0; j < d; j++) dispsam[j] = s->disp_kd[j];
+    free(c1);
+
+    for (irandom = 0; irandom < n_starts; irandom++) {
+        /* MakeRandomPara */
+        for (h = 0; h < k; h++) for (j = 0; j < d; j++) s->disp_kd[h * d + j] = dispsam[j] / k;      /* :1400 */
+        for (h = 0; h < k; h++) s->prop_k[h] = (float)(1.0 / k);                                     /* :1405 */
+        for (h = 0; h < k; h++) {
+            int ipt = 0, again = 1, ndraw;
+            for (ndraw = 0; again && ndraw < 100; ndraw++) {                                        /* :1419 */
+                int g;
+                /* RandomInteger(0, npt-1), nem_rnd.c:40-63: no draw is made when Mini >= Maxi */
+                if (0 >= n - 1) ipt = n - 1;
+                else ipt = (int)(random() % (long)n);
+                for (g = 0, again = 0; g < h && !again; g++) {
+                    int different = 0;
+                    for (j = 0; j < d; j++)
+                        if (s->center_kd[g * d + j] != (float)p->x[(size_t)ipt * d + j]) different = 1;
+                    if (!different) again = 1;
+                }
+            }
+            for (j = 0; j < d; j++) s->center_kd[h * d + j] = (float)p->x[(size_t)ipt * d + j];       /* :1457 */
+        }
+        err = run_from_params(p, s, 0);
+        if (err == ORC_STS_OK) {
+            nbsucc++;
+            if (nbsucc == 1 || s->crit[3] > bestcrit[3]) {                                          /* :1676-1697 */
+                memcpy(bestc, s->c_nk, sizeof(float) * nk);
+                memcpy(bestcrit, s->crit, sizeof bestcrit);
+                best = irandom; best_iters = s->iters; best_conv = s->converged;
+            }
+        }
+    }
+    if (nbsucc > 0) {
+        err = ORC_STS_OK;
+        memcpy(s->c_nk, bestc, sizeof(float) * nk);
+        /* (the reference restores saved centres / dispersions first; they only matter for missing data) */
+        orc_mstep(n, d, k, p->x, s->c_nk, p->disper, p->propor, s->prop_k, s->center_kd, s->disp_kd, s->nbobs_k,
+                  s->nbobs_kd, s->iner_kd, &ek);                                                    /* :1711 */
+        memcpy(s->crit, bestcrit, sizeof bestcrit);
+        s->iters = best_iters; s->converged = best_conv;
+    }
+    if (best_start) *best_start = best;
+    free(dispsam); free(bestc);
+    return err;
+}
+
+static int run_from_params(const orc_problem* p, orc_state* s, int reseed)
 {
     int n = p->n, d = p->d, k = p->k;
     int ncem = (p->algo == ORC_ALGO_NCEM);
@@ -366,7 +439,7 @@ int orc_run(const orc_problem* p, orc_state* s)
 
     if (!s->pkfki_nk) { s->pkfki_nk = (double*)malloc(sizeof(double) * nk); own_pk = 1; }
     if (!s->logpkfki_nk) { s->logpkfki_nk = (float*)malloc(sizeof(float) * nk); own_lp = 1; }
-    if (p->tie_rule == ORC_TIE_LIBC) srandom(p->tie_seed);         /* nem_exe.c:621 */
+    if (reseed && p->tie_rule == ORC_TIE_LIBC) srandom(p->tie_seed);   /* nem_exe.c:621 */
     s->n_zero_density = 0; s->emptyk = 0;
 
     memset(s->c_nk, 0, sizeof(float) * nk);                        /* calloc, nem_exe.c:524-526 */

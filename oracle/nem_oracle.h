@@ -104,6 +104,11 @@ int orc_converged(int n, int k, const float* c_nk, const float* cold_nk, float t
 /* ClassifyByNemOneBeta/INIT_PARAM_FILE + NemAlgo (nem_alg.c:1151-1169, 1746-1879) */
 int orc_run(const orc_problem* p, orc_state* s);
 
+/* INIT_RANDOM: ClassifyByNemOneBeta's default branch -> RandNemAlgo (nem_alg.c:1185-1189, 1574-1742): n_starts
+   random starts (centres = distinct data rows drawn with libc random() after srandom(seed)), best start by
+   criterion M, final EstimPara on the best partition.  best_start: 0-based index or -1. */
+int orc_run_random(const orc_problem* p, orc_state* s, int n_starts, unsigned seed, int* best_start);
+
 /* seconds of wall time spent in the EM iteration loop of the last orc_run (bench only) */
 double orc_last_loop_seconds(void);
 

@@ -174,6 +174,32 @@ class Oracle:
                     emptyk=s.emptyk, n_zero_density=s.n_zero_density, pkfki=pk, logpkfki=lp,
                     loop_seconds=float(self.lib.orc_last_loop_seconds()))
 
+    def run_random(self, x, nei, k, n_starts=50, rng_seed=1, algo="ncem", beta=0.5, disper="sk_", propor="pk",
+                   cvtest="clas", cvthres=1e-8, it_max=100, tie="libc", seed=None):
+        """INIT_RANDOM (RandNemAlgo): n_starts random starts drawn with libc random() after srandom(rng_seed).
+        tie="libc" shares that stream with the tie-breaks (the reference); "hash"/"first" use `seed` as tie seed."""
+        n, d = x.shape
+        x = np.ascontiguousarray(x, np.uint8)
+        ptr, idx, w = _csr(n, nei)
+        prop = np.zeros(k, np.float32)
+        center = np.zeros((k, d), np.float32)
+        disp = np.zeros((k, d), np.float32)
+        c = np.zeros((n, k), np.float32)
+        nk = np.zeros(k, np.float32)
+        nkd = np.zeros((k, d), np.float32)
+        iner = np.zeros((k, d), np.float32)
+        p = _Problem(n, d, k, _p(x, C.c_ubyte), _p(ptr, C.c_int), _p(idx, C.c_int), _p(w, C.c_float),
+                     ALGO[algo], DISP[disper], PROP[propor], CVT[cvtest], beta, cvthres, it_max, 0, TIE[tie],
+                     rng_seed if seed is None else seed)
+        s = _State(_p(c, C.c_float), _p(prop, C.c_float), _p(center, C.c_float), _p(disp, C.c_float),
+                   _p(nk, C.c_float), _p(nkd, C.c_float), _p(iner, C.c_float), None, None)
+        best = C.c_int(-1)
+        self.lib.orc_run_random.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.POINTER(C.c_int)]
+        sts = self.lib.orc_run_random(C.byref(p), C.byref(s), int(n_starts), C.c_uint(rng_seed), C.byref(best))
+        return dict(status=sts, c=c, prop=prop, center=center, disp=disp, nbobs_k=nk,
+                    crit=np.array(list(s.crit), np.float32), iters=s.iters, converged=bool(s.converged),
+                    best_start=best.value)
+
 
 class Reference:
     """The unmodified reference C NEM, compiled from /root/reference by oracle/Makefile."""
@@ -223,6 +249,31 @@ class Reference:
         return dict(status=sts, c=c, prop=prop, center=center, disp=disp, nbobs_k=nk, crit=crit, iters=iters,
                     converged=bool(m and m.group(1) == "converged"), log=text, seconds=secs.value,
                     zero_density=("density = 0" in text))
+
+    def classify_random(self, x, nei, k, n_starts=50, rng_seed=1, algo="ncem", beta=0.5, disper="sk_", propor="pk",
+                        cvtest="clas", cvthres=1e-8, it_max=100):
+        """ClassifyByNem with InitMode = INIT_RANDOM after srandom(rng_seed) (the reference seeds with time())."""
+        n, d = x.shape
+        xf = np.ascontiguousarray(x, np.float32)
+        ptr, idx, w = _csr(n, nei)
+        prop = np.zeros(k, np.float32)
+        center = np.zeros((k, d), np.float32)
+        disp = np.zeros((k, d), np.float32)
+        c = np.zeros((n, k), np.float32)
+        nk = np.zeros(k, np.float32)
+        crit = np.zeros(6, np.float32)
+        log = C.create_string_buffer(1 << 20)
+        secs = C.c_double(0)
+        sts = self.lib.ref_classify_ex(n, d, k, _p(xf, C.c_float), _p(ptr, C.c_int), _p(idx, C.c_int),
+                                       _p(w, C.c_float), ALGO[algo], C.c_float(beta), DISP[disper], PROP[propor],
+                                       CVT[cvtest], C.c_float(cvthres), it_max, 1, C.c_long(rng_seed), 1, int(n_starts),
+                                       _p(prop, C.c_float), _p(center, C.c_float), _p(disp, C.c_float),
+                                       _p(c, C.c_float), _p(nk, C.c_float), _p(crit, C.c_float), log, len(log),
+                                       C.byref(secs))
+        text = log.value.decode("latin1")
+        m = re.search(r"Best start was (\d+)", text)
+        return dict(status=sts, c=c, prop=prop, center=center, disp=disp, nbobs_k=nk, crit=crit,
+                    best_start=int(m.group(1)) - 1 if m else -1, log=text, seconds=secs.value)
 
     def estim_para(self, x, c, disper, propor, prop, center, disp):
         n, d = x.shape

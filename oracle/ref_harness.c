@@ -59,6 +59,16 @@ static double now_s(void)
  *  secs        out: wall seconds spent inside ClassifyByNem
  * returns the StatusET of ClassifyByNem.
  */
+int ref_classify_ex(int n, int d, int k,
+                    const float* x_nd,
+                    const int* nei_ptr, const int* nei_idx, const float* nei_w,
+                    int algo, float beta, int disper, int propor,
+                    int cvtest, float cvthres, int nbiters, int param_mode,
+                    long seed, int init_mode, int nb_random_inits,
+                    float* prop_k, float* center_kd, float* disp_kd,
+                    float* classif_nk, float* nbobs_k, float* crit6,
+                    char* log_text, int log_cap, double* secs);
+
 int ref_classify(int n, int d, int k,
                  const float* x_nd,
                  const int* nei_ptr, const int* nei_idx, const float* nei_w,
@@ -68,6 +78,23 @@ int ref_classify(int n, int d, int k,
                  float* prop_k, float* center_kd, float* disp_kd,
                  float* classif_nk, float* nbobs_k, float* crit6,
                  char* log_text, int log_cap, double* secs)
+{
+    return ref_classify_ex(n, d, k, x_nd, nei_ptr, nei_idx, nei_w, algo, beta, disper, propor, cvtest, cvthres,
+                           nbiters, param_mode, seed, INIT_PARAM_FILE, DEFAULT_NBRANDINITS, prop_k, center_kd,
+                           disp_kd, classif_nk, nbobs_k, crit6, log_text, log_cap, secs);
+}
+
+/* Same with the start mode of nem()'s init_mode argument (INIT_PARAM_FILE = 2, INIT_RANDOM = 1, nem_typ.h) and the
+   number of random starts (NbRandomInits, DEFAULT_NBRANDINITS = 50 in nem()). */
+int ref_classify_ex(int n, int d, int k,
+                    const float* x_nd,
+                    const int* nei_ptr, const int* nei_idx, const float* nei_w,
+                    int algo, float beta, int disper, int propor,
+                    int cvtest, float cvthres, int nbiters, int param_mode,
+                    long seed, int init_mode, int nb_random_inits,
+                    float* prop_k, float* center_kd, float* disp_kd,
+                    float* classif_nk, float* nbobs_k, float* crit6,
+                    char* log_text, int log_cap, double* secs)
 {
     DataT      data;
     NemParaT   para;
@@ -150,10 +177,10 @@ int ref_classify(int n, int d, int k,
     para.DoLog = FALSE;
     para.NbIters = nbiters;
     para.NbEIters = DEFAULT_NBEITERS;
-    para.NbRandomInits = DEFAULT_NBRANDINITS;
+    para.NbRandomInits = nb_random_inits;
     para.Seed = seed;
     para.Format = FORMAT_FUZZY;
-    para.InitMode = INIT_PARAM_FILE;
+    para.InitMode = (InitET)init_mode;
     para.MissMode = MISSING_REPLACE;      /* NemPara is zero-initialised in nem(): nem_exe.c:260 */
     para.ParamFileMode = (ParamFileET)param_mode;
     para.SortedVar = DEFAULT_SORTEDVAR;

@@ -145,15 +145,18 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     // ---- inputs, nem_exe.c:469-574
     lg.pr("Reading points ...\n");
     if ((sts = read_dat_file(base, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
-    if (init_mode != 2) {                                                   // INIT_PARAM_FILE, nem_typ.h:218
-        lg.pr("Initialization mode %d is not supported by this engine (only 2 = parameter file)\n", init_mode);
+    const bool random_init = (init_mode == 1);                              // INIT_RANDOM, nem_typ.h:217
+    if (init_mode != 2 && !random_init) {                                   // INIT_PARAM_FILE, nem_typ.h:218
+        lg.pr("Initialization mode %d is not supported by this engine (2 = parameter file, 1 = random starts)\n", init_mode);
         lg.pr("*** NEM error status : bad arguments\n");
         lg.close();
         return EXIT_E_ARGS_;
     }
-    lg.pr("Reading parameter file ...\n");
-    if ((sts = read_param_file(base, nk, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
-    cfg.param_fix = (in.param_mode == 2);
+    if (!random_init) {                                                     // nem_exe.c:513-519: only this mode reads <Fname>.m
+        lg.pr("Reading parameter file ...\n");
+        if ((sts = read_param_file(base, nk, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
+    }
+    cfg.param_fix = (!random_init && in.param_mode == 2);
     if (in.type != 'N') {
         lg.pr("Reading neighborhood information ...\n");
         if ((sts = read_nei_file(base, in, err)) != NEMGPU_OK) { fprintf(stderr, "%s\n", err.c_str()); lg.close(); return sts; }
@@ -189,11 +192,20 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, 0, nullptr);
     if (rc == NEMGPU_OK) rc = nemgpu_set_matrix_bits(e, in.xbits.data());
     if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
-    if (rc == NEMGPU_OK) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
+    if (rc == NEMGPU_OK && !random_init) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
     if (rc == NEMGPU_OK) rc = nemgpu_configure(e, &cfg);
     if (rc == NEMGPU_OK) {
-        lg.pr("Initializing parameters from given value\n");
-        rc = nemgpu_run(e, &res);
+        if (random_init) {
+            // RandNemAlgo with the reference's 50 starts (DEFAULT_NBRANDINITS, nem_typ.h:94); the draws come from the
+            // reference's generator seeded like its NemPara.Seed (time(NULL), or NEM_MI355X_SEED)
+            int best = -1;
+            rc = nemgpu_run_random(e, 50, cfg.tie_seed, &res, &best);
+            if (rc == NEMGPU_OK && best >= 0)
+                lg.pr("Best start was %d (%s = %g)\n", best + 1, "M", (double)res.crit[3]);                  // nem_alg.c:1722-1725
+        } else {
+            lg.pr("Initializing parameters from given value\n");
+            rc = nemgpu_run(e, &res);
+        }
     }
     if (rc != NEMGPU_OK) {
         lg.pr("*** NEM GPU engine error : %s\n", nemgpu_last_error());

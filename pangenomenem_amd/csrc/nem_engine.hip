@@ -16,6 +16,7 @@
 
 #include "nem_internal.hpp"
 #include "nem_ff.hpp"
+#include "nem_rng.hpp"
 #include "nem_kernels.hpp"
 
 using namespace nemk;
@@ -58,6 +59,7 @@ struct nemgpu_engine {
     // nothing outside the density kernels sees the order.
     uint32_t* xws = nullptr;
     int* perm = nullptr;
+    std::vector<uint32_t> host_bits;     // the family-major bit rows as uploaded (random starts pick centres from them)
     bool use_sort = true;
     uint64_t* xt = nullptr;
     int *nei_ptr = nullptr, *nei_idx = nullptr;
@@ -813,6 +815,7 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
             std::stable_sort(perm.begin() + t0, perm.begin() + t1, [&](int a, int b) { return pc[a] < pc[b]; });
         }
     }
+    e->host_bits.assign(xbits_host, xbits_host + words);
     HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
@@ -964,6 +967,111 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
         res->loop_seconds = secs;
         if ((r = criteria(e, res->crit))) return r;                // nem_alg.c:1852
     }
+    return NEMGPU_OK;
+}
+
+// INIT_RANDOM: RandNemAlgo (nem_alg.c:1574-1742).  InitPara's whole-sample dispersion (:1200-1281) is one M-step
+// with every family in class 0; every start draws its centres from the data (MakeRandomPara, :1381-1473), runs the
+// INIT_PARAM_FILE pipeline on them and is ranked by criterion M (DEFAULT_CRIT, nem_typ.h:80); the best partition is
+// restored and EstimPara run on it (:1703-1713).
+int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
+{
+    if (!e || n_starts <= 0) return NEMGPU_E_FUNCARG;
+    if (e->lo != 0 || e->hi != e->n_total) { set_error("random starts need the whole problem on one engine"); return NEMGPU_E_FUNCARG; }
+    if (!e->have_matrix || e->host_bits.empty()) { set_error("the matrix must be set first"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    const int n = e->n, d = e->d, k = e->k, wf = e->wf;
+    const size_t kd = (size_t)k * d;
+    if ((r = ensure_state_buffers(e))) return r;
+    // ---- InitPara: dispersion of the whole sample
+    e->have_params = true;                                         // (the slots are (re)written below)
+    if ((r = reset_state(e))) return r;
+    if (e->ncem()) {
+        HIPCHK(hipMemsetAsync(e->lab[0], 0, (size_t)e->n_total, e->stream));
+    } else {
+        std::vector<float> c1((size_t)n * k, 0.0f);
+        for (int i = 0; i < n; i++) c1[(size_t)i * k] = 1.0f;
+        HIPCHK(copy_sync(e, e->cbuf[0], c1.data(), c1.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->cur = 0; e->masks_valid = false;
+    if ((r = do_mstep(e))) return r;
+    std::vector<float> dispsam((size_t)d);
+    HIPCHK(copy_sync(e, dispsam.data(), e->disp, sizeof(float) * d, hipMemcpyDeviceToHost));
+
+    GlibcRandom rng(seed);
+    std::vector<float> prop((size_t)k), center(kd), disp(kd);
+    auto bit = [&](int i, int j) { return (float)((e->host_bits[(size_t)i * wf + (j >> 5)] >> (j & 31)) & 1u); };
+    uint8_t* best_lab = nullptr; float* best_c = nullptr;
+    g_alloc_stream = e->stream;
+    if (e->ncem()) { if ((r = dev_alloc(&best_lab, (size_t)e->n_total))) return r; }
+    else { if ((r = dev_alloc(&best_c, (size_t)e->n_total * k))) return r; }
+    auto cleanup = [&]() { (void)hipStreamSynchronize(e->stream); if (best_lab) (void)hipFree(best_lab); if (best_c) (void)hipFree(best_c); };
+    int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
+    float best_crit[6] = {0, 0, 0, 0, 0, 0};
+    nemgpu_result best_res{};
+    for (int s = 0; s < n_starts; s++) {
+        // MakeRandomPara
+        for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) disp[(size_t)h * d + j] = dispsam[j] / k;      // :1400
+        for (int h = 0; h < k; h++) prop[h] = (float)(1.0 / k);                                              // :1405
+        for (int h = 0; h < k; h++) {
+            int ipt = 0;
+            bool again = true;
+            for (int ndraw = 0; again && ndraw < 100; ndraw++) {                                             // :1419
+                ipt = rng.integer(0, n - 1);
+                again = false;
+                for (int g = 0; g < h && !again; g++) {
+                    bool different = false;
+                    for (int j = 0; j < d && !different; j++) different = center[(size_t)g * d + j] != bit(ipt, j);
+                    if (!different) again = true;
+                }
+            }
+            for (int j = 0; j < d; j++) center[(size_t)h * d + j] = bit(ipt, j);                             // :1457
+        }
+        HIPCHK(copy_sync(e, e->prop0, prop.data(), sizeof(float) * k, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->center0, center.data(), sizeof(float) * kd, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->disp0, disp.data(), sizeof(float) * kd, hipMemcpyHostToDevice));
+        // ComputePartitionFromPara + NemAlgo + criteria, as nemgpu_run does
+        if ((r = iterate(e, e->cfg.it_max, true))) { cleanup(); return r; }
+        if (e->iters == 0) {
+            if ((r = do_mstep(e)) || (r = do_tables(e)) || (r = do_density(e))) { cleanup(); return r; }
+        }
+        float crit[6];
+        if ((r = criteria(e, crit))) { cleanup(); return r; }
+        last_status = e->status;
+        if (e->status == NEMGPU_OK) {
+            nbsucc++;
+            if (nbsucc == 1 || crit[3] > best_crit[3]) {                                                     // :1676-1697
+                if (e->ncem()) HIPCHK(hipMemcpyAsync(best_lab, e->lab[e->cur], (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+                else HIPCHK(hipMemcpyAsync(best_c, e->cbuf[e->cur], sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
+                for (int t = 0; t < 6; t++) best_crit[t] = crit[t];
+                best = s;
+                fill_result(e, &best_res);
+            }
+        }
+    }
+    if (nbsucc > 0) {
+        if (e->ncem()) HIPCHK(hipMemcpyAsync(e->lab[e->cur], best_lab, (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+        else HIPCHK(hipMemcpyAsync(e->cbuf[e->cur], best_c, sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
+        e->masks_valid = false; e->tables_fresh = false; e->density_fresh = false;
+        if ((r = do_mstep(e))) { cleanup(); return r; }                                                      // :1711
+        e->status = NEMGPU_OK; e->emptyk = 0;
+        e->iters = best_res.iters; e->converged = best_res.converged;
+        if (res) { *res = best_res; res->status = NEMGPU_OK; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
+    } else if (res) {
+        fill_result(e, res);
+        res->status = last_status;
+    }
+    if (best_start) *best_start = best;
+    cleanup();
+    return NEMGPU_OK;
+}
+
+int nemgpu_glibc_random(uint32_t seed, int count, int32_t* out)
+{
+    if (!out || count < 0) return NEMGPU_E_FUNCARG;
+    nemk::GlibcRandom rng(seed);
+    for (int i = 0; i < count; i++) out[i] = (int32_t)rng.next();
     return NEMGPU_OK;
 }
 

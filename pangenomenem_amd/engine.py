@@ -59,6 +59,8 @@ def load_library():
     lib.nemgpu_set_params.argtypes = [vp, vp, vp, vp]
     lib.nemgpu_configure.argtypes = [vp, C.POINTER(Config)]
     lib.nemgpu_run.argtypes = [vp, C.POINTER(Result)]
+    lib.nemgpu_run_random.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(Result), ip]
+    lib.nemgpu_glibc_random.argtypes = [C.c_uint32, C.c_int, vp]
     lib.nemgpu_init_partition.argtypes = [vp]
     lib.nemgpu_iterate.argtypes = [vp, C.c_int, C.POINTER(Result)]
     lib.nemgpu_reset.argtypes = [vp]
@@ -187,6 +189,16 @@ class NemEngine:
         self._chk(self.lib.nemgpu_run(self._h, C.byref(r)))
         out = self._result(r)
         out.update(self.results())
+        return out
+
+    def run_random(self, n_starts=50, rng_seed=1):
+        """The reference's init_mode = INIT_RANDOM: n_starts random starts, best by criterion M (no set_params needed)."""
+        r = Result()
+        best = C.c_int(-1)
+        self._chk(self.lib.nemgpu_run_random(self._h, int(n_starts), C.c_uint32(rng_seed), C.byref(r), C.byref(best)))
+        out = self._result(r)
+        out.update(self.results())
+        out["best_start"] = best.value
         return out
 
     def init_partition(self):

@@ -176,3 +176,20 @@ def test_dat_reader_fast_path_agrees_with_the_tokeniser(lib, tmp_path):
     with pytest.raises(engine.NemGpuError, match="0/1"):
         engine.read_inputs(base, 3)
     del m
+
+
+def test_restated_generator_is_glibc_random(lib):
+    """csrc/nem_rng.hpp restates the generator behind the reference's random starts: libc random() after srandom(seed)
+    (nem_exe.c:621, nem_rnd.c:40-63).  Checked against this host's libc draw for draw."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    libc.random.restype = C.c_long
+    libc.srandom.argtypes = [C.c_uint]
+    lib.nemgpu_glibc_random.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+    for seed in (0, 1, 2, 12345, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 1759500000):
+        n = 2000
+        got = np.zeros(n, np.int32)
+        assert lib.nemgpu_glibc_random(seed, n, got.ctypes.data_as(C.c_void_p)) == 0
+        libc.srandom(seed)
+        want = np.array([libc.random() for _ in range(n)], np.int64)
+        assert np.array_equal(got.astype(np.int64), want), seed

@@ -69,3 +69,34 @@ def test_dropin_whole_call_at_configs1(gpu_lib, tmp_path):
     except OSError:
         pass
     assert t_ours < t_ref
+
+
+def test_dropin_random_starts_equal_the_reference_given_its_seed(gpu_lib, tmp_path, oracle):
+    """init_mode = 1 (INIT_RANDOM), what partition_shell uses (ppanggolin.py:1207): 50 random starts.  The reference
+    seeds with time(NULL); with the seed fixed (NEM_MI355X_SEED here, srandom() in the reference harness) and
+    tie-free data both sides draw the same centres, so the partition and the parameters must agree."""
+    from oracle import pyoracle
+    import nem as nem_module
+    n, d, k, seed = 1500, 30, 3, 4242
+    x, _ = synth.bernoulli_pa_matrix(n, d, 17)
+    nei = synth.contiguity_graph(n, 17)
+    prop, center, disp = synth.default_init(d)
+    base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
+    os.remove(base + ".m")                                     # not read in this mode (nem_exe.c:513-522)
+    os.environ["NEM_MI355X_SEED"] = str(seed)
+    try:
+        rc = nem_module.nem(base.encode(), k, b"ncem", 0.5, b"clas", 1e-8, b"fuzzy", 100, True, b"bern", b"pk", b"sk_", 1)
+    finally:
+        del os.environ["NEM_MI355X_SEED"]
+    assert rc == 0
+    labels, params, _, _ = nemfiles.read_nem_outputs(str(tmp_path), d, q=k, init="random")
+    want = oracle.run_random(x, nei, k, n_starts=50, rng_seed=seed, algo="ncem", disper="sk_", beta=0.5, it_max=100,
+                             tie="hash", seed=seed)
+    got_c = np.loadtxt(base + ".uf", dtype=np.float32).reshape(n, k)
+    assert np.array_equal(got_c.argmax(1), want["c"].argmax(1))
+    assert "Best start was %d" % (want["best_start"] + 1) in open(base + ".stderr").read()
+    if pyoracle.have_reference():
+        ref = pyoracle.Reference().classify_random(x, nei, k, n_starts=50, rng_seed=seed, algo="ncem", disper="sk_",
+                                                   beta=0.5, it_max=100)
+        assert ref["status"] == 0 and ref["best_start"] == want["best_start"]
+        assert np.array_equal(got_c.argmax(1), ref["c"].argmax(1))

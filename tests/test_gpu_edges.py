@@ -112,3 +112,34 @@ def test_all_identical_families_and_constant_columns(gpu_lib, oracle):
         got = solve(x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=6, tie=tie, seed=9)
         want = oracle.run(x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=6, tie=tie, seed=9)
         same_run(got, want, "ncem")
+
+
+@pytest.mark.parametrize("n,d,k,algo,disper,starts,seed", [
+    (1200, 40, 3, "ncem", "sk_", 10, 1), (900, 25, 3, "nem", "skd", 6, 7), (2000, 64, 4, "ncem", "skd", 8, 3),
+    (700, 300, 3, "ncem", "s__", 5, 5), (500, 16, 2, "nem", "s_d", 5, 11)])
+def test_random_starts_match_oracle(gpu_lib, oracle, n, d, k, algo, disper, starts, seed):
+    """nemgpu_run_random = the reference's init_mode INIT_RANDOM: same draws (the restated glibc generator), same
+    ranking of the starts, same final M-step."""
+    from pangenomenem_amd.engine import NemEngine
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed)
+    nei = synth.contiguity_graph(n, seed)
+    eng = NemEngine(n, d, k)
+    eng.set_matrix(x)
+    eng.set_graph(nei)
+    eng.configure(algo=algo, beta=0.5, disper=disper, propor="pk", it_max=30, tie="hash", seed=seed)
+    got = eng.run_random(n_starts=starts, rng_seed=seed)
+    want = oracle.run_random(x, nei, k, n_starts=starts, rng_seed=seed, algo=algo, disper=disper, beta=0.5, it_max=30,
+                             tie="hash", seed=seed)
+    assert got["status"] == want["status"]
+    assert got["best_start"] == want["best_start"]
+    assert got["iters"] == want["iters"] and got["converged"] == want["converged"]
+    assert np.array_equal(got["c"].argmax(1), want["c"].argmax(1))
+    if algo == "ncem":
+        assert np.array_equal(got["c"], want["c"])
+    assert maxdiff(got["c"], want["c"]) <= TOL
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, key
+    assert np.array_equal(got["center"], want["center"])
+    rel = np.abs(got["crit"].astype(np.float64) - want["crit"]) / np.maximum(1.0, np.abs(want["crit"]))
+    assert np.all((rel <= 1e-5) | ~np.isfinite(want["crit"]))
+    eng.close()

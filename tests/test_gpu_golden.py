@@ -127,7 +127,7 @@ def test_dropin_argument_errors(gpu_lib, tmp_path):
     assert call(Fname=(base + "_missing").encode()) == 5      # STS_E_FILEIN returned raw (nem_exe.c:309)
     assert call(model_family=b"norm") == 2                    # unsupported family -> EXIT_E_ARGS
     assert call(dispersion=b"xyz") == 6                       # unknown dispersion -> EXIT_E_BUG like the reference
-    assert call(init_mode=1) == 2                             # INIT_RANDOM not supported yet
+    assert call(init_mode=0) == 2 and call(init_mode=3) == 2  # INIT_SORT / INIT_FILE: not supported
     assert call(format=b"hard") == 0 and os.path.isfile(base + ".cf")
     labels = open(base + ".cf").read().split()
     assert len(labels) == case["x"].shape[0] and set(labels) <= {"1", "2", "3"}

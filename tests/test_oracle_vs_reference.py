@@ -62,3 +62,21 @@ def test_reference_files_equal_reference_memory(reference, tmp_path):
     labels, params, m_crit, _ = nemfiles.read_nem_outputs(str(tmp_path), d)
     assert abs(m_crit - mem["crit"][3]) <= 1e-5 * abs(mem["crit"][3])
     assert len(labels) == n and set(labels) <= {"P", "S", "C"}
+
+
+@pytest.mark.parametrize("n,d,k,algo,disper,starts,seed", [
+    (600, 20, 3, "ncem", "sk_", 8, 1), (600, 20, 3, "nem", "skd", 8, 7), (1000, 33, 4, "ncem", "skd", 6, 3),
+    (300, 12, 2, "ncem", "s__", 10, 5), (400, 9, 3, "nem", "s_d", 5, 11), (1, 6, 2, "ncem", "sk_", 3, 2)])
+def test_random_starts_bit_exact(oracle, reference, n, d, k, algo, disper, starts, seed):
+    """init_mode = INIT_RANDOM (RandNemAlgo): same libc stream (srandom(seed)) for the centre draws and the
+    tie-breaks, best start by M, final EstimPara -- everything bit for bit."""
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed)
+    nei = synth.contiguity_graph(n, seed) if n > 1 else None
+    a = oracle.run_random(x, nei, k, n_starts=starts, rng_seed=seed, algo=algo, disper=disper, beta=0.5, it_max=30)
+    b = reference.classify_random(x, nei, k, n_starts=starts, rng_seed=seed, algo=algo, disper=disper, beta=0.5,
+                                  it_max=30)
+    assert a["status"] == b["status"]
+    if b["status"] == 0:
+        assert a["best_start"] == b["best_start"]
+        for key in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+            assert bits_equal(a[key], b[key]), key
