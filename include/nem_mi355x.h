@@ -38,7 +38,8 @@ extern "C" {
  *   convergence_th threshold of the "clas" test (max |c - c_old| < th)
  *   format         "hard" (.cf) | "fuzzy" (.uf)
  *   it_max         maximum number of EM iterations (>= 0)
- *   dolog          non-zero: messages to <Fname>.stderr and an iteration log <Fname>.log
+ *   dolog          non-zero: messages to <Fname>.stderr and the reference's iteration log <Fname>.log (criteria
+ *                  before / after every E-step and all parameters per iteration; NEM_MI355X_LOG=0: header only)
  *   model_family   "bern" (the only family PPanGGOLiN uses; "norm"/"lapl" rejected)
  *   proportion     "p_" | "pk"
  *   dispersion     "s__" | "sk_" | "s_d" | "skd"
@@ -153,6 +154,9 @@ int nemgpu_density(nemgpu_engine* e);                     /* E1 only */
 int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds);  /* E2 only (one full Gauss-Seidel sweep) */
 int nemgpu_mstep(nemgpu_engine* e, int* emptyk);          /* M only */
 int nemgpu_criteria(nemgpu_engine* e, float crit6[6]);    /* C1 only */
+/* C1 on the partition the last E-step sweep started from, with the current densities: the "after the M-step"
+   criteria of the reference's <Fname>.log (WriteLogCrit, nem_alg.c:2361, 2620-2646) */
+int nemgpu_criteria_previous(nemgpu_engine* e, float crit6[6]);
 
 /* Multi-GPU step pieces (NCEM; families sharded across engines in contiguous blocks).  The host
    driver (pangenomenem_amd/distributed.py) owns the all-gathered label arrays (device memory) and

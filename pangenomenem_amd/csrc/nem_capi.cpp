@@ -50,6 +50,105 @@ struct Log {
 
 }  // namespace
 
+namespace {
+
+// ---- <Fname>.log, the reference's per-iteration log (dolog != 0) ---------------------------------------------
+// Line layout: StartLogFile (nem_alg.c:1478-1498), the INIT_PARAM_FILE preamble (:1151-1158), WriteLogHeader
+// (:1883-1945), and per iteration "%4d " + criteria before and after the E-step sweep (WriteLogCrit, :2620-2646,
+// called at :2361 and :2398) + WriteLogClasses (:1993-2052).
+float log_mult(int npt)
+{
+    return (float)exp(-((int)(log(npt / 1000.) / log(10))) * log(10));      // :1495, :2638
+}
+
+void log_crit(FILE* fl, const float crit6[6], float mult)
+{
+    fprintf(fl, " %5.0f %5.0f %5.3f", (double)(float)(crit6[2] * mult), (double)(float)(crit6[3] * mult),
+            (double)std::nanf(""));                                          // U, M, error rate (no reference partition)
+}
+
+void log_header(FILE* fl, int k, int d)
+{
+    fprintf(fl, "%4s  %5s %5s %5s", "It", "UM", "PM", "Er");
+    fprintf(fl, " %3s%-2d %3s%-2d %3s%-2d", "UE", 1, "PE", 1, "Er", 1);       // NbEIters = 1
+    fprintf(fl, " ");
+    fprintf(fl, " %5s", "Beta");
+    fprintf(fl, " ");
+    for (int h = 0; h < k; h++) fprintf(fl, " %3s%02d", "P", h + 1);
+    fprintf(fl, " ");
+    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "M", h + 1, j + 1);
+    fprintf(fl, " ");
+    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "D", h + 1, j + 1);
+    fprintf(fl, " ");
+    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "n", h + 1, j + 1);
+    fprintf(fl, "\n");
+}
+
+void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool sizes_known)
+{
+    std::vector<float> prop(k), center((size_t)k * d), disp((size_t)k * d), nk(k);
+    nemgpu_get_params(e, prop.data(), center.data(), disp.data(), nk.data());
+    fprintf(fl, " ");
+    fprintf(fl, " %5.3f", (double)beta);
+    fprintf(fl, " ");
+    for (int h = 0; h < k; h++) fprintf(fl, " %5.3f", (double)prop[h]);
+    fprintf(fl, " ");
+    for (size_t t = 0; t < (size_t)k * d; t++) fprintf(fl, " %7.3f", (double)center[t]);
+    fprintf(fl, " ");
+    for (size_t t = 0; t < (size_t)k * d; t++) fprintf(fl, " %7.3f", (double)disp[t]);
+    fprintf(fl, " ");
+    // NbObs_KD: zero until the first EstimPara (calloc, nem_exe.c:320), then N_K for every organism (no missing data)
+    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %7.1f", sizes_known ? (double)nk[h] : 0.0);
+    fprintf(fl, "\n");
+}
+
+// The INIT_PARAM_FILE run with the reference's log: one EM iteration per engine call, two criteria evaluations
+// per iteration (the partition the sweep started from is still in its buffer afterwards).
+int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res)
+{
+    const float mult = log_mult(n);
+    time_t timer = time(nullptr);
+    fprintf(fl, "NEM log file  -  %s\n", asctime(localtime(&timer)));
+    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)mult);
+    fprintf(fl, "Initializing parameters from given value :\n");
+    fprintf(fl, "%4d ", 0);
+    int rc;
+    float cb[6], ca[6];
+    if ((rc = nemgpu_reset(e))) return rc;
+    if ((rc = nemgpu_init_partition(e))) return rc;
+    if ((rc = nemgpu_criteria_previous(e, cb)) || (rc = nemgpu_criteria(e, ca))) return rc;
+    log_crit(fl, cb, mult); log_crit(fl, ca, mult);
+    log_classes(fl, e, cfg.beta, k, d, false);
+    fprintf(fl, "\n");                                                     // Needinit, :1985-1986
+    log_header(fl, k, d);
+    nemgpu_result r1{};
+    nemgpu_iterate(e, 0, &r1);                                               // (fills the counters of the start)
+    double loop_s = 0.0;
+    for (int iter = 1; iter <= cfg.it_max && !r1.converged && r1.status == NEMGPU_OK; iter++) {
+        fprintf(fl, "%4d ", iter);
+        if ((rc = nemgpu_iterate(e, 1, &r1))) return rc;
+        loop_s += r1.loop_seconds;
+        if (r1.status == NEMGPU_W_EMPTYCLASS) {                             // :1835-1837
+            fprintf(fl, " Class %d empty at iteration %d\n", r1.emptyk, iter);
+            break;
+        }
+        if ((rc = nemgpu_criteria_previous(e, cb)) || (rc = nemgpu_criteria(e, ca))) return rc;
+        log_crit(fl, cb, mult); log_crit(fl, ca, mult);
+        log_classes(fl, e, cfg.beta, k, d, !cfg.param_fix);
+    }
+    *res = r1;
+    res->loop_seconds = loop_s;
+    if (r1.iters == 0) {                                                    // :1845-1851
+        int ek = 0;
+        rc = nemgpu_mstep(e, &ek);
+        if (rc != NEMGPU_OK && rc != NEMGPU_W_EMPTYCLASS) return rc;
+        if ((rc = nemgpu_density(e))) return rc;
+    }
+    return nemgpu_criteria(e, res->crit);
+}
+
+}  // namespace
+
 extern "C" int nem(const char* Fname, const int nk, const char* algo, const float beta, const char* convergence,
                    const float convergence_th, const char* format, const int it_max, const int dolog,
                    const char* model_family, const char* proportion, const char* dispersion, const int init_mode)
@@ -189,6 +288,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     // ---- the EM run on the GPU (ClassifyByNem, :624)
     nemgpu_engine* e = nullptr;
     nemgpu_result res{};
+    bool full_log = false;
     int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, 0, nullptr);
     if (rc == NEMGPU_OK) rc = nemgpu_set_matrix_bits(e, in.xbits.data());
     if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
@@ -204,7 +304,12 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
                 lg.pr("Best start was %d (%s = %g)\n", best + 1, "M", (double)res.crit[3]);                  // nem_alg.c:1722-1725
         } else {
             lg.pr("Initializing parameters from given value\n");
-            rc = nemgpu_run(e, &res);
+            // dolog: the reference's per-iteration <Fname>.log (two criteria passes per iteration, one host round
+            // trip per iteration); NEM_MI355X_LOG=0 keeps the pipelined run and writes a header-only log
+            const char* lenv = getenv("NEM_MI355X_LOG");
+            FILE* fl = (dolog && !(lenv && lenv[0] == '0')) ? fopen((base + ".log").c_str(), "w") : nullptr;
+            if (fl) { rc = run_logged(e, cfg, in.n, in.d, nk, fl, &res); fclose(fl); full_log = true; }
+            else rc = nemgpu_run(e, &res);
         }
     }
     if (rc != NEMGPU_OK) {
@@ -236,7 +341,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         int w2 = write_mf_file(base + ".mf", res.crit, cfg.beta, in.d, nk, center.data(), prop.data(), disp.data());
         if (w1 != NEMGPU_OK) fprintf(stderr, "Could not open file '%s' in write mode\n", outname.c_str());
         if (w2 != NEMGPU_OK) fprintf(stderr, "Could not open file '%s.mf' in write mode\n", base.c_str());
-        if (dolog) {                                                        // minimal <Fname>.log (never parsed by PPanGGOLiN)
+        if (dolog && !full_log) {                                           // header-only <Fname>.log (never parsed by PPanGGOLiN)
             FILE* fl = fopen((base + ".log").c_str(), "w");
             if (fl) {
                 time_t t = time(nullptr);

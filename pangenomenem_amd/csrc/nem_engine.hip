@@ -641,19 +641,20 @@ int ensure_crit_buffers(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
-const float* float_partition(nemgpu_engine* e)
+const float* float_partition(nemgpu_engine* e, int buf)
 {
-    if (!e->ncem()) return e->cbuf[e->cur];
-    launch_onehot(e->n_total, e->k, e->lab[e->cur], e->c_onehot, e->stream);
+    if (!e->ncem()) return e->cbuf[buf];
+    launch_onehot(e->n_total, e->k, e->lab[buf], e->c_onehot, e->stream);
     return e->c_onehot;
 }
 
-int criteria(nemgpu_engine* e, float crit6[6])
+// ComputeCrit on the partition in buffer `buf` (default: the current one) with the current densities
+int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
 {
     int r;
     if (e->lo != 0 || e->hi != e->n_total) { set_error("criteria need the whole partition on one engine"); return NEMGPU_E_FUNCARG; }
     if ((r = ensure_crit_buffers(e))) return r;
-    const float* c = float_partition(e);
+    const float* c = float_partition(e, buf < 0 ? e->cur : buf);
     launch_criteria(e->n, e->k, e->npad, e->nei_ptr, e->nei_idx, e->nei_w, e->has_graph ? 1 : 0, e->cfg.beta, c,
                     e->pkfki, e->logpkfki, e->crit_dik, e->crit_gik, e->crit_lfi, e->crit_lzi, e->crit6_dev,
                     e->stream);
@@ -1331,6 +1332,16 @@ int nemgpu_shard_set_sweep_number(nemgpu_engine* e, int next_sweep)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, next_sweep, 1, e->stream));
     return NEMGPU_OK;
+}
+
+// Criteria of the partition the last sweep started from (buffer cur+2: the sweep's ping/pong leave it intact),
+// evaluated with the current densities -- what the reference logs "after the M-step" of an iteration
+// (WriteLogCrit at the top of ComputePartitionNEM, nem_alg.c:2361).
+int nemgpu_criteria_previous(nemgpu_engine* e, float crit6[6])
+{
+    if (!e || !crit6) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    return criteria(e, crit6, (e->cur + 2) % 3);
 }
 
 int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)

@@ -132,3 +132,34 @@ def test_dropin_argument_errors(gpu_lib, tmp_path):
     labels = open(base + ".cf").read().split()
     assert len(labels) == case["x"].shape[0] and set(labels) <= {"1", "2", "3"}
     assert call(algo=b"typo") == 0                            # quirk: unknown algo runs as "nem" (nem_exe.c:371-376, 472)
+
+
+@pytest.mark.parametrize("algo,disper,n,d", [("ncem", "sk_", 2048, 15), ("nem", "skd", 900, 21), ("ncem", "s__", 1500, 9)])
+def test_dropin_log_file_equals_the_reference(gpu_lib, tmp_path, algo, disper, n, d):
+    """<Fname>.log (dolog=1): header, criteria before and after every E-step sweep, all parameters per iteration --
+    the text of the reference's own log except its date line."""
+    import shutil
+    from oracle import pyoracle
+    if not pyoracle.have_reference():
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    from pangenomenem_amd import nemfiles, synth
+    import nem as nem_module
+    x, _ = synth.bernoulli_pa_matrix(n, d, n + d)
+    nei = synth.contiguity_graph(n, n + d)
+    prop, center, disp = synth.default_init(d)
+    ours, ref = str(tmp_path / "ours"), str(tmp_path / "ref")
+    base = nemfiles.write_nem_inputs(ours, x, nei, prop, center, disp)
+    shutil.copytree(ours, ref)
+    ref_base = os.path.join(ref, "nem_file")
+    args = (3, algo.encode(), 0.5, b"clas", 1e-8, b"fuzzy", 20, True, b"bern", b"pk", disper.encode(), 2)
+    assert nem_module.nem(base.encode(), *args) == 0
+    assert pyoracle.Reference().nem(ref_base, *args) == 0
+    a, b = open(base + ".log").read().split("\n"), open(ref_base + ".log").read().split("\n")
+    assert len(a) == len(b) and len(a) > 6
+    for i, (u, v) in enumerate(zip(a[1:], b[1:])):
+        if u != v:                                            # criteria columns: %5.0f of float sums, allow the last unit
+            tu, tv = u.split(), v.split()
+            assert len(tu) == len(tv), (i + 1, u[:100], v[:100])
+            for p, (s, t) in enumerate(zip(tu, tv)):
+                if s != t:
+                    assert p in (1, 2, 4, 5) and abs(float(s) - float(t)) <= 1.0, (i + 1, p, s, t)
