@@ -955,20 +955,6 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
 
 __global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
 
-// sharded runs: a rank's "some label changed in this round" byte, stored behind its block of labels so that
-// the label all-gather carries it to every rank
-__global__ void k_publish_flag(const int* __restrict__ flags4, uint8_t* __restrict__ out_byte,
-                               const int* __restrict__ stop)
-{
-    if (stop != nullptr && *stop) return;
-    *out_byte = (uint8_t)(flags4[FLAG_CHANGED] != 0);
-}
-
-void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, s, flags4, out_byte, stop);
-}
-
 // sharded runs: CVTEST_CLAS over the WHOLE (all-gathered) label array, so every rank takes the same decision
 // without another collective; slot t of true family f: (f / blk) * stride + f % blk
 __global__ void k_moved_global(int n_true, int blk, int stride, const uint8_t* __restrict__ lab_new,

@@ -61,7 +61,6 @@ struct SweepArgs {
     // its label block (the label all-gather then carries it to every rank)
     uint8_t* publish_byte; int* publish_ticket;
 };
-void launch_publish_flag(const int* flags4, uint8_t* out_byte, const int* stop, hipStream_t s);
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
                          const int* stop, const CtrlArgs* ctrl, hipStream_t s);
 

@@ -83,14 +83,6 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
 
-    def allreduce_sum_(self, t):
-        if self.backend == "gloo" and t.is_cuda:
-            h = t.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        else:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-
     def allreduce_max_int(self, v):
         t = self.torch.tensor([int(v)], dtype=self.torch.int32)
         if self.backend != "gloo":
