@@ -443,7 +443,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
-    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     // NCEM: the bookkeeping (masks, "moved", loop tests) rides in the last relaxation round's launch
     if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? &ca : nullptr, true))) { e->cur = saved; return r; }
     if (!e->ncem()) { if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; } }
@@ -476,7 +476,7 @@ int enqueue_init(nemgpu_engine* e)
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
-    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.is_init = 1;
     if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? &ca : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
     if (e->ncem()) e->masks_valid = true;
@@ -761,7 +761,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
     A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
     A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
-    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)2));   // [0] sweep number, [1] last-block ticket
+    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)32 + kTicketWords));   // [0] sweep number, [32..] last-block ticket counters
     A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
     A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
     A(dev_alloc(&e->mask, (size_t)k * e->nw64));
@@ -1228,7 +1228,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
     // the same launch builds the class masks of its output (for nemgpu_shard_counts) and publishes the flag byte
     a.post_on = 1; a.post_from_guess = 0; a.post_moved = 0; a.post_nw64 = e->nw64; a.post_mask = e->mask;
     a.post_flags = e->iter_flags();
-    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 1;
+    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = false;
@@ -1247,7 +1247,7 @@ int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const 
     a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
     a.flags = e->round_flags(1);
     a.flags_in = labels_guess_dev + e->sh_blk;                     // rank 0's flag byte; stride = slot_stride
-    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 1;
+    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
@@ -1262,7 +1262,7 @@ int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, con
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = beta != 0.0f ? 1 : 0; ca.cvtest = e->cfg.cvtest; ca.ncem = 1;
-    ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 1;
+    ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.q_flags = labels_q_dev + e->sh_blk; ca.r_flags = labels_r_dev + e->sh_blk;
     ca.n_ranks = e->sh_world; ca.flag_stride = e->sh_stride; ca.is_init = is_init;
     launch_moved_global(e->n_true, e->sh_blk, e->sh_stride, labels_q_dev, labels_old_dev, e->iter_flags(), e->stop_ptr,

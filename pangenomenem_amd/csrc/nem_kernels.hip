@@ -753,15 +753,34 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
 
 // last-block-done ticket: returns true in exactly one thread of the grid, after every block's global
 // writes (made before its call) are visible to it
+// Two levels (groups of blocks, then the groups) once the grid is larger than 32 blocks: same-address atomics
+// are served one after the other (~45 ns each on MI355X), so a flat counter costs 9 us at 200 blocks; with at most
+// 32 groups on counters 128 bytes apart it is ~sqrt of that.  `ticket` points at kTicketWords zeroed ints.
 __device__ inline bool last_block_ticket(int* ticket, int nblocks)
 {
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        const int t = atomicAdd(ticket, 1);
-        s_last = (t == nblocks - 1);
-        if (s_last) { *ticket = 0; __threadfence(); }
+        int last = 0;
+        if (nblocks <= 32) {
+            const int t = atomicAdd(ticket, 1);
+            last = (t == nblocks - 1);
+            if (last) *ticket = 0;
+        } else {
+            const int gsz = (nblocks + 31) / 32;                   // blocks per group; at most 32 groups
+            const int g = blockIdx.x / gsz;
+            const int ng = (nblocks + gsz - 1) / gsz;
+            const int members = min(gsz, nblocks - g * gsz);
+            int* gc = ticket + 32 * (1 + g);
+            if (atomicAdd(gc, 1) == members - 1) {
+                *gc = 0;
+                __threadfence();
+                if (atomicAdd(ticket, 1) == ng - 1) { *ticket = 0; last = 1; }
+            }
+        }
+        if (last) __threadfence();
+        s_last = last;
     }
     __syncthreads();
     return s_last && threadIdx.x == 0;

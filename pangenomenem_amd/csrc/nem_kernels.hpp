@@ -8,6 +8,7 @@
 namespace nemk {
 
 constexpr int kMaxKernelK = 32;
+constexpr int kTicketWords = 32 * 33;   // last-block ticket: top counter + 32 group counters, 128 bytes apart
 constexpr double kEpsilonD = 1e-20;   // EPSILON, reference nem_typ.h:63
 
 // per-round flag slot of an E2 sweep
