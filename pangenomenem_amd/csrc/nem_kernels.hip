@@ -1034,36 +1034,56 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
 
 // M1-M3 for NCEM as integer counts: S1[k][d] = #{i : label_i = k, x_id = 1}, N_k = #{label = k}.
 // grid = d + 1 blocks (the last one counts class sizes); out: stats[0..K) = N_k, stats[K + k*d + j] = S1.
+template <int R>
 __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, const uint64_t* __restrict__ xt,
                                                       const uint64_t* __restrict__ mask, int* __restrict__ stats,
                                                       const int* __restrict__ stop)
 {
-    __shared__ int red[4][4];
+    // R organism rows per block (row D = the all-ones row that counts the class sizes): each class-mask word is
+    // loaded once for R rows, so the masks' L2 traffic (K * N/8 bytes per block) shrinks by R
+    __shared__ int red[4][R][4];
     if (stop != nullptr && *stop) return;
-    const int d = blockIdx.x;
+    const int d0 = blockIdx.x * R;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t* __restrict__ row = xt + (size_t)(d < D ? d : 0) * nw64;
-    // four classes per pass over the organism's bit row (K = 3: the row is read once)
+    const uint64_t* rows[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rows[r] = xt + (size_t)min(d0 + r, D - 1) * nw64;
+    // four classes per pass over the bit rows (K = 3: the rows are read once)
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int kn = min(4, K - k0);
-        int acc[4] = {0, 0, 0, 0};
+        int acc[4][R];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[c][r] = 0;
         for (int j = threadIdx.x; j < nw64; j += 256) {
-            const uint64_t xv = (d < D) ? row[j] : ~0ull;
+            uint64_t xv[R];
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (c < kn) acc[c] += __popcll(xv & mask[(size_t)(k0 + c) * nw64 + j]);
+            for (int r = 0; r < R; r++) xv[r] = (d0 + r < D) ? rows[r][j] : ~0ull;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (c < kn) {
+                    const uint64_t m = mask[(size_t)(k0 + c) * nw64 + j];
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[c][r] += __popcll(xv[r] & m);
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int v = wave_reduce_add(acc[c]);
-            if (lane == 0) red[c][wv] = v;
-        }
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int v = wave_reduce_add(acc[c][r]);
+                if (lane == 0) red[c][r][wv] = v;
+            }
         __syncthreads();
-        if (threadIdx.x < kn) {
-            const int c = threadIdx.x, k = k0 + c;
-            const int v = red[c][0] + red[c][1] + red[c][2] + red[c][3];
-            if (d < D) stats[K + k * D + d] = v; else stats[k] = v;
+        if (threadIdx.x < 4 * R) {
+            const int c = threadIdx.x / R, r = threadIdx.x % R, k = k0 + c, d = d0 + r;
+            if (c < kn && d <= D) {
+                const int v = red[c][r][0] + red[c][r][1] + red[c][r][2] + red[c][r][3];
+                if (d < D) stats[K + k * D + d] = v; else stats[k] = v;
+            }
         }
     }
 }
@@ -1554,7 +1574,10 @@ void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
                          const int* stop, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mstep_counts, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
+    // wide matrices: 4 organism rows per block (fewer re-reads of the class masks); narrow ones keep one row per
+    // block so that the launch still spreads over the CUs
+    if (D + 1 >= 1024) hipLaunchKernelGGL(k_mstep_counts<4>, dim3((D + 1 + 3) / 4), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
+    else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
