@@ -110,6 +110,14 @@ struct nemgpu_engine {
     // auto: on from 256 organisms (below that the chain is mostly the small-binade prefix that is stepped anyway
     // and the table build is pure overhead).  Measured on MI355X: 20k x 500 on par with plain stepping
     // (latency-bound, one wave per SIMD), 50k x 1000 1.7x, 200k x 5000 9x faster.
+    // parameter update folded into the density launch: per-organism dispersions (skd) always; one dispersion per
+    // class (sk_) only while InerToDispK_'s d-ordered sums provably never round (N*D <= 2^24: closed form) --
+    // beyond that every block would redo a D-step sequential chain, which k_finish does once
+    bool fused_update() const
+    {
+        return d <= kFusedMaxD && (cfg.disper == NEMGPU_DISP_KD ||
+                                   (cfg.disper == NEMGPU_DISP_K_ && (long long)n_true * d <= (1ll << 24)));
+    }
     bool use_ff() const { return ff_mode < 0 ? d >= 256 : ff_mode != 0; }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
@@ -418,8 +426,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     int r;
     const int saved = e->cur;
     e->cur = cur;
-    const bool fused = !e->cfg.param_fix && e->ncem() && e->d <= kFusedMaxD &&
-                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
+    const bool fused = !e->cfg.param_fix && e->ncem() && e->fused_update();
     if (fused) {
         // M-step counts, then ONE kernel: parameter update (per block, from the counts) + density
         if (!e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) { e->cur = saved; return r; } }
@@ -1197,8 +1204,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
     if (!e || !labels_old_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     int r;
-    const bool fused = stats_dev != nullptr && e->d <= kFusedMaxD &&
-                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
+    const bool fused = stats_dev != nullptr && e->fused_update();
     if (fused) {
         // parameter update (per block, from the summed counts) + density in one launch
         FinishArgs t = finish_args(e, 1, stats_dev);
@@ -1441,8 +1447,7 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
     if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }
     double total = 0.0;
     // measure the kernel the EM loop actually launches: the fused one (parameter update + density) when it applies
-    const bool fused = !e->cfg.param_fix && e->ncem() && e->d <= kFusedMaxD && e->iters > 0 &&
-                       (e->cfg.disper == NEMGPU_DISP_K_ || e->cfg.disper == NEMGPU_DISP_KD);
+    const bool fused = !e->cfg.param_fix && e->ncem() && e->fused_update() && e->iters > 0;
     for (int i = 0; i < reps; i++) {
         HIPCHK(hipEventRecord(e->ev0, e->stream));
         if (fused) {
