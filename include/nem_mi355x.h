@@ -194,6 +194,20 @@ int nemgpu_shard_end_enqueue(nemgpu_engine* e);   /* async copy of the control b
 int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* need_rounds);   /* sync + report */
 int nemgpu_shard_set_sweep_number(nemgpu_engine* e, int next_sweep);
 
+/* RCCL called directly: the sharded EM's one collective (the in-place all-gather of label blocks) issued from C, so
+   that a whole batch -- kernels and all-gathers -- is enqueued by ONE call instead of a Python round trip per
+   launch.  librccl.so is bound at run time (pass the path of the library PyTorch ships; NULL: the loader's default);
+   torch.distributed remains the bootstrap (it carries the 128-byte ncclUniqueId from rank 0) and the fallback.
+   nemgpu_rccl_attach is collective over the job's ranks.  nemgpu_shard_enqueue_batch = nemgpu_shard_begin,
+   [the two initial sweeps], n_iters iterations (round 0, all-gather, round 1 + counts, all-gather, convergence +
+   loop control), nemgpu_shard_end_enqueue; follow with nemgpu_shard_end.  lab0..2: the three all-gathered label
+   arrays; stats_off: byte offset of a rank's statistics inside its block; base: buffer of the current partition. */
+int nemgpu_rccl_open(const char* librccl_path);
+int nemgpu_rccl_unique_id(uint8_t id128[128]);
+int nemgpu_rccl_attach(nemgpu_engine* e, const uint8_t id128[128], int world, int rank);
+int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
+                               uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off);
+
 /* Test hook: load a partition (row-major [n_total x k], HOST) as the current state
    (argmax labels for ncem engines). */
 int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk);

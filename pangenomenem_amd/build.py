@@ -12,7 +12,7 @@ SRC = [os.path.join(HERE, "csrc", f) for f in ("nem_kernels.hip", "nem_engine.hi
 HDR = [os.path.join(HERE, "csrc", f) for f in ("nem_kernels.hpp", "nem_internal.hpp", "nem_ff.hpp", "nem_rng.hpp")] + \
       [os.path.join(HERE, "..", "include", "nem_mi355x.h")]
 LIB = os.path.join(HERE, "lib", "libnem_mi355x.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17", "-ldl",
          "-Wall", "-Wno-unused-function"]
 
 

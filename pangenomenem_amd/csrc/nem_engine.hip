@@ -5,6 +5,7 @@
 // numeric work in the kernels of nem_kernels.hip.  There is no CPU compute path here: every
 // entry point returns NEMGPU_E_DEVICE when HIP is unusable.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -43,6 +44,7 @@ constexpr int kRoundBatch = 2;    // rounds enqueued between host checks (round 
 struct nemgpu_engine {
     int n_total = 0, d = 0, k = 0, lo = 0, hi = 0, n = 0;
     int n_true = 0;               // families of the whole problem (= n_total unless label slots carry padding)
+    void* rccl_comm = nullptr;           // native RCCL communicator of a sharded engine (nemgpu_rccl_attach)
     int sh_world = 1, sh_rank = 0, sh_blk = 0, sh_stride = 0;   // sharded label-slot layout (stride 0 = plain)
     int npad = 0, dpad = 0, W = 0, wf = 0, nw64 = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -782,11 +784,14 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     return NEMGPU_OK;
 }
 
+void rccl_release(nemgpu_engine* e);
+
 void nemgpu_destroy(nemgpu_engine* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    rccl_release(e);
     void* ptrs[] = {e->xw, e->xws, e->perm, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
                     e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
                     e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->sweep_next, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
@@ -1329,6 +1334,136 @@ int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* ne
     if (need_rounds) *need_rounds = c[C_NEED_ROUNDS];
     e->flags_clean = false;
     return NEMGPU_OK;
+}
+
+// ---- RCCL called directly (no Python between the launches of a batch) ------------------------------------------
+// The sharded EM needs one collective, an in-place all-gather of label blocks.  Issued through torch.distributed
+// every call costs tens of microseconds of host time, more than the iteration's kernels; issued from here the whole
+// batch -- kernels and all-gathers -- is enqueued by one C call.  librccl.so (the one PyTorch ships and has already
+// loaded) is bound at run time; torch.distributed stays the bootstrap (it carries the ncclUniqueId) and the fallback.
+struct nccl_uid_t { char internal[128]; };                                     // ncclUniqueId, rccl.h:40-43
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    int (*get_unique_id)(nccl_uid_t*) = nullptr;                               // ncclGetUniqueId
+    int (*comm_init_rank)(void**, int, nccl_uid_t, int) = nullptr;             // ncclCommInitRank(comm*, nranks, id, rank)
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_fail(const char* what, int code)
+{
+    set_error(std::string(what) + " failed: " + (g_rccl.error_string ? g_rccl.error_string(code) : "?"));
+    return NEMGPU_E_DEVICE;
+}
+}  // namespace
+
+int nemgpu_rccl_open(const char* librccl_path)
+{
+    if (g_rccl.handle) return NEMGPU_OK;
+    void* h = dlopen(librccl_path && librccl_path[0] ? librccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { set_error(std::string("dlopen(librccl) failed: ") + dlerror()); return NEMGPU_E_DEVICE; }
+    g_rccl.get_unique_id = (int (*)(nccl_uid_t*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (int (*)(void**, int, nccl_uid_t, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.comm_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy) {
+        set_error("librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+        dlclose(h);
+        return NEMGPU_E_DEVICE;
+    }
+    g_rccl.handle = h;
+    return NEMGPU_OK;
+}
+
+int nemgpu_rccl_unique_id(uint8_t id128[128])
+{
+    if (!id128) return NEMGPU_E_FUNCARG;
+    if (!g_rccl.handle) { set_error("nemgpu_rccl_open first"); return NEMGPU_E_FUNCARG; }
+    nccl_uid_t id;
+    int rc = g_rccl.get_unique_id(&id);
+    if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(id128, id.internal, 128);
+    return NEMGPU_OK;
+}
+
+void rccl_release(nemgpu_engine* e)
+{
+    if (e->rccl_comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(e->rccl_comm);
+    e->rccl_comm = nullptr;
+}
+
+// collective: every rank of the job calls it with the id rank 0 produced
+int nemgpu_rccl_attach(nemgpu_engine* e, const uint8_t id128[128], int world, int rank)
+{
+    if (!e || !id128 || world <= 0 || rank < 0 || rank >= world) return NEMGPU_E_FUNCARG;
+    if (!g_rccl.handle) { set_error("nemgpu_rccl_open first"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    nccl_uid_t id;
+    memcpy(id.internal, id128, 128);
+    void* comm = nullptr;
+    int rc = g_rccl.comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
+    e->rccl_comm = comm;
+    return NEMGPU_OK;
+}
+
+namespace {
+int rccl_allgather_blocks(nemgpu_engine* e, uint8_t* buf)
+{
+    const size_t stride = (size_t)e->sh_stride;
+    int rc = g_rccl.all_gather(buf + (size_t)e->sh_rank * stride, buf, stride, /*ncclUint8*/ 1, e->rccl_comm, e->stream);
+    if (rc != 0) return rccl_fail("ncclAllGather", rc);
+    return NEMGPU_OK;
+}
+}  // namespace
+
+// One whole batch of the sharded EM -- [the two initial sweeps +] n_iters iterations, all-gathers included --
+// enqueued on the engine's stream without returning to the caller in between (what ShardedNem._enqueue_batch
+// does through torch.distributed).  lab[3]: the all-gathered label arrays; stats_off: byte offset of a rank's
+// statistics inside its block; base: buffer of the current partition (2 after an init).
+int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
+                               uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off)
+{
+    if (!e || !lab0 || !lab1 || !lab2 || n_iters < 0 || base < 0 || base > 2) return NEMGPU_E_FUNCARG;
+    if (!e->rccl_comm) { set_error("nemgpu_rccl_attach first"); return NEMGPU_E_FUNCARG; }
+    uint8_t* L[3] = {lab0, lab1, lab2};
+    const bool use_nei = beta != 0.0f;
+    auto own_stats = [&](uint8_t* buf) { return (int32_t*)(buf + (size_t)e->sh_rank * e->sh_stride + stats_off); };
+    auto all_stats = [&](uint8_t* buf) { return (const int32_t*)(buf + stats_off); };
+    int r;
+#define NEM_TRY(call) do { if ((r = (call)) != NEMGPU_OK) return r; } while (0)
+    NEM_TRY(nemgpu_shard_begin(e));
+    if (with_init) {
+        NEM_TRY(nemgpu_shard_estep_round0(e, nullptr, 0.0f, 0, L[0], L[1]));       // blind sweep
+        NEM_TRY(rccl_allgather_blocks(e, L[1]));
+        NEM_TRY(nemgpu_shard_estep_round0(e, nullptr, beta, 1, L[1], L[2]));
+        if (want_stats && !use_nei) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[2])));
+        NEM_TRY(rccl_allgather_blocks(e, L[2]));
+        if (use_nei) {
+            NEM_TRY(nemgpu_shard_estep_round1(e, beta, 1, L[1], L[2], L[0]));
+            if (want_stats) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[0])));
+            NEM_TRY(rccl_allgather_blocks(e, L[0]));
+        }
+        NEM_TRY(nemgpu_shard_finish_iteration(e, beta, 1, L[1], L[2], L[0]));
+    }
+    for (int j = 0; j < n_iters; j++) {
+        const int P = (base + j) % 3, Q = (P + 1) % 3, R = (P + 2) % 3;
+        const int S = use_nei ? Q : P;                                             // where P's statistics were gathered
+        NEM_TRY(nemgpu_shard_estep_round0(e, want_stats ? all_stats(L[S]) : nullptr, beta, -1, L[P], L[Q]));
+        if (want_stats && !use_nei) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[Q])));
+        NEM_TRY(rccl_allgather_blocks(e, L[Q]));
+        if (use_nei) {
+            NEM_TRY(nemgpu_shard_estep_round1(e, beta, -1, L[P], L[Q], L[R]));
+            if (want_stats) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[R])));
+            NEM_TRY(rccl_allgather_blocks(e, L[R]));
+        }
+        NEM_TRY(nemgpu_shard_finish_iteration(e, beta, 0, L[P], L[Q], L[R]));
+    }
+#undef NEM_TRY
+    return nemgpu_shard_end_enqueue(e);
 }
 
 // host-side completion of an iteration whose sweep needed extra rounds: count it like k_ctrl would have

@@ -127,6 +127,47 @@ class GpuStepper:
     def alloc(self, n, dtype):
         return self.torch.zeros(n, dtype=getattr(self.torch, dtype), device=self.device)
 
+    # ---- RCCL called directly from the library (one C call enqueues a whole batch, collectives included)
+    native = False
+
+    def enable_native(self, comm):
+        """Give the engine its own RCCL communicator over the ranks of `comm`.  torch.distributed is the bootstrap:
+        it carries rank 0's ncclUniqueId to everybody and lets the ranks agree on whether the attempt worked.
+        Collective; returns True when every rank attached."""
+        import ctypes
+        import os
+        torch, dist = self.torch, comm.dist
+        ok = 1
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        try:
+            lib = self.eng.lib
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if lib.nemgpu_rccl_open(path.encode() if os.path.isfile(path) else None) != 0:
+                ok = 0
+            if ok and comm.rank == 0:
+                buf = (ctypes.c_uint8 * 128)()
+                if lib.nemgpu_rccl_unique_id(buf) != 0:
+                    ok = 0
+                else:
+                    uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        except Exception:
+            ok = 0
+        # every rank goes through the same collectives whatever happened above
+        dist.broadcast(uid, src=0, group=comm.group)
+        if comm.allreduce_max_int(0 if ok else 1) != 0:
+            return False
+        host = (ctypes.c_uint8 * 128).from_buffer_copy(uid.cpu().numpy().tobytes())
+        try:
+            self.eng._chk(self.eng.lib.nemgpu_rccl_attach(self.eng._h, ctypes.addressof(host), comm.world, comm.rank))
+        except Exception:
+            ok = 0
+        self.native = comm.allreduce_max_int(0 if ok else 1) == 0
+        return self.native
+
+    def enqueue_batch_native(self, with_init, n_iters, base, beta, want_stats, labels):
+        self.eng.shard_enqueue_batch(with_init, n_iters, base, beta, want_stats, [t.data_ptr() for t in labels],
+                                     stats_offset(self.blk))
+
     def on_stream(self):
         """Context under which the driver issues this rank's work (kernels through the engine, collectives
         through torch): the stepper's stream."""
@@ -220,6 +261,12 @@ class ShardedNem:
         # development box and a wedged replay would cost the whole job, while eager launches are only ~1.7x slower
         default = "1" if comm.world == 1 else "0"
         self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", default) != "0"
+        # RCCL straight from the library: a whole batch (kernels + all-gathers) per C call.  On by default over the
+        # nccl backend; NEM_DIST_NATIVE=0 keeps every collective in torch.distributed.
+        self.native = False
+        if (comm.backend == "nccl" and hasattr(stepper, "enable_native")
+                and os.environ.get("NEM_DIST_NATIVE", "1") != "0"):
+            self.native = bool(stepper.enable_native(comm))
         self._graphs, self._seen = {}, set()
         self.reset()
 
@@ -299,6 +346,9 @@ class ShardedNem:
         return Q
 
     def _enqueue_batch(self, with_init, g, base):
+        if self.native:
+            self.st.enqueue_batch_native(with_init, g, base, self.beta, not self.param_fix, self.labels)
+            return
         self.st.begin()
         if with_init:
             self._enqueue_init()

@@ -85,6 +85,10 @@ def load_library():
     lib.nemgpu_shard_begin.argtypes = [vp]
     lib.nemgpu_shard_mstep_partial.argtypes = [vp, vp, vp]
     lib.nemgpu_shard_counts.argtypes = [vp, vp]
+    lib.nemgpu_rccl_open.argtypes = [C.c_char_p]
+    lib.nemgpu_rccl_unique_id.argtypes = [vp]
+    lib.nemgpu_rccl_attach.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.nemgpu_shard_enqueue_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, C.c_int]
     lib.nemgpu_shard_estep_round0.argtypes = [vp, vp, C.c_float, C.c_int, vp, vp]
     lib.nemgpu_shard_estep_round1.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
     lib.nemgpu_shard_finish_iteration.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
@@ -281,6 +285,11 @@ class NemEngine:
 
     def shard_mstep_partial(self, labels_ptr, stats_ptr):
         self._chk(self.lib.nemgpu_shard_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
+
+    def shard_enqueue_batch(self, with_init, n_iters, base, beta, want_stats, lab_ptrs, stats_off):
+        self._chk(self.lib.nemgpu_shard_enqueue_batch(self._h, int(with_init), int(n_iters), int(base), C.c_float(beta),
+                                                      int(want_stats), C.c_void_p(lab_ptrs[0]), C.c_void_p(lab_ptrs[1]),
+                                                      C.c_void_p(lab_ptrs[2]), int(stats_off)))
 
     def shard_counts(self, stats_ptr):
         self._chk(self.lib.nemgpu_shard_counts(self._h, C.c_void_p(stats_ptr)))
