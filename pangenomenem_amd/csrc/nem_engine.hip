@@ -666,7 +666,7 @@ int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
     const float* c = float_partition(e, buf < 0 ? e->cur : buf);
     launch_criteria(e->n, e->k, e->npad, e->nei_ptr, e->nei_idx, e->nei_w, e->has_graph ? 1 : 0, e->cfg.beta, c,
                     e->pkfki, e->logpkfki, e->crit_dik, e->crit_gik, e->crit_lfi, e->crit_lzi, e->crit6_dev,
-                    e->stream);
+                    e->ncem() ? 1 : 0, e->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(crit6, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -1439,12 +1439,15 @@ __global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, cons
                                                     const double* __restrict__ pkfki,
                                                     const float* __restrict__ logpkfki, float* __restrict__ dik,
                                                     float* __restrict__ gik, double* __restrict__ lfi,
-                                                    double* __restrict__ lzi)
+                                                    double* __restrict__ lzi, int hard)
 {
+    // hard (NCEM): rows are one-hot, so a site adds exactly one term to D and to G -- stored as ONE entry per site,
+    // which makes the i-ordered chains of k_crit_reduce K times shorter (same adds, same order)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double fi = 0.0;
     float zi = 0.0f;
+    float dsel = -0.0f, gsel = -0.0f;
     const int b = use_nei ? nei_ptr[i] : 0, e = use_nei ? nei_ptr[i + 1] : 0;
     for (int k = 0; k < K; k++) {
         const float cik = c[(size_t)i * K + k];
@@ -1458,11 +1461,12 @@ __global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, cons
             dv = (float)((double)cik * ((double)lp - log((double)cik)));  // :2731
             gv = cik * pik;                                               // :2732
         }
-        dik[(size_t)i * K + k] = dv;
-        gik[(size_t)i * K + k] = gv;
+        if (hard) { if (cik > FLT_MIN) { dsel = dv; gsel = gv; } }
+        else { dik[(size_t)i * K + k] = dv; gik[(size_t)i * K + k] = gv; }
         fi = fi + pkfki[(size_t)k * npad + i];                            // :2739
         zi = (float)((double)zi + exp((double)(beta * pik)));             // :2740
     }
+    if (hard) { dik[i] = dsel; gik[i] = gsel; }
     lfi[i] = log(fi);                                                     // :2744
     lzi[i] = log((double)zi);                                             // :2745
 }
@@ -1624,11 +1628,11 @@ void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStr
 
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
                      float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
-                     double* lfi, double* lzi, float* crit6, hipStream_t s)
+                     double* lfi, double* lzi, float* crit6, int hard, hipStream_t s)
 {
     hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, n, K, npad, nei_ptr, nei_idx, nei_w,
-                       use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi);
-    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, K, beta, dik, gik, lfi, lzi, crit6);
+                       use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi, hard);
+    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, hard ? 1 : K, beta, dik, gik, lfi, lzi, crit6);
 }
 
 }  // namespace nemk

@@ -106,6 +106,6 @@ void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStr
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s);
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
                      float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
-                     double* lfi, double* lzi, float* crit6, hipStream_t s);
+                     double* lfi, double* lzi, float* crit6, int hard, hipStream_t s);   // hard: one-hot rows (NCEM)
 
 }  // namespace nemk
