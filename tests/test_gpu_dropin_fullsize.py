@@ -57,11 +57,8 @@ def test_dropin_whole_call_at_configs1(gpu_lib, tmp_path):
     assert len(labels) == cfg["x"].shape[0]
     # <Fname>.log: the per-iteration log (criteria before / after each E-step, all parameters), line for line
     # except the date in the first one
-    ours_log, ref_log = open(base + ".log").read().split("\n"), open(ref_base + ".log").read().split("\n")
-    assert ours_log[0].startswith("NEM log file  -  ") and ref_log[0].startswith("NEM log file  -  ")
-    assert len(ours_log) == len(ref_log)
-    for i, (a, b) in enumerate(zip(ours_log[1:], ref_log[1:])):
-        assert a == b, (i + 1, a[:120], b[:120])
+    from tests.util import assert_same_nem_log
+    assert_same_nem_log(open(base + ".log").read(), open(ref_base + ".log").read())
 
     rec = dict(workload="BASELINE configs[1] files: 20000 x 500, K=3, beta=0.5, ncem/sk_/pk, dolog=1",
                input_bytes=sum(os.path.getsize(base + e) for e in (".str", ".dat", ".nei", ".m")),

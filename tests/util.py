@@ -43,3 +43,20 @@ def random_hard_partition(n, k, seed):
     c = np.zeros((n, k), np.float32)
     c[np.arange(n), lab] = 1.0
     return c
+
+
+def assert_same_nem_log(ours_text, ref_text):
+    """<Fname>.log against the reference's: every line identical except the date in the first one; the four criteria
+    columns of an iteration line (%5.0f of i-ordered float sums that pass through the device's exp/log) may differ by
+    one unit in the last printed digit."""
+    a, b = ours_text.split("\n"), ref_text.split("\n")
+    assert a[0].startswith("NEM log file  -  ") and b[0].startswith("NEM log file  -  ")
+    assert len(a) == len(b) and len(a) > 6, (len(a), len(b))
+    for i, (u, v) in enumerate(zip(a[1:], b[1:])):
+        if u == v:
+            continue
+        tu, tv = u.split(), v.split()
+        assert len(tu) == len(tv), (i + 1, u[:100], v[:100])
+        for p, (s, t) in enumerate(zip(tu, tv)):
+            if s != t:
+                assert p in (1, 2, 4, 5) and abs(float(s) - float(t)) <= 1.0, (i + 1, p, s, t)
