@@ -47,3 +47,26 @@ def test_concurrent_dropin_calls(gpu_lib, tmp_path):
     for c, uf, mf in zip(calls, alone, alone_mf):
         assert open(c["Fname"].decode() + ".uf", "rb").read() == uf
         assert open(c["Fname"].decode() + ".mf", "rb").read() == mf
+
+
+@pytest.mark.parametrize("free_dispersion", [False, True])
+def test_run_partitioning_arrays_equals_the_file_route(gpu_lib, tmp_path, free_dispersion):
+    """The in-memory counterpart of PPanGGOLiN's run_partitioning (f1) returns what parsing nem()'s files returns."""
+    import nem as nem_module
+    from pangenomenem_amd.partitioning import run_partitioning_arrays
+    n, d = 4000, 90
+    x, _ = synth.bernoulli_pa_matrix(n, d, 71)
+    nei = synth.contiguity_graph(n, 71)
+    prop, center, disp = synth.default_init(d)
+    base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
+    rc = nem_module.nem(base.encode(), 3, b"ncem", 0.5, b"clas", 1e-8, b"fuzzy", 100, True, b"bern", b"pk",
+                        b"skd" if free_dispersion else b"sk_", 2)
+    assert rc == 0
+    labels, params, _, _ = nemfiles.read_nem_outputs(str(tmp_path), d, q=3)
+    got_labels, got_params = run_partitioning_arrays(x, nei, 0.5, free_dispersion)
+    assert [got_labels["fam%d" % (i + 1)] for i in range(n)] == labels
+    assert set(got_labels.values()) <= {"P", "S", "C"}
+    for k in range(3):
+        assert got_params[k][0] == params[k][0]                                  # mu as booleans
+        assert np.allclose(got_params[k][1], params[k][1], rtol=0, atol=1e-5)    # epsilon through the .mf text
+        assert abs(got_params[k][2] - params[k][2]) <= 5.1e-4                   # pi is printed with 3 decimals
