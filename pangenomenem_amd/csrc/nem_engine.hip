@@ -730,6 +730,12 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
         set_error("nemgpu_create: bad sizes (need n,d > 0, 1 <= k <= 32, 0 <= lo < hi <= n)");
         return NEMGPU_E_ARG;
     }
+    if (n_total > (1 << 24)) {
+        // class sizes are float sums of 0/1 memberships in the reference (EstimSizes, nem_mod.c:1293-1315): exact
+        // integers only up to 2^24, which is what the popcount M-step reproduces
+        set_error("nemgpu_create: more than 2^24 families (the reference's float class sizes stop being integers)");
+        return NEMGPU_E_ARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no usable HIP device: this library has no CPU fallback");

@@ -50,10 +50,10 @@ def _run(world, backend, n, d, beta):
     return [np.load(os.path.join(outdir, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
-def test_gpu_sharded_matches_oracle(gpu_lib, oracle, world, backend):
+@pytest.mark.parametrize("world,backend,beta", [(1, "nccl", 0.5), (2, "gloo", 0.5), (1, "nccl", 0.0), (2, "gloo", 0.0)])
+def test_gpu_sharded_matches_oracle(gpu_lib, oracle, world, backend, beta):
     from pangenomenem_amd import synth
-    n, d, beta = 4096, 15, 0.5
+    n, d = 4096, 15
     outs = _run(world, backend, n, d, beta)
     x, _ = synth.bernoulli_pa_matrix(n, d, 1)
     prop, center, disp = synth.default_init(d)
