@@ -246,26 +246,28 @@ __device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int 
 // sQ0 / sQ1: the class's 256-entry increment tables (LDS).  Bit-identical to chain_plain.
 constexpr int kFFPlainWords = 2;
 
-__device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sQ1, uint32_t bits, uint32_t& q0, uint32_t& q1,
+// sQ0[E] = q0, sDQ[E] = q1 - q0 (both at most 2^23: 24-bit multiplies), see ff_build
+__device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sDQ, uint32_t bits, uint32_t& q0, uint32_t& dq,
                                         uint32_t& end)
 {
     const uint32_t E = (bits >> 23) & 255u;
     q0 = sQ0[E];
-    q1 = sQ1[E];
+    dq = sDQ[E];
     end = (E + 1u) << 23;
 }
 
-// pattern after n organisms of which p mismatch (counts <= 32, increments <= 2^23: 24-bit multiplies, sum < 2^32)
-__device__ __forceinline__ uint32_t ff_advance(uint32_t bits, uint32_t n, uint32_t p, uint32_t q0, uint32_t q1)
+// pattern after n organisms of which p mismatch: bits + n*q0 + p*(q1 - q0)  (two multiply-adds; the sum stays
+// below 2^32: pattern < 2^31, n <= 32 increments of at most 2^23)
+__device__ __forceinline__ uint32_t ff_advance(uint32_t bits, uint32_t n, uint32_t p, uint32_t q0, uint32_t dq)
 {
-    return bits + __umul24(n - p, q0) + __umul24(p, q1);
+    return bits + __umul24(n, q0) + __umul24(p, dq);
 }
 
 // one word (nb organisms, mismatch bits m) of the fast-forwarded chain
-__device__ __forceinline__ void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& q1, uint32_t& end, uint32_t m, int nb,
-                                        const uint32_t* sQ0, const uint32_t* sQ1, double l1h, double l0)
+__device__ __forceinline__ void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& dq, uint32_t& end, uint32_t m, int nb,
+                                        const uint32_t* sQ0, const uint32_t* sDQ, double l1h, double l0)
 {
-    const uint32_t cand = ff_advance(bits, (uint32_t)nb, (uint32_t)__popc(m), q0, q1);
+    const uint32_t cand = ff_advance(bits, (uint32_t)nb, (uint32_t)__popc(m), q0, dq);
     const bool ok = cand < end;
     if (ok) bits = cand;
     if (__all(ok)) return;
@@ -277,26 +279,26 @@ __device__ __forceinline__ void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& 
 #pragma unroll
             for (int st = 16; st >= 1; st >>= 1) {
                 const int t = j + st;
-                const uint32_t f = ff_advance(bits, (uint32_t)t, (uint32_t)__popc(mm & ((1u << t) - 1u)), q0, q1);
+                const uint32_t f = ff_advance(bits, (uint32_t)t, (uint32_t)__popc(mm & ((1u << t) - 1u)), q0, dq);
                 if (f < end) j = t;                      // (f(t) >= f(rem) >= end for t >= rem: never accepted)
             }
-            bits = ff_advance(bits, (uint32_t)j, (uint32_t)__popc(mm & ((1u << j) - 1u)), q0, q1);
+            bits = ff_advance(bits, (uint32_t)j, (uint32_t)__popc(mm & ((1u << j) - 1u)), q0, dq);
             bits = __float_as_uint(bern_step(__uint_as_float(bits), mm, j, l1h, l0));
             rem -= j + 1;
             if (rem <= 0) break;
             mm = mm >> (j + 1);                          // j + 1 <= 31 here
-            ff_load(sQ0, sQ1, bits, q0, q1, end);
-            const uint32_t c2 = ff_advance(bits, (uint32_t)rem, (uint32_t)__popc(mm), q0, q1);
+            ff_load(sQ0, sDQ, bits, q0, dq, end);
+            const uint32_t c2 = ff_advance(bits, (uint32_t)rem, (uint32_t)__popc(mm), q0, dq);
             if (c2 < end) { bits = c2; break; }
         }
-        ff_load(sQ0, sQ1, bits, q0, q1, end);
+        ff_load(sQ0, sDQ, bits, q0, dq, end);
     }
 }
 
 // four full words (128 organisms) of the fast-forwarded chain
 __device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint32_t* am0, const uint32_t* am1, uint32_t& bits,
                                          uint32_t& q0, uint32_t& q1, uint32_t& end, const uint32_t* sQ0,
-                                         const uint32_t* sQ1, double l1h, double l0)
+                                         const uint32_t* sQ1, double l1h, double l0)   // (q1 / sQ1 carry q1 - q0)
 {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -363,12 +365,15 @@ __device__ __forceinline__ float chain_ff(const uint4* __restrict__ xw4, int npa
     return __uint_as_float(bits);
 }
 
-// the class's increment tables, one exponent per thread of a 256-thread block (caller synchronises)
-__device__ __forceinline__ void ff_build(uint32_t* sQ0, uint32_t* sQ1, double l1, double l0, int tid)
+// the class's increment tables, one exponent per thread of a 256-thread block (caller synchronises): q0 and
+// q1 - q0.  An unusable q0 makes the whole binade unusable (q1 - q0 must stay a 24-bit non-negative number); an
+// unusable q1 alone is kept: then q1 - q0 = 2^23 - q0 and a mismatch still "leaves the binade".
+__device__ __forceinline__ void ff_build(uint32_t* sQ0, uint32_t* sDQ, double l1, double l0, int tid)
 {
     uint32_t q0, q1;
     ff_entry(l1, -l0, tid, q0, q1);
-    sQ0[tid] = q0; sQ1[tid] = q1;
+    if (q0 == kFFInvalid) q1 = kFFInvalid;
+    sQ0[tid] = q0; sDQ[tid] = q1 - q0;
 }
 
 // Epilogue of both density kernels: lane tid of the tile ran family perm[tile*256 + tid], which lies in the same
