@@ -828,20 +828,41 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     if (active && !skip) {
 
     float ctx[KA];
+    double cinum[KA];
 #pragma unroll
     for (int k = 0; k < KA; k++) ctx[k] = 0.0f;
+    // the densities do not depend on the graph: requested first, so that they travel while the neighbour lists do
+#pragma unroll
+    for (int k = 0; k < KA; k++) if (k < K) cinum[k] = a.pkfki[(size_t)k * a.npad + i];
 
     if (a.use_nei) {
         const int b = a.nei_ptr[i], e = a.nei_ptr[i + 1];
-        for (int t = b; t < e; t++) {                    // SumNeighsOfClass, nem_alg.c:2865-2875
-            const int j = a.nei_idx[t];
-            const float wt = a.nei_w[t];
-            if (NCEM) {
-                const int lab = (j < gi) ? a.lab_guess[j] : a.lab_old[j];
+        if (NCEM) {
+            // four neighbours per trip: index and weight loads together, then the label gathers together (the adds
+            // keep the .nei order, SumNeighsOfClass nem_alg.c:2865-2875)
+            for (int t = b; t < e; t += 4) {
+                int jn[4]; float wn[4]; int ln[4];
 #pragma unroll
-                for (int k = 0; k < KA; k++)
-                    if (k < K) ctx[k] = ctx[k] + ((lab == k) ? wt : -0.0f);  // w*1 = w ; w*0 is an additive identity
-            } else {
+                for (int u = 0; u < 4; u++) {
+                    const bool ok = t + u < e;
+                    jn[u] = ok ? a.nei_idx[t + u] : gi;
+                    wn[u] = ok ? a.nei_w[t + u] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) ln[u] = (jn[u] < gi) ? a.lab_guess[jn[u]] : a.lab_old[jn[u]];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (t + u < e) {
+#pragma unroll
+                        for (int k = 0; k < KA; k++)
+                            if (k < K) ctx[k] = ctx[k] + ((ln[u] == k) ? wn[u] : -0.0f);   // w*1 = w ; w*0: additive identity
+                    }
+                }
+            }
+        } else {
+            for (int t = b; t < e; t++) {
+                const int j = a.nei_idx[t];
+                const float wt = a.nei_w[t];
                 const float* row = ((j < gi) ? a.c_guess : a.c_old) + (size_t)j * K;
 #pragma unroll
                 for (int k = 0; k < KA; k++)
@@ -850,12 +871,11 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         }
     }
 
-    double cinum[KA];
     double cum = 0.0;
 #pragma unroll
     for (int k = 0; k < KA; k++) {
         if (k < K) {                                     // nem_alg.c:2581-2584
-            double v = a.pkfki[(size_t)k * a.npad + i];
+            double v = cinum[k];
             if (a.use_nei) v = v * exp((double)a.beta * (double)ctx[k]);
             cinum[k] = v;
             cum = cum + v;
