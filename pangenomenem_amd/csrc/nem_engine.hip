@@ -383,11 +383,7 @@ int init_partition(nemgpu_engine* e)
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
     // ClassifM starts as zeros (calloc, nem_exe.c:524-526): the blind beta = 0 sweep never reads it
-    {   // one round, no neighbour reads: nothing to verify, no host sync needed
-        SweepCtx c;
-        if ((r = sweep_enqueue(e, 0.0f, c))) return r;
-        e->sweep_rounds += 1;
-    }
+    if ((r = do_sweep(e, 0.0f, nullptr))) return r;                // blind sweep: one round, no neighbour reads
     e->cur = (e->cur + 1) % 3;
     if ((r = do_sweep(e, e->cfg.beta, nullptr))) return r;
     e->cur = (e->cur + 1) % 3;
@@ -487,6 +483,7 @@ int enqueue_init(nemgpu_engine* e)
     ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.is_init = 1;
+    ca.blind = e->round_flags(kRoundCap - 1);
     if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? &ca : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
     if (e->ncem()) e->masks_valid = true;
     else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }

@@ -725,6 +725,10 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
     }
     if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
+        if (a.blind != nullptr && a.blind[FLAG_NZERO] > 0) {      // the blind sweep's zero-density sites come first
+            c[C_NZERO] += a.blind[FLAG_NZERO];
+            if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = a.blind[FLAG_FIRSTZERO];
+        }
         if (a.use_nei && ch0 != 0 && ch1 != 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
         const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
         c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one

@@ -31,6 +31,7 @@ struct CtrlArgs {
     // of each rank's block of the label arrays (nullptr on a single GPU: the int flags above are used)
     const uint8_t* q_flags; const uint8_t* r_flags; int n_ranks, flag_stride;
     int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
+    const int* blind;              // is_init: flag slot of the blind beta = 0 sweep (its zero-density tally), or nullptr
 };
 void launch_ctrl(const CtrlArgs& a, hipStream_t s);
 
