@@ -81,3 +81,32 @@ def test_random_problem(gpu_lib, oracle, seed):
         assert maxdiff(got[key], want[key]) <= TOL, (key, ctx)
     assert np.array_equal(np.nan_to_num(got["center"], nan=-7), np.nan_to_num(want["center"], nan=-7)), ctx
     assert got["n_zero_density"] == want["n_zero_density"], ctx
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_large_problem(gpu_lib, oracle, seed):
+    """Sizes where the other code paths live: sums above 2^24 (sequential dispersion chains in k_finish), long
+    chains (fast-forward over many binades), several density tiles per class, 1024-site sweep blocks."""
+    from pangenomenem_amd import synth
+    from pangenomenem_amd.engine import solve
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    n = int(rng.integers(18000, 80000))
+    d = int(rng.choice([260, 500, 777, 1024, 1025, 1500, 2300]))
+    k = int(rng.choice([2, 3, 3, 4]))
+    x, _ = synth.grouped_pa_matrix(n, d, 1000 + seed, groups=max(k, 3), p_in=float(rng.uniform(0.7, 0.97)),
+                                   p_out=float(rng.uniform(0.02, 0.3)))
+    nei = synth.contiguity_graph(n, seed, chord_frac=float(rng.uniform(0.0, 0.3)))
+    prop, center, disp = synth.kclass_init(x, k, eps=float(rng.uniform(0.05, 0.4)))
+    cfg = dict(algo=str(rng.choice(["ncem", "ncem", "nem"])), beta=float(rng.choice([0.0, 0.5, 1.0])),
+               disper=str(rng.choice(["sk_", "sk_", "skd", "s__", "s_d"])), propor="pk", it_max=3, tie="hash", seed=seed)
+    want = oracle.run(x, nei, k, prop, center, disp, **cfg)
+    got = solve(x, nei, k, prop, center, disp, **cfg)
+    ctx = (seed, x.shape, k, cfg)
+    assert got["status"] == want["status"] and got["iters"] == want["iters"], ctx
+    assert np.array_equal(got["c"].argmax(1), want["c"].argmax(1)), ctx
+    if cfg["algo"] == "ncem":
+        assert np.array_equal(got["c"], want["c"]), ctx
+    assert maxdiff(got["c"], want["c"]) <= TOL, ctx
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, (key, ctx)
+    assert np.array_equal(got["center"], want["center"]), ctx
