@@ -14,8 +14,9 @@ are real pre-convergence iterations; the restart (reset + the two initial sweeps
 timed region and is NOT counted as steps.
 
 For N > 1 (one process per GPU, torch.distributed / RCCL): families are sharded in contiguous
-blocks, every rank holds configs[1]-sized shard (weak scaling); per iteration one all-reduce of
-the integer M-step statistics and one all-gather of the labels per relaxation round.
+blocks, every rank holds configs[1]-sized shard (weak scaling); per iteration two all-gathers of the
+label blocks (one per relaxation round), the second of which also carries every rank's partial integer
+M-step statistics -- no separate all-reduce (pangenomenem_amd/distributed.py).
 
 Rank 0 prints ONE JSON line.
 """
@@ -197,8 +198,9 @@ def main():
                                n_loc, d, args.algo),
                 "families_total": n_tot, "organisms": d, "K": k, "beta": beta,
                 "cycle_iterations": cycle,
-                "parallelism": "1 GPU" if world == 1 else "families sharded over %d GPUs; all-reduce(int32 stats) "
-                                                           "per iteration + all-gather(labels) per relaxation round" % world,
+                "parallelism": "1 GPU" if world == 1 else "families sharded over %d GPUs; per EM iteration two RCCL "
+                                                           "all-gathers of the label blocks (the second also carries the "
+                                                           "ranks' int32 M-step statistics)" % world,
             },
             "roofline": {
                 "bound": "hbm",
