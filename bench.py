@@ -40,14 +40,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--families", type=int, default=20000, help="families per GPU")
     ap.add_argument("--organisms", type=int, default=500)
     ap.add_argument("--algo", default="ncem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
-    ap.add_argument("--cpu-iters", type=int, default=8, help="reference iterations timed for the CPU baseline")
+    ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
     return ap.parse_args()
 
 
