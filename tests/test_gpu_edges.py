@@ -143,3 +143,22 @@ def test_random_starts_match_oracle(gpu_lib, oracle, n, d, k, algo, disper, star
     rel = np.abs(got["crit"].astype(np.float64) - want["crit"]) / np.maximum(1.0, np.abs(want["crit"]))
     assert np.all((rel <= 1e-5) | ~np.isfinite(want["crit"]))
     eng.close()
+
+
+def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
+    # D > 32768: the class masks of the uniform chain no longer fit its LDS staging, every class takes the general
+    # chain; K = 32 is the engine's maximum
+    n, d = 300, 33000
+    x, _ = synth.bernoulli_pa_matrix(n, d, 99)
+    nei = synth.contiguity_graph(n, 99)
+    prop, center, disp = synth.default_init(d, low_disp=0.45)
+    run_both(oracle, x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, disper="sk_", it_max=2)
+    n, d, k = 4000, 40, 32
+    x, _ = synth.grouped_pa_matrix(n, d, 98, groups=32)
+    nei = synth.contiguity_graph(n, 98)
+    prop, center, disp = synth.kclass_init(x, k)
+    for algo in ("ncem", "nem"):
+        run_both(oracle, x, nei, k, prop, center, disp, algo=algo, beta=0.4, disper="skd", it_max=3)
+    from pangenomenem_amd.engine import NemEngine, NemGpuError
+    with pytest.raises(NemGpuError):
+        NemEngine(100, 10, 33)
