@@ -111,6 +111,8 @@ class GpuStepper:
         self.torch = torch
         self.device = torch.device("cuda", device)
         d = x_local.shape[1]
+        if x_local.shape[0] == 0:
+            raise ValueError("rank %d would own no family (n_total=%d over %d ranks): use fewer ranks" % (rank, n_total, world))
         blk, stride = slot_layout(n_total, world, k + k * d)
         self.rank, self.blk, self.stride = rank, blk, stride
         # one dedicated (non-default) stream carries this rank's kernels AND the collectives torch issues for
