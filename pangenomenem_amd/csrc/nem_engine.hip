@@ -71,7 +71,8 @@ struct nemgpu_engine {
     float *prop = nullptr, *center = nullptr, *disp = nullptr;
     float *prop0 = nullptr, *center0 = nullptr, *disp0 = nullptr;
     float *nbobs_k = nullptr, *iner = nullptr;
-    float *fz_s0 = nullptr, *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
+    int *fz_lastz = nullptr, *fz_any1 = nullptr;
+    float *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
     double2* tabT = nullptr;
     double* tabL0 = nullptr;
     uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
@@ -163,13 +164,14 @@ int ensure_state_buffers(nemgpu_engine* e)
     } else {
         for (int b = 0; b < 3; b++)
             if (!e->cbuf[b]) { int r = dev_alloc(&e->cbuf[b], (size_t)e->n_total * e->k); if (r) return r; }
-        if (!e->fz_s0) {
+        if (!e->fz_in0) {
             size_t kd = (size_t)e->k * e->d;
             int r;
-            if ((r = dev_alloc(&e->fz_s0, kd))) return r;
             if ((r = dev_alloc(&e->fz_in0, kd))) return r;
             if ((r = dev_alloc(&e->fz_in1, kd))) return r;
-            if ((r = dev_alloc(&e->fz_inh, kd))) return r;
+            if ((r = dev_alloc(&e->fz_inh, (size_t)e->k))) return r;
+            if ((r = dev_alloc(&e->fz_lastz, kd))) return r;
+            if ((r = dev_alloc(&e->fz_any1, kd))) return r;
         }
     }
     return NEMGPU_OK;
@@ -353,7 +355,7 @@ int do_mstep(nemgpu_engine* e)
         launch_finish(finish_args(e, 1, e->stats), e->stream);
     } else {
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
-                           e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->center, e->iner, e->stop_ptr, e->stream);
+                           e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream);
         launch_finish(finish_args(e, 2, nullptr), e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -796,7 +798,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     rccl_release(e);
     void* ptrs[] = {e->xw, e->xws, e->perm, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
-                    e->disp0, e->nbobs_k, e->iner, e->fz_s0, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
+                    e->disp0, e->nbobs_k, e->iner, e->fz_lastz, e->fz_any1, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
                     e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->sweep_next, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
                     e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
                     e->crit6_dev, e->crit_lfi, e->crit_lzi};

@@ -1334,102 +1334,222 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Fuzzy NEM M-step: the reference's sums are i-ordered float accumulators, so each (class,
-// organism) chain stays on one lane; the K*D chains run in parallel.  wave = 64 organisms of
-// one class: c_ik is wave-uniform, the bit word is shared by 32 lanes.
-//   pass A: N_K, zeros-side total S0, inertia candidates for mu = 0, 1, 0.5
-//   pass B: ComputeMedian's prefix scan (zeros in index order, then ones) against halfwei
+// Fuzzy NEM M-step.  The reference's sums are i-ordered float accumulators, so every (class, organism) chain
+// stays on one lane and the K*D chains run in parallel; a wave holds 64 organisms of one class.  With so few
+// waves (K*D/64) a wave is alone on its SIMD and the time is (instructions per family) x N, so:
+//   * the N families are walked 64 at a time: one strided vector load brings the 64 memberships c_ik, two more
+//     the 64 bit words of the wave's organisms, the next group's loads fly over this group's chain, and the
+//     inner loop takes everything from registers (v_readlane -> SGPRs: c_ik is wave-uniform, and the two bit
+//     words of a family ARE the wave's 64-bit lane mask "organism has the family");
+//   * every chain gets its own wave (roles along blockIdx.x), each step = 3 v_readlane + an add + a select:
+//       pass A  inertia for mu = 0 (sum of c_ik over the ones) / for mu = 1 (over the zeros) / the class total
+//               N_k / the inertia for mu = 0.5 (the same for every organism) / the two order-free facts
+//               ComputeMedian's tie rule needs (they do not depend on N_k, so they run here, beside the sums)
+//       pass B  ComputeMedian's prefix scan over the zeros against N_k/2 (needs pass A's N_k).
+//   (float)((double)a + (double)b) is the float sum a + b -- a double holds the exact sum of two floats' leading
+//   2*24+2 bits, so the double rounding is innocuous -- which is how the mu = 0 / mu = 1 chains are float adds.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_f32(float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); }
+__device__ __forceinline__ uint64_t lane_mask(uint32_t lo, uint32_t hi, int j)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, j) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32);
+}
+
+// one wave's view of the families: 64 memberships and the 64 lane masks at a time
+struct FuzzyWalk {
+    const float* c; const uint32_t *col_lo, *col_hi; int n, K, k, lane;
+    float cv; uint32_t xl, xh;
+    __device__ __forceinline__ void load(int i0, float& v, uint32_t& l, uint32_t& h) const
+    {
+        const int il = min(i0 + lane, n - 1);
+        v = c[(size_t)il * K + k]; l = col_lo[il]; h = col_hi[il];
+    }
+    // group(cv, xl, xh, cnt): lane j of the three registers holds family i0 + j, cnt of them are valid
+    template <typename G> __device__ __forceinline__ void groups(G&& group)
+    {
+        load(0, cv, xl, xh);
+        int i0 = 0;
+        for (; i0 + 64 <= n; i0 += 64) {
+            float cn; uint32_t ln, hn;
+            load(i0 + 64, cn, ln, hn);
+            group(cv, xl, xh, 64);
+            cv = cn; xl = ln; xh = hn;
+        }
+        if (i0 < n) group(cv, xl, xh, n - i0);
+    }
+    template <typename F> static __device__ __forceinline__ void lanes(int cnt, F&& f)
+    {
+        if (cnt == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) f(j);
+        } else {
+            for (int j = 0; j < cnt; j++) f(j);                          // j is wave-uniform
+        }
+    }
+    template <typename F> __device__ __forceinline__ void run(F&& step)
+    {
+        groups([&](float v, uint32_t l, uint32_t h, int cnt) { lanes(cnt, [&](int j) { step(v, l, h, j); }); });
+    }
+};
+
+__device__ __forceinline__ FuzzyWalk fuzzy_walk(int n, int npad, int K, int D, int k, int bx, const uint32_t* xw, const float* c)
+{
+    FuzzyWalk w;
+    w.c = c; w.n = n; w.K = K; w.k = k; w.lane = threadIdx.x;
+    w.col_lo = xw + (size_t)(min(bx * 64, D - 1) >> 5) * npad;           // organisms 64 bx .. +31 -> lanes 0..31
+    w.col_hi = xw + (size_t)(min(bx * 64 + 32, D - 1) >> 5) * npad;      //           64 bx + 32 .. -> lanes 32..63
+    return w;
+}
+
+// roles along blockIdx.x: [0,DB) in0, [DB,2DB) in1, [2DB,3DB) last zero of weight >= EPSILON,
+// [3DB,4DB) "some one has weight >= EPSILON", 4DB: N_k, 4DB+1: inertia for mu = 0.5
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
                                                       const float* __restrict__ c, float* __restrict__ nbobs_k,
-                                                      float* __restrict__ s0_out, float* __restrict__ in0_out,
-                                                      float* __restrict__ in1_out, float* __restrict__ inh_out,
-                                                      const int* __restrict__ stop)
+                                                      float* __restrict__ in0_out, float* __restrict__ in1_out,
+                                                      float* __restrict__ inh_k, int* __restrict__ lastz_out,
+                                                      int* __restrict__ any1_out, const int* __restrict__ stop)
 {
     if (stop != nullptr && *stop) return;
+    const int DB = (D + 63) >> 6;
+    const int role = blockIdx.x < 4 * DB ? blockIdx.x / DB : 4 + (int)blockIdx.x - 4 * DB;
+    const int bx = role < 4 ? blockIdx.x - role * DB : 0;
     const int k = blockIdx.y;
-    const int d = blockIdx.x * 64 + threadIdx.x;
-    const int dw = min(d, D - 1) >> 5, db = d & 31;
-    const uint32_t* col = xw + (size_t)dw * npad;
-    float nk = 0.0f, s0 = 0.0f, in0 = 0.0f, in1 = 0.0f, inh = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < n; i++) {
-        const float ci = c[(size_t)i * K + k];
-        const bool one = (col[i] >> db) & 1u;
-        nk += ci;                                                        // nem_mod.c:1308
-        if (!one) s0 += ci;                                              // nem_mod.c:1456 (zeros first)
-        const double cd = (double)ci;
-        if (one) in0 = (float)((double)in0 + cd * 1.0);                  // nem_mod.c:1683, mu = 0
-        else in1 = (float)((double)in1 + cd * 1.0);                      //                 mu = 1
-        inh = (float)((double)inh + cd * 0.5);                           //                 mu = 0.5
+    const int d = bx * 64 + threadIdx.x;
+    FuzzyWalk w = fuzzy_walk(n, npad, K, D, k, bx, xw, c);
+    if (role == 4) {
+        float nk = 0.0f;
+        w.run([&](float cv, uint32_t, uint32_t, int j) { nk += lane_f32(cv, j); });          // nem_mod.c:1308
+        if (threadIdx.x == 0) nbobs_k[k] = nk;
+        return;
     }
-    if (d < D) {
-        const int t = k * D + d;
-        s0_out[t] = s0; in0_out[t] = in0; in1_out[t] = in1; inh_out[t] = inh;
-        if (d == 0) nbobs_k[k] = nk;
+    if (role == 5) {
+        // nem_mod.c:1683 with |x - 0.5| = 0.5: inh = (float)((double)inh + (double)c * 0.5).  When c/2 is a float
+        // (always, but for an odd subnormal) that is the float sum inh + c/2; groups holding such a c take the
+        // double form.
+        float inh = 0.0f;
+        w.groups([&](float cv, uint32_t, uint32_t, int cnt) {
+            const float hv = cv * 0.5f;
+            if (__ballot(hv * 2.0f != cv) == 0) FuzzyWalk::lanes(cnt, [&](int j) { inh += lane_f32(hv, j); });
+            else FuzzyWalk::lanes(cnt, [&](int j) { inh = (float)((double)inh + (double)lane_f32(cv, j) * 0.5); });
+        });
+        if (threadIdx.x == 0) inh_k[k] = inh;
+        return;
     }
+    if (role == 2) {
+        // what ComputeMedian's tie rule looks for after the crossing (nem_mod.c:1470-1483): the index of the last
+        // zero whose weight is >= EPSILON (pass B compares it with where its chain crossed)
+        int last = -1, i0 = 0;
+        w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
+            const bool big = !((double)cv < kEpsilonD);                  // lane j = family i0 + j here
+            const uint32_t zl = big ? ~xl : 0u, zh = big ? ~xh : 0u;
+            int lj = -1;
+            FuzzyWalk::lanes(cnt, [&](int j) { lj = __builtin_amdgcn_inverse_ballot_w64(lane_mask(zl, zh, j)) ? j : lj; });
+            last = lj >= 0 ? i0 + lj : last;
+            i0 += 64;
+        });
+        if (d < D) lastz_out[k * D + d] = last;
+        return;
+    }
+    if (role == 3) {
+        uint64_t any1 = 0;
+        w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
+            const bool big = !((double)cv < kEpsilonD);
+            const uint32_t ol = big ? xl : 0u, oh = big ? xh : 0u;
+            FuzzyWalk::lanes(cnt, [&](int j) { any1 |= lane_mask(ol, oh, j); });
+        });
+        if (d < D) any1_out[k * D + d] = __builtin_amdgcn_inverse_ballot_w64(any1) ? 1 : 0;
+        return;
+    }
+    const uint32_t flip = role == 1 ? ~0u : 0u;                          // role 1 sums over the zeros
+    float acc = 0.0f;
+    w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
+        const uint32_t ml = xl ^ flip, mh = xh ^ flip;
+        FuzzyWalk::lanes(cnt, [&](int j) {
+            const float nx = acc + lane_f32(cv, j);                      // nem_mod.c:1683 with |x - mu| = 1
+            acc = __builtin_amdgcn_inverse_ballot_w64(lane_mask(ml, mh, j)) ? nx : acc;
+        });
+    });
+    if (d < D) (role == 0 ? in0_out : in1_out)[k * D + d] = acc;
 }
 
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
                                                       const float* __restrict__ c, const float* __restrict__ nbobs_k,
-                                                      const float* __restrict__ s0_in, const float* __restrict__ in0,
-                                                      const float* __restrict__ in1, const float* __restrict__ inh,
-                                                      float* __restrict__ center, float* __restrict__ iner,
-                                                      const int* __restrict__ stop)
+                                                      const float* __restrict__ in0, const float* __restrict__ in1,
+                                                      const float* __restrict__ inh_k, const int* __restrict__ lastz,
+                                                      const int* __restrict__ any1, float* __restrict__ center,
+                                                      float* __restrict__ iner, const int* __restrict__ stop)
 {
     if (stop != nullptr && *stop) return;
     const int k = blockIdx.y;
     const int d = blockIdx.x * 64 + threadIdx.x;
-    const int dc = min(d, D - 1);
-    const int dw = dc >> 5, db = dc & 31;
-    const uint32_t* col = xw + (size_t)dw * npad;
+    const int t = k * D + min(d, D - 1);
+    FuzzyWalk w = fuzzy_walk(n, npad, K, D, k, blockIdx.x, xw, c);
     const float nk = nbobs_k[k];
-    const int t = k * D + dc;
     if (!((double)nk > kEpsilonD)) {
         // "empty" class (nem_mod.c:1404-1408): the centre is kept, and EstimLaplaceIner (:1669-1686) still runs
         // against that old centre -- the class may hold weights between 0 and EPSILON, which InerToDisp* then
         // turns into a dispersion (they test N_K > 0, not > EPSILON)
         const float mu = center[t];
+        const double a1 = fabs((double)(1.0f - mu)), a0 = fabs((double)(0.0f - mu));
         float in = 0.0f;
-        for (int i = 0; i < n; i++) {
-            const float ci = c[(size_t)i * K + k];
-            const float xij = ((col[i] >> db) & 1u) ? 1.0f : 0.0f;
-            in = (float)((double)in + (double)ci * fabs((double)(xij - mu)));     // :1683
-        }
+        w.run([&](float cv, uint32_t xl, uint32_t xh, int j) {
+            const float ci = lane_f32(cv, j);
+            const bool one = __builtin_amdgcn_inverse_ballot_w64(lane_mask(xl, xh, j));
+            in = (float)((double)in + (double)ci * (one ? a1 : a0));     // :1683
+        });
         if (d < D) iner[t] = in;
         return;
     }
+    // Only the zeros' chain decides (nem_mod.c:1439-1497): once the cumulated weight of the zeros reaches N_k/2
+    // the median sits among them, otherwise it is a one (or midway between two ones) whatever the ones' chain
+    // does.  crossed = lane mask "the chain has reached N_k/2" (it is frozen from there on).
     const float half = nk / 2;                           // nem_mod.c:1439
     const double half_eps = (double)half + kEpsilonD;    // nem_mod.c:1464
-    float cum0 = 0.0f, cum1 = s0_in[t];
-    // phase: 0 scanning, 1 crossed with equality (looking for next c >= EPSILON), 2 resolved
-    int ph0 = 0, ph1 = 0, next0 = 0, next1 = 0, gt0 = 0, gt1 = 0, any1 = 0;
-#pragma unroll 4
-    for (int i = 0; i < n; i++) {
-        const float ci = c[(size_t)i * K + k];
-        const bool one = (col[i] >> db) & 1u;
-        const bool big = !((double)ci < kEpsilonD);
-        if (!one) {
-            if (ph0 == 0) { cum0 += ci; if (!(cum0 < half)) { ph0 = 1; gt0 = ((double)cum0 > half_eps); } }
-            else if (big) next0 = 1;
-        } else {
-            any1 |= big;
-            if (ph1 == 0) { cum1 += ci; if (!(cum1 < half)) { ph1 = 1; gt1 = ((double)cum1 > half_eps); } }
-            else if (big) next1 = 1;
+    // The weights are >= 0, so a chain that has reached N_k/2 stays there: the walk runs the bare chain (add, select
+    // on the family's lane mask) over 64 families, tests the crossing once per group, and only a group in which
+    // some lane crossed is walked again, from the saved start, to find that lane's family and value.
+    float run = 0.0f, cum = 0.0f;
+    int istar = n, i0 = 0;                               // family at which the chain crossed
+    uint64_t crossed = 0;
+    w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
+        const float start = run;
+        FuzzyWalk::lanes(cnt, [&](int j) {
+            const float nx = run + lane_f32(cv, j);
+            run = __builtin_amdgcn_inverse_ballot_w64(lane_mask(xl, xh, j)) ? run : nx;
+        });
+        const uint64_t newly = __ballot(!(run < half)) & ~crossed;
+        if (newly != 0) {
+            float r2 = start;
+            int cj = -1;
+            uint64_t seen = ~newly;
+            FuzzyWalk::lanes(cnt, [&](int j) {
+                const uint64_t one = lane_mask(xl, xh, j);
+                const float nx = r2 + lane_f32(cv, j);
+                const uint64_t now = __ballot(!(nx < half)) & ~one & ~seen;
+                r2 = __builtin_amdgcn_inverse_ballot_w64(one) ? r2 : nx;
+                cum = __builtin_amdgcn_inverse_ballot_w64(now) ? nx : cum;
+                cj = __builtin_amdgcn_inverse_ballot_w64(now) ? j : cj;
+                seen |= now;
+            });
+            istar = cj >= 0 ? i0 + cj : istar;
+            crossed |= newly;
         }
-    }
+        i0 += 64;
+    });
+    const bool ph0 = __builtin_amdgcn_inverse_ballot_w64(crossed);
+    const bool gt0 = (double)cum > half_eps;             // cum is the value at the crossing
     float mu;
     if (ph0) {                                           // median position among the zeros
+        const bool next0 = lastz[t] > istar;             // a zero of weight >= EPSILON follows the crossing
         if (gt0 || next0) mu = 0.0f;                     // x_med = 0 (or midway to another 0)
-        else if (any1) mu = 0.5f;                        // midway to the first one with weight
+        else if (any1[t]) mu = 0.5f;                     // midway to the first one with weight
         else mu = 0.0f;                                  // reference runs off the array here (UB)
     } else {
-        (void)ph1; (void)gt1; (void)next1;
         mu = 1.0f;                                       // x_med = 1 (or midway to another 1)
     }
     if (d < D) {
         center[t] = mu;
-        iner[t] = (mu == 0.0f) ? in0[t] : (mu == 1.0f ? in1[t] : inh[t]);
+        iner[t] = (mu == 0.0f) ? in0[t] : (mu == 1.0f ? in1[t] : inh_k[k]);
     }
 }
 
@@ -1613,13 +1733,15 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
     else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
 }
 
-void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k, float* s0,
-                        float* in0, float* in1, float* inh, float* center, float* iner, const int* stop, hipStream_t s)
+void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k,
+                        float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center, float* iner,
+                        const int* stop, hipStream_t s)
 {
-    dim3 grid((D + 63) / 64, K), block(64);
-    hipLaunchKernelGGL(k_mstep_fuzzy_a, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh, stop);
-    hipLaunchKernelGGL(k_mstep_fuzzy_b, grid, block, 0, s, n, npad, K, D, xw, c, nbobs_k, s0, in0, in1, inh, center,
-                       iner, stop);
+    const int DB = (D + 63) / 64;
+    hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, n, npad, K, D, xw, c, nbobs_k, in0, in1, inh_k,
+                       lastz, any1, stop);
+    hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, n, npad, K, D, xw, c, nbobs_k, in0, in1, inh_k, lastz,
+                       any1, center, iner, stop);
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
