@@ -203,7 +203,7 @@ __device__ __forceinline__ float bern_step(float dk, uint32_t m, int b, double l
     return (float)(fma(f, l1h, (double)dk) - l0);
 }
 
-// The uniform chain of one (family, class) lane.  am0 / am1: mismatch masks of the class per 32-organism word.
+// The uniform chain of one (family, class) lane.  am[w] = {am0, am1}: mismatch masks of the class per 32-organism word.
 __device__ __forceinline__ uint32_t word_of(const uint4& v, int c)
 {
     return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
@@ -211,8 +211,16 @@ __device__ __forceinline__ uint32_t word_of(const uint4& v, int c)
 
 // xw4: E1's matrix copy, uint4[W4][npad]: lane i reads words 4g .. 4g+3 of its family with one 16-byte load
 // (1 KB per wave and request), two groups ahead of the one being consumed.
+// (x & am1) | (~x & am0) is one bit-field insert
+__device__ __forceinline__ uint32_t mismatch_word(uint32_t x, const uint2 am)
+{
+    uint32_t m;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(am.y), "v"(am.x));
+    return m;
+}
+
 __device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int npad, int i, int D,
-                                    const uint32_t* am0, const uint32_t* am1, double l1h, double l0)
+                                    const uint2* am, double l1h, double l0)
 {
     float dk = 0.0f;
     const int wlast = (D - 1) >> 5;                      // padding organisms must not take a step here
@@ -225,8 +233,7 @@ __device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int 
         for (int c = 0; c < 4; c++) {
             const int w = 4 * g + c;
             if (w > wlast) break;
-            const uint32_t x = word_of(xv, c);
-            const uint32_t m = (x & am1[w]) | (~x & am0[w]);
+            const uint32_t m = mismatch_word(word_of(xv, c), am[w]);
             const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
             if (nb == 32) {
 #pragma unroll
@@ -256,55 +263,85 @@ __device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sDQ
     end = (E + 1u) << 23;
 }
 
-// pattern after n organisms of which p mismatch: bits + n*q0 + p*(q1 - q0)  (two multiply-adds; the sum stays
-// below 2^32: pattern < 2^31, n <= 32 increments of at most 2^23)
-__device__ __forceinline__ uint32_t ff_advance(uint32_t bits, uint32_t n, uint32_t p, uint32_t q0, uint32_t dq)
+// The integer side of the fast-forward is written as instructions: left to itself the compiler loses the 24-bit
+// range of the increments (they travel through loop-carried registers) and emits v_mul_lo_u32 / v_mad_u64_u32 --
+// quarter-rate multiplies -- where ONE full-rate v_mad_u32_u24 does.
+// a * b + c on the low 24 bits of a and b
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
 {
-    return bits + __umul24(n, q0) + __umul24(p, dq);
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// popc(m) * dq + base
+__device__ __forceinline__ uint32_t ff_cand(uint32_t m, uint32_t dq, uint32_t base)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0\n\tv_mad_u32_u24 %0, %0, %2, %3" : "=&v"(r) : "v"(m), "v"(dq), "v"(base));
+    return r;
+}
+// popc(low t bits of m) * dq + base
+__device__ __forceinline__ uint32_t ff_probe(uint32_t m, uint32_t t, uint32_t dq, uint32_t base)
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, 0, %2\n\tv_bcnt_u32_b32 %0, %0, 0\n\tv_mad_u32_u24 %0, %0, %3, %4"
+        : "=&v"(r) : "v"(m), "v"(t), "v"(dq), "v"(base));
+    return r;
+}
+
+// the boundary organism (bit j of mm, j not a compile-time constant) with the reference's own arithmetic
+__device__ __forceinline__ uint32_t ff_exact_step(uint32_t bits, uint32_t mm, uint32_t j, double l1h, double l0)
+{
+    const uint32_t hi = ((mm >> j) & 1u) << 30;          // 2.0 if the organism mismatches, else 0.0 (see bern_step)
+    const double f = __hiloint2double((int)hi, 0);
+    return __float_as_uint((float)(fma(f, l1h, (double)__uint_as_float(bits)) - l0));
 }
 
 // one word (nb organisms, mismatch bits m) of the fast-forwarded chain
 __device__ __forceinline__ void ff_word(uint32_t& bits, uint32_t& q0, uint32_t& dq, uint32_t& end, uint32_t m, int nb,
                                         const uint32_t* sQ0, const uint32_t* sDQ, double l1h, double l0)
 {
-    const uint32_t cand = ff_advance(bits, (uint32_t)nb, (uint32_t)__popc(m), q0, dq);
-    const bool ok = cand < end;
-    if (ok) bits = cand;
-    if (__all(ok)) return;
-    if (!ok) {
+    // pattern after the nb organisms of which popc(m) mismatch: bits + nb*q0 + popc(m)*(q1 - q0)  (stays below
+    // 2^32: pattern < 2^31, at most 32 increments of at most 2^23)
+    const uint32_t cand = ff_cand(m, dq, (nb == 32) ? bits + (q0 << 5) : mad24((uint32_t)nb, q0, bits));
+    const bool cross = cand >= end;
+    bits = cross ? bits : cand;
+    if (cross) {                                         // (a wave none of whose lanes cross skips this)
         uint32_t mm = m;
         int rem = nb;
         for (;;) {
-            int j = 0;                                   // organisms of this word that still fit in the binade
+            // organisms of this word that still fit in the binade: binary search over j, the pattern after the j
+            // matching ones (at = bits + j * q0) carried along, so that a probe costs a shift-add and ONE multiply
+            uint32_t j = 0, at = bits;
 #pragma unroll
-            for (int st = 16; st >= 1; st >>= 1) {
-                const int t = j + st;
-                const uint32_t f = ff_advance(bits, (uint32_t)t, (uint32_t)__popc(mm & ((1u << t) - 1u)), q0, dq);
-                if (f < end) j = t;                      // (f(t) >= f(rem) >= end for t >= rem: never accepted)
+            for (int sh = 4; sh >= 0; sh--) {
+                const uint32_t t = j + (1u << sh);
+                const uint32_t at_t = at + (q0 << sh);
+                const bool fits = ff_probe(mm, t, dq, at_t) < end;   // (f(t) >= f(rem) >= end for t >= rem: never accepted)
+                j = fits ? t : j;
+                at = fits ? at_t : at;
             }
-            bits = ff_advance(bits, (uint32_t)j, (uint32_t)__popc(mm & ((1u << j) - 1u)), q0, dq);
-            bits = __float_as_uint(bern_step(__uint_as_float(bits), mm, j, l1h, l0));
-            rem -= j + 1;
+            bits = ff_probe(mm, j, dq, at);
+            bits = ff_exact_step(bits, mm, j, l1h, l0);
+            ff_load(sQ0, sDQ, bits, q0, dq, end);        // the increments of the binade the step landed in
+            rem -= (int)j + 1;
             if (rem <= 0) break;
-            mm = mm >> (j + 1);                          // j + 1 <= 31 here
-            ff_load(sQ0, sDQ, bits, q0, dq, end);
-            const uint32_t c2 = ff_advance(bits, (uint32_t)rem, (uint32_t)__popc(mm), q0, dq);
-            if (c2 < end) { bits = c2; break; }
+            mm = mm >> (j + 1u);                         // j + 1 <= 31 here
+            const uint32_t c2 = ff_cand(mm, dq, mad24((uint32_t)rem, q0, bits));
+            if (c2 < end) { bits = c2; break; }          // (stays inside the binade just loaded)
         }
-        ff_load(sQ0, sDQ, bits, q0, dq, end);
     }
 }
 
 // four full words (128 organisms) of the fast-forwarded chain
-__device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint32_t* am0, const uint32_t* am1, uint32_t& bits,
+__device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint2* am, uint32_t& bits,
                                          uint32_t& q0, uint32_t& q1, uint32_t& end, const uint32_t* sQ0,
                                          const uint32_t* sQ1, double l1h, double l0)   // (q1 / sQ1 carry q1 - q0)
 {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int w = 4 * g + c;
-        const uint32_t x = word_of(xv, c);
-        const uint32_t m = (x & am1[w]) | (~x & am0[w]);
+        const uint32_t m = mismatch_word(word_of(xv, c), am[w]);
         if (c < kFFPlainWords && g == 0) {
             // the first organisms run through small binades (a crossing every few steps): stepping is cheaper
             float dk0 = __uint_as_float(bits);
@@ -319,7 +356,7 @@ __device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint32_t*
 }
 
 __device__ __forceinline__ float chain_ff(const uint4* __restrict__ xw4, int npad, int i, int D,
-                                          const uint32_t* am0, const uint32_t* am1, const uint32_t* sQ0,
+                                          const uint2* am, const uint32_t* sQ0,
                                           const uint32_t* sQ1, double l1h, double l0)
 {
     const int wlast = (D - 1) >> 5;
@@ -328,36 +365,39 @@ __device__ __forceinline__ float chain_ff(const uint4* __restrict__ xw4, int npa
     uint32_t q0, q1, end;
     ff_load(sQ0, sQ1, bits, q0, q1, end);
     // four register buffers, refilled right after use: three loads stay in flight while a group is consumed.
-    // Every load is issued unconditionally (indices clamped to the last group, which always exists) so that the
-    // compiler can count outstanding loads exactly and wait for the oldest one only.
-    const uint4* p = xw4 + i;
-    uint4 x0 = p[(size_t)min(0, gfull) * npad];
-    uint4 x1 = p[(size_t)min(1, gfull) * npad];
-    uint4 x2 = p[(size_t)min(2, gfull) * npad];
-    uint4 x3 = p[(size_t)min(3, gfull) * npad];
+    // Every load is issued unconditionally (past the last group it simply repeats the last one) so that the
+    // compiler can count outstanding loads exactly and wait for the oldest one only.  The groups are read in
+    // order through ONE running pointer (a 64-bit add per load; indexing would cost three quarter-rate multiplies).
+    const uint4* pn = xw4 + i;
+    int gi = 0;                                          // group *pn points at (wave-uniform)
+    auto next = [&]() {
+        const uint4 v = *pn;
+        if (gi < gfull) { pn += npad; gi++; }
+        return v;
+    };
+    uint4 x0 = next(), x1 = next(), x2 = next(), x3 = next();
     int g = 0;
     for (; g + 4 <= gfull; g += 4) {
-        ff_group(x0, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
-        x0 = p[(size_t)min(g + 4, gfull) * npad];
-        ff_group(x1, g + 1, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
-        x1 = p[(size_t)min(g + 5, gfull) * npad];
-        ff_group(x2, g + 2, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
-        x2 = p[(size_t)min(g + 6, gfull) * npad];
-        ff_group(x3, g + 3, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
-        x3 = p[(size_t)min(g + 7, gfull) * npad];
+        ff_group(x0, g, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x0 = next();
+        ff_group(x1, g + 1, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x1 = next();
+        ff_group(x2, g + 2, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x2 = next();
+        ff_group(x3, g + 3, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0);
+        x3 = next();
     }
     // 0..3 full groups left, then the last group (1..4 words, the last one possibly partial): after the loop
     // x0, x1, x2, x3 hold groups g, g+1, g+2, g+3 (clamped to gfull)
     uint4 xt = x0;
-    if (g < gfull) { ff_group(x0, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x1; g++; }
-    if (g < gfull) { ff_group(x1, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x2; g++; }
-    if (g < gfull) { ff_group(x2, g, am0, am1, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x3; g++; }
+    if (g < gfull) { ff_group(x0, g, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x1; g++; }
+    if (g < gfull) { ff_group(x1, g, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x2; g++; }
+    if (g < gfull) { ff_group(x2, g, am, bits, q0, q1, end, sQ0, sQ1, l1h, l0); xt = x3; g++; }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int w = 4 * gfull + c;
         if (w > wlast) break;
-        const uint32_t x = word_of(xt, c);
-        uint32_t m = (x & am1[w]) | (~x & am0[w]);
+        uint32_t m = mismatch_word(word_of(xt, c), am[w]);
         const int nb = (w < wlast) ? 32 : (D - (wlast << 5));
         if (nb < 32) m &= (1u << nb) - 1u;
         ff_word(bits, q0, q1, end, m, nb, sQ0, sQ1, l1h, l0);
@@ -415,7 +455,7 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
     __shared__ uint32_t sQ0[256], sQ1[256];
-    __shared__ uint32_t sAm0[kDensMaskWords], sAm1[kDensMaskWords];
+    __shared__ uint2 sAm[kDensMaskWords];                // {am0, am1} of a word together: one 8-byte LDS read
     if (a.stop != nullptr && *a.stop) return;
     int k, tile;
     if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
@@ -437,14 +477,14 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a)
         // the class's mismatch masks go through LDS: read from global inside the chain they would share the
         // vector-memory counter with the matrix prefetch and drain it at every word
         // (W <= kDensMaskWords here: table_flag_general sends wider matrices down the general path)
-        for (int w = tid; w < W; w += 256) { sAm0[w] = a.am0[k * W + w]; sAm1[w] = a.am1[k * W + w]; }
+        for (int w = tid; w < W; w += 256) sAm[w] = make_uint2(a.am0[k * W + w], a.am1[k * W + w]);
         if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
             ff_build(sQ0, sQ1, l1, l0, tid);
             __syncthreads();
-            dk = chain_ff(a.xw, npad, i, a.D, sAm0, sAm1, sQ0, sQ1, l1h, l0);
+            dk = chain_ff(a.xw, npad, i, a.D, sAm, sQ0, sQ1, l1h, l0);
         } else {
             __syncthreads();
-            dk = chain_plain(a.xw, npad, i, a.D, sAm0, sAm1, l1h, l0);
+            dk = chain_plain(a.xw, npad, i, a.D, sAm, l1h, l0);
         }
     } else {
         // ---- general case (skd, s_d, hand-written .m files): per-(k,d) constants staged through LDS
@@ -510,7 +550,8 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     __shared__ float sVal[FD_MAXD];                      // inertia per organism, later epsilon per organism
     __shared__ double2 sT[FD_CH];
     __shared__ double sL[FD_CH];
-    __shared__ uint32_t sAm0[FD_MAXD / 32], sAm1[FD_MAXD / 32], sNz0[FD_CH / 32], sNz1[FD_CH / 32];
+    __shared__ uint2 sAm[FD_MAXD / 32];                   // {am0, am1} per word
+    __shared__ uint32_t sNz0[FD_CH / 32], sNz1[FD_CH / 32];
     __shared__ uint32_t sQ0[256], sQ1[256];
     __shared__ unsigned long long sTot2;
     __shared__ float sEps;
@@ -564,8 +605,8 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         const uint64_t b0 = __ballot(a0), b1 = __ballot(a1);
         if (lane == 0) {
             const int w = d >> 5;
-            sAm0[w] = (uint32_t)b0; sAm0[w + 1] = (uint32_t)(b0 >> 32);
-            sAm1[w] = (uint32_t)b1; sAm1[w + 1] = (uint32_t)(b1 >> 32);
+            sAm[w] = make_uint2((uint32_t)b0, (uint32_t)b1);
+            sAm[w + 1] = make_uint2((uint32_t)(b0 >> 32), (uint32_t)(b1 >> 32));
         }
     }
     acc2 = wave_reduce_add_ll(acc2);
@@ -630,9 +671,9 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
         if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
             ff_build(sQ0, sQ1, l1, l0, tid);
             __syncthreads();
-            dk = chain_ff(a.xw, npad, i, D, sAm0, sAm1, sQ0, sQ1, l1h, l0);
+            dk = chain_ff(a.xw, npad, i, D, sAm, sQ0, sQ1, l1h, l0);
         } else {
-            dk = chain_plain(a.xw, npad, i, D, sAm0, sAm1, l1h, l0);
+            dk = chain_plain(a.xw, npad, i, D, sAm, l1h, l0);
         }
     } else {
         // general chain: per-organism constants built chunk by chunk in LDS (table_entry's arithmetic)
@@ -646,7 +687,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
                 if (d < D) {
                     const float eps = eps_per_d ? sVal[d] : eps_u;
                     int ad0, ad1;
-                    if (nonempty) { ad0 = (sAm0[d >> 5] >> (d & 31)) & 1; ad1 = (sAm1[d >> 5] >> (d & 31)) & 1; }
+                    if (nonempty) { ad0 = (sAm[d >> 5].x >> (d & 31)) & 1; ad1 = (sAm[d >> 5].y >> (d & 31)) & 1; }
                     else { const float mu = a.center[k * D + d]; ad0 = abs((int)(0.0f - mu)); ad1 = abs((int)(1.0f - mu)); }
                     if ((double)eps > kEpsilonD) {
                         const double ll1 = log((double)((1.0f - eps) / eps));
