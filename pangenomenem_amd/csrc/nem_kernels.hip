@@ -251,7 +251,7 @@ __device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int 
 // word finds the last organism that still fits (5-step binary search over prefix popcounts), takes the
 // boundary step with the reference's own arithmetic, reloads the increments of the new binade and goes on.
 // sQ0 / sQ1: the class's 256-entry increment tables (LDS).  Bit-identical to chain_plain.
-constexpr int kFFPlainWords = 2;
+constexpr int kFFPlainWords = 1;
 
 // sQ0[E] = q0, sDQ[E] = q1 - q0 (both at most 2^23: 24-bit multiplies), see ff_build
 __device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sDQ, uint32_t bits, uint32_t& q0, uint32_t& dq,
