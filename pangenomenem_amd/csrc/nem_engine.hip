@@ -257,6 +257,7 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         if (ncem) { c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[gb]; c.a.lab_out = e->lab[ob]; }
         else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
         c.a.flags = e->round_flags(c.slot_base + r);
+        c.a.fold_ticket = e->sweep_next + 32;
         c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(c.slot_base + r - 1) + FLAG_CHANGED);
         c.a.stop = e->stop_ptr;
         c.a.post_on = 0;
@@ -1167,6 +1168,7 @@ void shard_sweep_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id)
     a.sweep_id_ptr = sweep_id >= 0 ? nullptr : e->sweep_next;     // -1: the device keeps count (pipelined loop)
     a.stop = e->stop_ptr;
     a.n_ranks = e->sh_world; a.slot_stride = e->sh_stride; a.slot_pad = e->sh_stride - e->sh_blk;
+    a.fold_ticket = e->sweep_next + 32;
 }
 uint8_t* own_flag_byte(nemgpu_engine* e, uint8_t* labels) { return labels + (size_t)e->sh_rank * e->sh_stride + e->sh_blk; }
 }  // namespace

@@ -774,6 +774,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
         c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one
         if (fi[FLAG_NZERO] > 0) { c[C_NZERO] += fi[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = fi[FLAG_FIRSTZERO]; }
+        c[C_FOLD] = fi[FLAG_NZERO] > 0;                           // how the next sweeps tally such sites, see k_sweep
         return;
     }
     const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -794,6 +795,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         c[C_NZERO] += f[FLAG_NZERO];
         if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
     }
+    c[C_FOLD] = f[FLAG_NZERO] > 0;
     c[C_COMMITS] += 1;
     if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
         const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
@@ -806,11 +808,14 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
 // Two levels (groups of blocks, then the groups) once the grid is larger than 32 blocks: same-address atomics
 // are served one after the other (~45 ns each on MI355X), so a flat counter costs 9 us at 200 blocks; with at most
 // 32 groups on counters 128 bytes apart it is ~sqrt of that.  `ticket` points at kTicketWords zeroed ints.
-__device__ inline bool last_block_ticket(int* ticket, int nblocks)
+// The counters are 64-bit: arrivals in the low word, and in the high word an optional grid-wide sum (`tally`, this
+// block's share; the last block stores the total to *tally_out) that rides on the same atomics -- a sum that would
+// otherwise cost one same-address atomic per block.
+__device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0, int* tally_out = nullptr)
 {
     __shared__ int s_last;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && tally_out == nullptr) {                // plain ticket: 32-bit counters
         __threadfence();
         int last = 0;
         if (nblocks <= 32) {
@@ -818,7 +823,7 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks)
             last = (t == nblocks - 1);
             if (last) *ticket = 0;
         } else {
-            const int gsz = (nblocks + 31) / 32;                   // blocks per group; at most 32 groups
+            const int gsz = (nblocks + 31) / 32;
             const int g = blockIdx.x / gsz;
             const int ng = (nblocks + gsz - 1) / gsz;
             const int members = min(gsz, nblocks - g * gsz);
@@ -830,6 +835,38 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks)
             }
         }
         if (last) __threadfence();
+        s_last = last;
+    } else if (threadIdx.x == 0) {
+        __threadfence();
+        using u64 = unsigned long long;
+        const u64 mine = 1ull | ((u64)(unsigned)tally << 32);
+        int last = 0;
+        u64 total = 0;
+        if (nblocks <= 32) {
+            u64* tc = reinterpret_cast<u64*>(ticket);
+            const u64 t = atomicAdd(tc, mine);
+            last = ((int)(t & 0xffffffffull) == nblocks - 1);
+            if (last) { *tc = 0; total = (t >> 32) + (u64)(unsigned)tally; }
+        } else {
+            const int gsz = (nblocks + 31) / 32;                   // blocks per group; at most 32 groups
+            const int g = blockIdx.x / gsz;
+            const int ng = (nblocks + gsz - 1) / gsz;
+            const int members = min(gsz, nblocks - g * gsz);
+            u64* gc = reinterpret_cast<u64*>(ticket + 32 * (1 + g));
+            const u64 t = atomicAdd(gc, mine);
+            if ((int)(t & 0xffffffffull) == members - 1) {
+                *gc = 0;
+                const u64 gsum = (t >> 32) + (u64)(unsigned)tally;
+                __threadfence();
+                u64* tc = reinterpret_cast<u64*>(ticket);
+                const u64 tt = atomicAdd(tc, 1ull | (gsum << 32));
+                if ((int)(tt & 0xffffffffull) == ng - 1) { *tc = 0; last = 1; total = (tt >> 32) + gsum; }
+            }
+        }
+        if (last) {
+            if (tally_out != nullptr) *tally_out = (int)total;
+            __threadfence();
+        }
         s_last = last;
     }
     __syncthreads();
@@ -849,7 +886,13 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks)
 template <int KT, bool NCEM, int BS>
 __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
 {
-    if (a.stop != nullptr && *a.stop) return;
+    int fold_hint = 0;
+    if (a.stop != nullptr) {
+        static_assert(C_STOP == 0 && C_FOLD == 1, "one 8-byte load");
+        const int2 sf = *reinterpret_cast<const int2*>(a.stop);
+        if (sf.x) return;
+        fold_hint = sf.y;
+    }
     bool skip = (a.prev_changed != nullptr && *a.prev_changed == 0);   // the previous round was already the fixed point
     if (a.flags_in != nullptr) {                         // sharded: did ANY rank change a label last round?
         int any = 0;
@@ -986,8 +1029,13 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         atomicMax(&s_first, a.n_total - (gi + (int)__ffsll((long long)zmask) - 1));   // lanes are consecutive sites
     }
     __syncthreads();
+    // One same-address atomic per block is what a round costs when every site reports (all densities underflow at
+    // D = 5000: 196 blocks x ~45 ns, 12 of a round's 26 us at 200 000 x 5 000).  Once the loop control has seen
+    // such a sweep (ctrl[C_FOLD], set by ctrl_logic, read with the stop word) the tally rides on the last-block
+    // counters instead.
+    const bool fold = fold_hint != 0 && a.fold_ticket != nullptr && gridDim.x > 32;
     if (threadIdx.x == 0 && s_nzero > 0) {
-        atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
+        if (!fold) atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
         if (a.flags[FLAG_FIRSTZERO] < s_first) atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);   // first site = n_total - max
     }
     if (NCEM && a.post_on) {                             // k_labels_post's work, see SweepArgs
@@ -1006,9 +1054,9 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         if (__any(moved) && (threadIdx.x & 63) == 0 && a.post_flags[FLAG_MOVED] == 0) atomicOr(&a.post_flags[FLAG_MOVED], 1);
     }
     const bool post_ctrl = NCEM && a.post_on && a.post_ctrl.ctrl != nullptr;
-    if (a.publish_byte != nullptr || post_ctrl) {
-        int* ticket = a.publish_byte != nullptr ? a.publish_ticket : a.post_ctrl.ticket;
-        if (last_block_ticket(ticket, gridDim.x)) {
+    if (a.publish_byte != nullptr || post_ctrl || fold) {
+        int* ticket = a.publish_byte != nullptr ? a.publish_ticket : (post_ctrl ? a.post_ctrl.ticket : a.fold_ticket);
+        if (last_block_ticket(ticket, gridDim.x, fold ? s_nzero : 0, fold ? &a.flags[FLAG_NZERO] : nullptr)) {
             if (a.publish_byte != nullptr)
                 *a.publish_byte = (uint8_t)(__hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
             if (post_ctrl) ctrl_logic(a.post_ctrl);
@@ -1351,7 +1399,7 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
         for (int t = kb * a.D + tid; t < ke * a.D; t += 1024) { a.center[t] = a.reset_center[t]; a.disp[t] = a.reset_disp[t]; }
         if (tid >= kb && tid < ke) { a.prop[tid] = a.reset_prop[tid]; a.nbobs_k[tid] = 0.0f; }
         if (blockIdx.x == 0) {
-            if (tid < a.reset_ctrl_words) a.reset_ctrl[tid] = 0;
+            if (tid < a.reset_ctrl_words && tid != C_FOLD) a.reset_ctrl[tid] = 0;
             if (tid == 0) a.reset_sweep_next[0] = 0;
         }
         __syncthreads();

@@ -19,7 +19,9 @@ enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_ROUND_STRIDE =
 enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 4 };
 
 // device-side loop control block (ints), see k_ctrl
-enum { C_STOP = 0, C_ITERS = 1, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
+// C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
+// zero-density sites" (how the next sweeps tally them, see k_sweep); it survives a restart.
+enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
        C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_WORDS = 16 };
 
 struct CtrlArgs {
@@ -62,6 +64,8 @@ struct SweepArgs {
     // sharded runs: the last block to finish stores this rank's "some label changed in this round" byte behind
     // its label block (the label all-gather then carries it to every rank)
     uint8_t* publish_byte; int* publish_ticket;
+    // zero-density tally of a large grid (see k_sweep): last-block counters to fold it through, or nullptr
+    int* fold_ticket;
 };
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
                          const int* stop, const CtrlArgs* ctrl, hipStream_t s);

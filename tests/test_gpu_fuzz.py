@@ -110,3 +110,24 @@ def test_random_large_problem(gpu_lib, oracle, seed):
     for key in ("disp", "prop"):
         assert maxdiff(got[key], want[key]) <= TOL, (key, ctx)
     assert np.array_equal(got["center"], want["center"]), ctx
+
+
+@pytest.mark.parametrize("n,d", [(12000, 2800), (66000, 2800)])
+def test_every_density_underflows(gpu_lib, oracle, n, d):
+    """Wide matrices drive every density to zero (exp(-dk) underflows): every site takes the uniform-posterior
+    branch of nem_alg.c:2603-2613 and is counted.  Grids of 47 (256-site) and 65 (1024-site) blocks: the tally
+    goes through the last-block counters from the second sweep on, and must still equal the reference's."""
+    from pangenomenem_amd import synth
+    from pangenomenem_amd.engine import solve
+    x, _ = synth.bernoulli_pa_matrix(n, d, 5)
+    nei = synth.contiguity_graph(n, 5)
+    prop, center, disp = synth.default_init(d)
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=3, tie="hash", seed=3)
+    want = oracle.run(x, nei, 3, prop, center, disp, **cfg)
+    got = solve(x, nei, 3, prop, center, disp, **cfg)
+    assert want["n_zero_density"] > n // 2               # the regime this test is about
+    assert got["n_zero_density"] == want["n_zero_density"]
+    assert got["status"] == want["status"] and got["iters"] == want["iters"]
+    assert np.array_equal(got["c"], want["c"])
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, key
