@@ -256,6 +256,15 @@ int nemgpu_set_fast_forward(nemgpu_engine* e, int on);
    (2^23 = "step exactly").  Host-only, needs no GPU. */
 int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256);
 
+/* The criteria of ComputeCrit (nem_alg.c:2727-2745) are i-ordered float accumulators
+   acc = (float)((double)acc + x_i); the library evaluates them exactly but in parallel: between two powers of two
+   the accumulator moves on a fixed grid and the chain is a prefix sum of integers
+   (pangenomenem_amd/csrc/nem_chain.hpp).  Test hooks for that procedure on arbitrary doubles:
+   nemgpu_chain_host -- mode 0: the plain sequential loop, mode 1: the host emulation of the device procedure
+   (no GPU needed); nemgpu_chain_device -- the device procedure itself. */
+float nemgpu_chain_host(const double* x, long long n, float init, int mode);
+int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out);
+
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);
 

@@ -17,6 +17,7 @@
 
 #include "nem_internal.hpp"
 #include "nem_ff.hpp"
+#include "nem_chain.hpp"
 #include "nem_rng.hpp"
 #include "nem_kernels.hpp"
 
@@ -644,7 +645,7 @@ int ensure_crit_buffers(nemgpu_engine* e)
         if ((r = dev_alloc(&e->crit_gik, nk))) return r;
         if ((r = dev_alloc(&e->crit_lfi, (size_t)e->n))) return r;
         if ((r = dev_alloc(&e->crit_lzi, (size_t)e->n))) return r;
-        if ((r = dev_alloc(&e->crit6_dev, 8))) return r;
+        if ((r = dev_alloc(&e->crit6_dev, 16))) return r;     // six criteria + the four chains' results
     }
     if (e->ncem() && !e->c_onehot) { if ((r = dev_alloc(&e->c_onehot, (size_t)e->n_total * e->k))) return r; }
     return NEMGPU_OK;
@@ -1662,3 +1663,29 @@ int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
 }
 
 }  // extern "C"
+
+// ---- test hooks for the exact segmented chains (nem_chain.hpp) ----
+// mode 0: plain sequential loop; 1: the host emulation of the device procedure.  No GPU needed.
+extern "C" float nemgpu_chain_host(const double* x, long long n, float init, int mode)
+{
+    return mode == 0 ? nemchain::run_sequential(x, n, init) : nemchain::run_segmented(x, n, init);
+}
+
+// the device procedure on device `device`; returns NEMGPU_OK or an error code
+extern "C" int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out)
+{
+    if (x == nullptr || out == nullptr || n < 0) { set_error("nemgpu_chain_device: bad argument"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(device));
+    double* dx = nullptr; float* dout = nullptr;
+    HIPCHK(hipMalloc(&dx, (size_t)std::max<long long>(n, 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&dout, sizeof(float)));
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    nemk::launch_chain_debug(dx, n, init, dout, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipStreamDestroy(st); (void)hipFree(dx); (void)hipFree(dout);
+    return NEMGPU_OK;
+}

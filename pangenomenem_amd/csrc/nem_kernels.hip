@@ -16,6 +16,7 @@
 #include <cstdint>
 
 #include "nem_ff.hpp"
+#include "nem_chain.hpp"
 #include "nem_kernels.hpp"
 
 namespace nemk {
@@ -1709,55 +1710,180 @@ __global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, cons
     lzi[i] = log((double)zi);                                             // :2745
 }
 
-// The four accumulators are i-ordered (k inner) float chains: one lane each, fed from LDS-staged
-// chunks.  Entries with cik <= MINFLOAT were stored as -0.0f by k_crit_terms, so adding every entry
-// reproduces the reference's conditional adds (nem_alg.c:2727-2736) bit for bit.
-__global__ __launch_bounds__(256) void k_crit_reduce(int n, int K, float beta, const float* __restrict__ dik,
-                                                     const float* __restrict__ gik, const double* __restrict__ lfi,
-                                                     const double* __restrict__ lzi, float* __restrict__ crit6)
+// ------------------------------------------------------------------------------------------
+// The four accumulators are i-ordered (k inner) float chains, acc = (float)((double)acc + x).  They are evaluated
+// exactly, but not one element after the other: between two powers of two the accumulator moves on a fixed grid and
+// the chain is a prefix sum of integers (nem_chain.hpp).  One 1024-thread block per chain: a window of 4096 values
+// is staged in LDS as doubles; each pass gives every thread 4 consecutive values, scans the increments, finds the
+// first element the integer form cannot take (next binade, (near) tie, shrinking sum, non-finite) and takes that
+// one -- and a burst after it, short at first, doubling while the integer form keeps making no headway (sums that
+// change binade at every step, or all non-finite: then the chain is simply stepped) -- with the reference's
+// arithmetic.
+// Entries with cik <= MINFLOAT were stored as -0.0f by k_crit_terms, so adding every entry reproduces the
+// reference's conditional adds (nem_alg.c:2727-2736) bit for bit.
+// ------------------------------------------------------------------------------------------
+constexpr int CH_T = 1024, CH_C = 4, CH_W = CH_T * CH_C;
+
+struct ChainShared {
+    double x[CH_W];
+    uint32_t wave_sum[CH_T / 64];
+    uint32_t m_before;
+    float acc;
+    int pstar, next;
+};
+
+// `count` reference steps from xs[p] on, sixteen values fetched at a time ahead of the dependent chain
+__device__ inline float chain_steps(float acc, const double* xs, int p, int count)
 {
-    constexpr int CAP = 4096;                            // staged (site, class) entries per chunk
-    __shared__ float4 sD4[CAP / 4], sG4[CAP / 4];
-    __shared__ double sL[CAP / 2], sZ[CAP / 2];
-    __shared__ float fin[4];
-    float* sD = reinterpret_cast<float*>(sD4);
-    float* sG = reinterpret_cast<float*>(sG4);
-    const int ch = max(1, min(CAP / K, CAP / 2));        // sites per chunk
-    float acc = 0.0f;                                    // lane 0: D, 64: G, 128: L, 192: Z
-    for (int i0 = 0; i0 < n; i0 += ch) {
-        const int cn = min(ch, n - i0);
-        const int m = cn * K;
-        __syncthreads();
-        for (int t = threadIdx.x; t < ((m + 3) & ~3); t += 256) {
-            const size_t g = (size_t)i0 * K + t;         // row-major (i, k): i outer, k inner
-            sD[t] = t < m ? dik[g] : -0.0f;
-            sG[t] = t < m ? gik[g] : -0.0f;
-        }
-        for (int t = threadIdx.x; t < cn; t += 256) { sL[t] = lfi[i0 + t]; sZ[t] = lzi[i0 + t]; }
-        __syncthreads();
-        if (threadIdx.x == 0) {                                                            // :2734
-#pragma unroll 4
-            for (int t = 0; t < (m + 3) / 4; t++) { const float4 v = sD4[t]; acc = (((acc + v.x) + v.y) + v.z) + v.w; }
-        } else if (threadIdx.x == 64) {                                                    // :2735
-#pragma unroll 4
-            for (int t = 0; t < (m + 3) / 4; t++) { const float4 v = sG4[t]; acc = (((acc + v.x) + v.y) + v.z) + v.w; }
-        } else if (threadIdx.x == 128) {                                                   // :2744
-#pragma unroll 8
-            for (int t = 0; t < cn; t++) acc = (float)((double)acc + sL[t]);
-        } else if (threadIdx.x == 192) {                                                   // :2745
-#pragma unroll 8
-            for (int t = 0; t < cn; t++) acc = (float)((double)acc - sZ[t]);
-        }
+    int i = 0;
+    for (; i + 16 <= count; i += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = xs[p + i + t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = nemchain::step(acc, v[t]);
     }
-    if ((threadIdx.x & 63) == 0) fin[threadIdx.x >> 6] = acc;
+    for (; i < count; i++) acc = nemchain::step(acc, xs[p + i]);
+    return acc;
+}
+
+// consume the wn staged values; every thread of the block calls this (uniform control flow: all decisions are taken
+// on shared values read after a barrier)
+__device__ inline void chain_window(ChainShared& s, int wn, int& burst)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int wpos = 0;
+    while (wpos < wn) {
+        __syncthreads();                                 // s.acc (and, the first time round, s.x) is settled
+        const float acc = s.acc;
+        int E, neg;
+        if (!nemchain::ready(acc, E, neg)) {
+            if (tid == 0) {
+                const int cnt = min(burst, wn - wpos);
+                s.acc = chain_steps(acc, s.x, wpos, cnt); s.next = wpos + cnt;
+            }
+            burst = nemchain::next_burst(burst, -1);
+            __syncthreads();
+            wpos = s.next;
+            continue;
+        }
+        if (tid == 0) s.pstar = INT_MAX;
+        const double sc = nemchain::scale(E, neg);
+        const long long M0 = nemchain::mantissa(acc);
+        const int j0 = wpos + tid * CH_C;
+        // Increments are below 2^25 and every prefix that matters is at most 2^24, so the scan runs on 32-bit
+        // unsigned integers: a prefix that wraps belongs to a thread behind the first stop, whose candidate (always
+        // at or behind its own first element) loses to the true one.
+        uint32_t inc[CH_C];
+        int stop = CH_C;                                 // first element of my four that needs the exact step
+        uint32_t lsum = 0;
+#pragma unroll
+        for (int c = 0; c < CH_C; c++) {
+            inc[c] = 0;
+            if (j0 + c < wn && c < stop) {
+                long long v;
+                if (nemchain::increment(s.x[j0 + c], sc, v)) { inc[c] = (uint32_t)v; lsum += inc[c]; }
+                else stop = c;
+            }
+        }
+        uint32_t incl = lsum;                            // inclusive scan over the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s.wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t M = (uint32_t)M0 + incl - lsum;
+#pragma unroll
+        for (int w = 0; w < CH_T / 64; w++) {            // (independent loads, one LDS latency)
+            const uint32_t v = s.wave_sum[w];
+            M += (w < wave) ? v : 0u;
+        }
+        int cand = INT_MAX;
+        uint32_t candM = 0;
+        constexpr uint32_t top = (uint32_t)nemchain::kTop;
+#pragma unroll
+        for (int c = 0; c < CH_C; c++) {
+            const int j = j0 + c;
+            if (j < wn && cand == INT_MAX) {
+                if (c == stop || M >= top || M + inc[c] > top) { cand = j; candM = M; }
+                else M += inc[c];
+            }
+        }
+        if (cand != INT_MAX) atomicMin(&s.pstar, cand);
+        __syncthreads();
+        const int p = s.pstar;
+        if (p == INT_MAX) {                              // the rest of the window went through in integer form
+            if (j0 <= wn - 1 && wn - 1 < j0 + CH_C) s.acc = nemchain::compose((long long)M, E, neg);
+            burst = nemchain::next_burst(burst, wn - wpos);
+            wpos = wn;
+            continue;                                    // (the barrier at the loop head / the caller's publishes s.acc)
+        }
+        if (cand == p) s.m_before = candM;
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt = min(burst, wn - p);
+            s.acc = chain_steps(nemchain::compose((long long)s.m_before, E, neg), s.x, p, cnt); s.next = p + cnt;
+        }
+        burst = nemchain::next_burst(burst, p - wpos);
+        __syncthreads();
+        wpos = s.next;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float D = fin[0], G = fin[1], L = fin[2], Z = fin[3];
-        crit6[0] = D; crit6[1] = G;
-        crit6[2] = (float)((double)D + (0.5 * (double)beta) * (double)G);   // :2750
-        crit6[3] = (D + (beta * G)) + Z;                                    // :2751
-        crit6[4] = L; crit6[5] = Z;
+}
+
+// chain 0: D (sum of dik), 1: G (sum of gik), 2: L (sum of lfi), 3: Z (minus the sum of lzi); result to part[chain]
+__global__ __launch_bounds__(CH_T) void k_crit_reduce(int n, int K, const float* __restrict__ dik,
+                                                      const float* __restrict__ gik, const double* __restrict__ lfi,
+                                                      const double* __restrict__ lzi, float* __restrict__ part)
+{
+    __shared__ ChainShared s;
+    const int chain = blockIdx.x;
+    const long long total = chain < 2 ? (long long)n * K : (long long)n;     // row-major (i, k): i outer, k inner
+    if (threadIdx.x == 0) s.acc = 0.0f;
+    int burst = nemchain::kBurst;
+    for (long long base = 0; base < total; base += CH_W) {
+        const int wn = (int)min((long long)CH_W, total - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < wn; t += CH_T) {
+            const long long g = base + t;
+            s.x[t] = chain == 0 ? (double)dik[g] : chain == 1 ? (double)gik[g] : chain == 2 ? lfi[g] : -lzi[g];
+        }
+        chain_window(s, wn, burst);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) part[chain] = s.acc;
+}
+
+__global__ void k_crit_final(float beta, const float* __restrict__ part, float* __restrict__ crit6)
+{
+    const float D = part[0], G = part[1], L = part[2], Z = part[3];
+    crit6[0] = D; crit6[1] = G;
+    crit6[2] = (float)((double)D + (0.5 * (double)beta) * (double)G);   // :2750
+    crit6[3] = (D + (beta * G)) + Z;                                    // :2751
+    crit6[4] = L; crit6[5] = Z;
+}
+
+// test hook: the chain procedure on arbitrary doubles (one block)
+__global__ __launch_bounds__(CH_T) void k_chain_debug(const double* __restrict__ x, long long n, float init, float* out)
+{
+    __shared__ ChainShared s;
+    if (threadIdx.x == 0) s.acc = init;
+    int burst = nemchain::kBurst;
+    for (long long base = 0; base < n; base += CH_W) {
+        const int wn = (int)min((long long)CH_W, n - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < wn; t += CH_T) s.x[t] = x[base + t];
+        chain_window(s, wn, burst);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *out = s.acc;
+}
+
+void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_chain_debug, dim3(1), dim3(CH_T), 0, s, x, n, init, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1872,7 +1998,9 @@ void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_
 {
     hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, n, K, npad, nei_ptr, nei_idx, nei_w,
                        use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi, hard);
-    hipLaunchKernelGGL(k_crit_reduce, dim3(1), dim3(256), 0, s, n, hard ? 1 : K, beta, dik, gik, lfi, lzi, crit6);
+    // (crit6 has room for the four partial results behind the six criteria)
+    hipLaunchKernelGGL(k_crit_reduce, dim3(4), dim3(CH_T), 0, s, n, hard ? 1 : K, dik, gik, lfi, lzi, crit6 + 6);
+    hipLaunchKernelGGL(k_crit_final, dim3(1), dim3(1), 0, s, beta, crit6 + 6, crit6);
 }
 
 }  // namespace nemk
