@@ -265,6 +265,11 @@ int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256);
 float nemgpu_chain_host(const double* x, long long n, float init, int mode);
 int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out);
 
+/* nemgpu_destroy parks an engine's stream, first 16 MB of device memory and pinned control block (up to 16 sets
+   per process) for the next nemgpu_create on the same device -- a nem() call creates and destroys an engine, and
+   creating these costs as much as a small EM run.  This frees whatever is parked. */
+void nemgpu_release_cached(void);
+
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);
 

@@ -3,6 +3,7 @@
 // Same symbol, argument list, file formats and return codes as the reference's only FFI entry;
 // the EM loop runs on the GPU through the nemgpu_* engine.  Text written to <Fname>.stderr keeps
 // the reference's wording where a caller could plausibly grep it.
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -181,6 +182,11 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         return EXIT_E_ARGS_;
     }
 
+    // wall-clock of the call's phases, reported on one "[engine]" line of the text output
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t_start = clk::now();
+
     NemInputs in;
     std::string err;
     int sts;
@@ -286,6 +292,8 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     }
 
     // ---- the EM run on the GPU (ClassifyByNem, :624)
+    const clk::time_point t_read = clk::now();
+    clk::time_point t_up = t_read;
     nemgpu_engine* e = nullptr;
     nemgpu_result res{};
     bool full_log = false;
@@ -294,6 +302,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
     if (rc == NEMGPU_OK && !random_init) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
     if (rc == NEMGPU_OK) rc = nemgpu_configure(e, &cfg);
+    t_up = clk::now();
     if (rc == NEMGPU_OK) {
         if (random_init) {
             // RandNemAlgo with the reference's 50 starts (DEFAULT_NBRANDINITS, nem_typ.h:94); the draws come from the
@@ -329,6 +338,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         else lg.pr("  NEM did not converge after %d iterations\n", res.iters);
     }
     lg.pr("  [engine] EM loop %.6f s, %d sweep relaxation rounds\n", res.loop_seconds, res.sweep_rounds);
+    const clk::time_point t_run = clk::now();
 
     int ret = EXIT_OK_;
     if (res.status == NEMGPU_OK) {
@@ -350,6 +360,8 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
                 fclose(fl);
             }
         }
+        lg.pr("  [engine] phases: read %.4f s, engine + upload %.4f s, run%s %.4f s, results %.4f s\n", secs(t_start, t_read),
+              secs(t_read, t_up), full_log ? " (logged)" : "", secs(t_up, t_run), secs(t_run, clk::now()));
         lg.pr("NEM completed, classification in %s\n", outname.c_str());    // :642-645
         lg.pr(" criteria and parameters in %s%s\n", base.c_str(), ".mf");
         if (dolog) lg.pr("Log of detailed running in %s.log\n", base.c_str());

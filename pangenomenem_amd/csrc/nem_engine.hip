@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "nem_internal.hpp"
@@ -126,6 +127,14 @@ struct nemgpu_engine {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
 
+    // Device memory comes from a few large zeroed chunks (one hipMalloc + one fill each) that buffers are carved
+    // from and that live as long as the engine: a nem() call creates and destroys an engine, and ~50 hipMalloc /
+    // fill / hipFree triples were a fifth of its time at configs[1].
+    struct Chunk { char* base; size_t size, used; };
+    std::vector<Chunk> chunks;
+    int shared_chunk = -1;                     // the chunk small buffers are carved from
+    uint8_t* best_lab = nullptr; float* best_c = nullptr;   // nemgpu_run_random: the best start's partition
+
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
     int* iter_flags() const { return flags_dev + C_WORDS; }
@@ -142,14 +151,53 @@ namespace {
 // default stream: several engines may run on different host threads at once (pangenomenem_amd/batch.py), and a
 // legacy-stream operation of one thread would collide with a graph capture in progress on another.
 thread_local hipStream_t g_alloc_stream = nullptr;      // stream of the engine whose buffers are being allocated
+thread_local nemgpu_engine* g_alloc_engine = nullptr;   // ... and the engine itself (owner of the chunks)
+void alloc_for(nemgpu_engine* e) { g_alloc_engine = e; g_alloc_stream = e->stream; }
 
+// What an engine needs before it can do anything -- a stream, a first chunk of device memory, the pinned block the
+// loop control is copied to -- costs ~2 ms to create and up to 2 ms to release; a destroyed engine's set is parked
+// here and handed to the next engine on the same device (PPanGGOLiN calls nem() once per chunk of organisms, each
+// call creating and destroying an engine).  nemgpu_release_cached() frees what is parked.
+struct ParkedSet { int device; hipStream_t stream; char* chunk; int* flags_host; };
+std::mutex g_park_mutex;
+std::vector<ParkedSet> g_parked;
+constexpr size_t kParkMax = 16;
+
+constexpr size_t kChunkShared = (size_t)16 << 20;       // small buffers share 16 MB chunks
+constexpr size_t kChunkOwn = (size_t)4 << 20;           // from 4 MB on a buffer gets a chunk of its own
+
+int chunk_new(nemgpu_engine* e, size_t bytes)
+{
+    char* base = nullptr;
+    HIPCHK(hipMalloc((void**)&base, bytes));
+    e->chunks.push_back({base, bytes, 0});
+    HIPCHK(hipMemsetAsync(base, 0, bytes, g_alloc_stream));   // (every later use is on the same stream)
+    return NEMGPU_OK;
+}
+
+// zeroed device memory that lives until the engine is destroyed
 template <typename T>
 int dev_alloc(T** p, size_t count)
 {
     *p = nullptr;
+    nemgpu_engine* e = g_alloc_engine;
+    if (e == nullptr) { set_error("dev_alloc outside an engine"); return NEMGPU_E_FUNCARG; }
     if (count == 0) count = 1;
-    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
-    HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), g_alloc_stream));   // (every later use is on the same stream)
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    int r;
+    if (bytes >= kChunkOwn) {
+        if ((r = chunk_new(e, bytes))) return r;
+        e->chunks.back().used = bytes;
+        *p = reinterpret_cast<T*>(e->chunks.back().base);
+        return NEMGPU_OK;
+    }
+    if (e->shared_chunk < 0 || e->chunks[e->shared_chunk].size - e->chunks[e->shared_chunk].used < bytes) {
+        if ((r = chunk_new(e, kChunkShared))) return r;
+        e->shared_chunk = (int)e->chunks.size() - 1;
+    }
+    nemgpu_engine::Chunk& c = e->chunks[e->shared_chunk];
+    *p = reinterpret_cast<T*>(c.base + c.used);
+    c.used += bytes;
     return NEMGPU_OK;
 }
 
@@ -158,7 +206,7 @@ hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes,
 
 int ensure_state_buffers(nemgpu_engine* e)
 {
-    g_alloc_stream = e->stream;
+    alloc_for(e);
     if (e->ncem()) {
         for (int b = 0; b < 3; b++)
             if (!e->lab[b]) { int r = dev_alloc(&e->lab[b], (size_t)e->n_total); if (r) return r; }
@@ -637,7 +685,7 @@ void drop_graphs(nemgpu_engine* e)
 
 int ensure_crit_buffers(nemgpu_engine* e)
 {
-    g_alloc_stream = e->stream;
+    alloc_for(e);
     int r;
     size_t nk = (size_t)e->n * e->k;
     if (!e->crit_dik) {
@@ -758,14 +806,26 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
-    if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
+    ParkedSet parked{-1, nullptr, nullptr, nullptr};
+    if (!hip_stream) {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        for (size_t i = 0; i < g_parked.size(); i++)
+            if (g_parked[i].device == device) { parked = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); break; }
+    }
+    if (parked.device >= 0) {
+        e->stream = parked.stream; e->own_stream = true;
+        e->flags_host = parked.flags_host;
+        e->chunks.push_back({parked.chunk, kChunkShared, 0});
+        e->shared_chunk = 0;
+        if (hipMemsetAsync(parked.chunk, 0, kChunkShared, e->stream) != hipSuccess) { nemgpu_destroy(e); set_error("hipMemsetAsync failed"); return NEMGPU_E_DEVICE; }
+    } else if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
         e->own_stream = true;
     }
     int r = NEMGPU_OK;
     const size_t kd = (size_t)k * d, kdp = (size_t)k * e->dpad;
-    g_alloc_stream = e->stream;
+    alloc_for(e);
     auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
     A(dev_alloc(&e->xw, (size_t)e->W * e->npad));
     A(dev_alloc(&e->xws, (size_t)((e->W + 3) / 4) * 4 * e->npad));   // uint4[ceil(W/4)][npad]
@@ -783,7 +843,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     A(dev_alloc(&e->mask, (size_t)k * e->nw64));
     A(dev_alloc(&e->stats, (size_t)k + kd));
     A(dev_alloc(&e->flags_dev, e->flag_words()));
-    if (r == NEMGPU_OK && hipHostMalloc((void**)&e->flags_host, e->flag_words() * sizeof(int)) != hipSuccess) {
+    if (r == NEMGPU_OK && !e->flags_host && hipHostMalloc((void**)&e->flags_host, e->flag_words() * sizeof(int)) != hipSuccess) {
         set_error("hipHostMalloc failed"); r = NEMGPU_E_DEVICE;
     }
     if (r != NEMGPU_OK) { nemgpu_destroy(e); return r; }
@@ -799,18 +859,36 @@ void nemgpu_destroy(nemgpu_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     rccl_release(e);
-    void* ptrs[] = {e->xw, e->xws, e->perm, e->xt, e->nei_ptr, e->nei_idx, e->nei_w, e->prop, e->center, e->disp, e->prop0, e->center0,
-                    e->disp0, e->nbobs_k, e->iner, e->fz_lastz, e->fz_any1, e->fz_in0, e->fz_in1, e->fz_inh, e->tabT, e->tabL0, e->nz0,
-                    e->nz1, e->am0, e->am1, e->uni, e->nonuni, e->sweep_next, e->pk, e->logpk, e->pkfki, e->logpkfki, e->lab[0], e->lab[1], e->lab[2], e->cbuf[0],
-                    e->cbuf[1], e->cbuf[2], e->mask, e->stats, e->flags_dev, e->c_onehot, e->crit_dik, e->crit_gik,
-                    e->crit6_dev, e->crit_lfi, e->crit_lzi};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (e->flags_host) (void)hipHostFree(e->flags_host);
     drop_graphs(e);
+    // park the stream, the first shared chunk and the pinned block for the next engine on this device
+    char* keep = nullptr;
+    if (e->own_stream && e->stream && e->flags_host)
+        for (const nemgpu_engine::Chunk& c : e->chunks) if (c.size == kChunkShared) { keep = c.base; break; }
+    if (keep) {
+        std::lock_guard<std::mutex> lock(g_park_mutex);
+        if (g_parked.size() < kParkMax) g_parked.push_back({e->device, e->stream, keep, e->flags_host});
+        else keep = nullptr;
+    }
+    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.base != keep) (void)hipFree(c.base);
+    if (!keep) {
+        if (e->flags_host) (void)hipHostFree(e->flags_host);
+        if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+void nemgpu_release_cached(void)
+{
+    std::vector<ParkedSet> sets;
+    { std::lock_guard<std::mutex> lock(g_park_mutex); sets.swap(g_parked); }
+    for (const ParkedSet& p : sets) {
+        (void)hipSetDevice(p.device);
+        (void)hipFree(p.chunk);
+        (void)hipHostFree(p.flags_host);
+        (void)hipStreamDestroy(p.stream);
+    }
 }
 
 int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
@@ -883,9 +961,9 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     for (int t = 0; t < nnz; t++)
         if (idx[t] < 0 || idx[t] >= e->n_total) { set_error("graph: neighbour index out of range"); return NEMGPU_E_ARG; }
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->nei_ptr) { (void)hipFree(e->nei_ptr); (void)hipFree(e->nei_idx); (void)hipFree(e->nei_w); e->nei_ptr = nullptr; e->nei_idx = nullptr; e->nei_w = nullptr; }
+    e->nei_ptr = nullptr; e->nei_idx = nullptr; e->nei_w = nullptr;   // (a replaced graph's arrays stay in their chunk)
     int r;
-    g_alloc_stream = e->stream;
+    alloc_for(e);
     if ((r = dev_alloc(&e->nei_ptr, (size_t)e->n + 1))) return r;
     if ((r = dev_alloc(&e->nei_idx, (size_t)nnz))) return r;
     if ((r = dev_alloc(&e->nei_w, (size_t)nnz))) return r;
@@ -1022,11 +1100,11 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
     GlibcRandom rng(seed);
     std::vector<float> prop((size_t)k), center(kd), disp(kd);
     auto bit = [&](int i, int j) { return (float)((e->host_bits[(size_t)i * wf + (j >> 5)] >> (j & 31)) & 1u); };
-    uint8_t* best_lab = nullptr; float* best_c = nullptr;
-    g_alloc_stream = e->stream;
-    if (e->ncem()) { if ((r = dev_alloc(&best_lab, (size_t)e->n_total))) return r; }
-    else { if ((r = dev_alloc(&best_c, (size_t)e->n_total * k))) return r; }
-    auto cleanup = [&]() { (void)hipStreamSynchronize(e->stream); if (best_lab) (void)hipFree(best_lab); if (best_c) (void)hipFree(best_c); };
+    alloc_for(e);
+    if (e->ncem()) { if (!e->best_lab && (r = dev_alloc(&e->best_lab, (size_t)e->n_total))) return r; }
+    else { if (!e->best_c && (r = dev_alloc(&e->best_c, (size_t)e->n_total * k))) return r; }
+    uint8_t* best_lab = e->best_lab; float* best_c = e->best_c;
+    auto cleanup = [&]() { (void)hipStreamSynchronize(e->stream); };
     int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
     float best_crit[6] = {0, 0, 0, 0, 0, 0};
     nemgpu_result best_res{};

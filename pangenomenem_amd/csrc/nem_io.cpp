@@ -290,13 +290,35 @@ int read_param_file(const std::string& base, int k, NemInputs& in, std::string& 
 }
 
 // SaveResults, fuzzy branch: nem_exe.c:1673-1687
+// " %5.3f " of one membership, as printf prints it.  Memberships live in [0, 1]: v * 1000 is exact in a double (24 + 10
+// bits), so rint() -- round to nearest, ties to even, printf's rule in the default rounding mode -- of that product
+// is the three-decimal rounding of the exact binary value; anything else (negative, >= 10, NaN) goes to snprintf.
+static inline char* put_membership(char* o, float v)
+{
+    if (v >= 0.0f && v < 9.9994f && !std::signbit(v)) {    // (-0.0 prints as -0.000)
+        const int r = (int)rint((double)v * 1000.0);     // 0 .. 9999
+        o[0] = ' ';
+        o[1] = (char)('0' + r / 1000);
+        o[2] = '.';
+        o[3] = (char)('0' + (r / 100) % 10);
+        o[4] = (char)('0' + (r / 10) % 10);
+        o[5] = (char)('0' + r % 10);
+        o[6] = ' ';
+        return o + 7;
+    }
+    return o + snprintf(o, 64, " %5.3f ", v);
+}
+
 int write_uf_file(const std::string& path, const float* c, int n, int k)
 {
     FILE* fp = fopen(path.c_str(), "w");
     if (!fp) return NEMGPU_E_FILEOUT;
+    std::vector<char> buf((size_t)64 * k + 2);
     for (int i = 0; i < n; i++) {
-        for (int kk = 0; kk < k; kk++) fprintf(fp, " %5.3f ", c[(size_t)i * k + kk]);
-        fputc('\n', fp);
+        char* o = buf.data();
+        for (int kk = 0; kk < k; kk++) o = put_membership(o, c[(size_t)i * k + kk]);
+        *o++ = '\n';
+        fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp);
     }
     fclose(fp);
     return NEMGPU_OK;

@@ -193,3 +193,23 @@ def test_restated_generator_is_glibc_random(lib):
         libc.srandom(seed)
         want = np.array([libc.random() for _ in range(n)], np.int64)
         assert np.array_equal(got.astype(np.int64), want), seed
+
+
+def test_uf_writer_fast_path_prints_like_printf(lib, tmp_path):
+    """The .uf writer formats memberships itself (" %5.3f "); it must print what printf prints: exact binary value,
+    three decimals, ties to even -- dyadic ties, values a hair beside them, the ends of the fast path's range,
+    and the values it hands to snprintf (negative, -0.0, >= 10, NaN, inf)."""
+    from pangenomenem_amd import engine
+    rng = np.random.Generator(np.random.PCG64(5))
+    ties = np.array([0.0625, 0.1875, 0.3125, 0.4375, 0.5625, 0.0005, 0.0015, 0.0025, 0.9995, 0.99949998, 0.99950004,
+                     0.5, 0.25, 0.125, 0.0, 1.0, 1.0 / 3, 2.0 / 3, 1e-30, 1e-4, 4.99e-4, 5.01e-4, 9.9993, 9.9994, 9.99949,
+                     9.9995, 10.0, 123.456, -0.0, -0.25, -1e-9, np.nan, np.inf, -np.inf], np.float32)
+    near = np.nextafter(ties[:12], np.float32(2)), np.nextafter(ties[:12], np.float32(-2))
+    vals = np.concatenate([ties, near[0], near[1], rng.random(3000).astype(np.float32),
+                           (rng.integers(0, 8193, 3000) / 8192.0).astype(np.float32),      # many exact ties
+                           (rng.random(900) * 10).astype(np.float32)])
+    vals = vals[: (len(vals) // 3) * 3].reshape(-1, 3)
+    path = str(tmp_path / "fmt.uf")
+    assert engine.write_uf(path, vals) == 0
+    want = "".join("".join(" %5.3f " % float(v) for v in row) + "\n" for row in vals)
+    assert open(path).read() == want

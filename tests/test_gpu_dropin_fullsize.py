@@ -63,7 +63,8 @@ def test_dropin_whole_call_at_configs1(gpu_lib, tmp_path):
     rec = dict(workload="BASELINE configs[1] files: 20000 x 500, K=3, beta=0.5, ncem/sk_/pk, dolog=1",
                input_bytes=sum(os.path.getsize(base + e) for e in (".str", ".dat", ".nei", ".m")),
                reference_nem_whole_call_s=t_ref, this_library_nem_whole_call_s=t_ours,
-               speedup_whole_call=t_ref / t_ours, python_input_write_s=t_write, host_cores_used=1)
+               speedup_whole_call=t_ref / t_ours, python_input_write_s=t_write, host_cores_used=1,
+               phases=[l.strip() for l in open(base + ".stderr").read().splitlines() if "[engine]" in l])
     print(json.dumps(rec))
     out = os.path.join(ROOT, "gpurun_out")
     try:
