@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 
 #include "nem_internal.hpp"
 
@@ -107,10 +111,73 @@ int read_str_file(const std::string& base, NemInputs& in, std::string& err)
 
 // ReadMatrixFile, nem_exe.c:834-898: N*D whitespace-separated numbers.  This engine handles
 // presence/absence data: every value must be 0 or 1 (what ppanggolin.py:850 writes).
+// One row of the text ppanggolin.py:850 writes -- one character per value, one tab between values, a newline at
+// the end ("0\t1\t...\t1\n", 2*d bytes): 4 values per 8-byte load, validated and packed with integer arithmetic.
+// Returns how many values (a multiple of 4, or d) were taken.
+static inline int pack_regular_row(const char* p, int d, uint32_t* row)
+{
+    int j = 0;
+    for (; j + 4 <= d; j += 4) {
+        uint64_t w;
+        memcpy(&w, p + 2 * (size_t)j, 8);
+        const bool last = (j + 4 == d);
+        const uint64_t seps = last ? 0x0A00090009000900ull : 0x0900090009000900ull;
+        if ((w & 0xFFFEFFFEFFFEFFFEull) != (0x0030003000300030ull | seps)) break;
+        const uint32_t nib = (uint32_t)(((w & 0x0001000100010001ull) * 0x0001000200040008ull) >> 48) & 0xFu;
+        row[j >> 5] |= nib << (j & 31);                 // j % 4 == 0: the nibble never straddles a word
+    }
+    return j;
+}
+
+// A file of exactly n rows of 2*d bytes (d a multiple of 4) is, if every row has the regular form, n rows at known
+// offsets: a few threads pread() their share of rows through a small buffer each (the text never sits in memory as
+// a whole) and pack it.  false = some row is not regular (nothing is reported; the general reader takes over).
+static bool read_dat_regular(const std::string& path, int n, int d, int wf, uint32_t* xbits)
+{
+    if (n <= 0 || d <= 0 || (d & 3)) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    const size_t rowb = 2 * (size_t)d;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size != rowb * (size_t)n) { close(fd); return false; }
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::max(1u, std::min({4u, hw ? hw : 1u, (unsigned)(((size_t)st.st_size >> 21) + 1)}));   // 2 MB and more per thread
+    std::vector<char> ok((size_t)nt, 1);
+    auto work = [&](int t) {
+        const int r0 = (int)((long long)n * t / nt), r1 = (int)((long long)n * (t + 1) / nt);
+        const int rows_per = (int)std::max<size_t>(1, ((size_t)256 << 10) / rowb);              // ~256 KB per pread
+        std::vector<char> buf((size_t)rows_per * rowb + 8);                                     // (+8: the 8-byte loads)
+        for (int r = r0; r < r1; r += rows_per) {
+            const int nr = std::min(rows_per, r1 - r);
+            const size_t want = (size_t)nr * rowb;
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t g = pread(fd, buf.data() + got, want - got, (off_t)((size_t)r * rowb + got));
+                if (g <= 0) { ok[(size_t)t] = 0; return; }
+                got += (size_t)g;
+            }
+            for (int i = 0; i < nr; i++)
+                if (pack_regular_row(buf.data() + (size_t)i * rowb, d, xbits + (size_t)(r + i) * wf) != d) { ok[(size_t)t] = 0; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (std::thread& x : th) x.join();
+    close(fd);
+    for (char c : ok) if (!c) return false;
+    return true;
+}
+
 int read_dat_file(const std::string& base, NemInputs& in, std::string& err)
 {
     std::vector<char> buf;
     const std::string path = base + ".dat";
+    {
+        const int wf0 = (in.d + 31) / 32;
+        in.xbits.assign((size_t)in.n * wf0, 0u);
+        if (read_dat_regular(path, in.n, in.d, wf0, in.xbits.data())) return NEMGPU_OK;
+    }
     if (!slurp(path, buf)) { err = "File matrix " + path + " does not exist"; return NEMGPU_E_FILEIN; }
     const int n = in.n, d = in.d, wf = (d + 31) / 32;
     in.xbits.assign((size_t)n * wf, 0u);
@@ -119,19 +186,10 @@ int read_dat_file(const std::string& base, NemInputs& in, std::string& err)
     for (int i = 0; i < n; i++) {
         uint32_t* row = in.xbits.data() + (size_t)i * wf;
         int j = 0;
-        // Row fast path for the text ppanggolin.py:850 writes -- one character per value, one tab between values,
-        // a newline at the end ("0\t1\t...\t1\n"): 4 values per 8-byte load, validated and packed with integer
-        // arithmetic.  Anything else in the row (spaces, "1.0", blank lines) leaves the rest to the tokeniser below.
+        // Row fast path (pack_regular_row); anything else in the row (spaces, "1.0", blank lines) leaves the rest
+        // to the tokeniser below.
         if ((size_t)(bend - p) >= 2 * (size_t)d) {
-            for (; j + 4 <= d; j += 4) {
-                uint64_t w;
-                memcpy(&w, p + 2 * (size_t)j, 8);
-                const bool last = (j + 4 == d);
-                const uint64_t seps = last ? 0x0A00090009000900ull : 0x0900090009000900ull;
-                if ((w & 0xFFFEFFFEFFFEFFFEull) != (0x0030003000300030ull | seps)) break;
-                const uint32_t nib = (uint32_t)(((w & 0x0001000100010001ull) * 0x0001000200040008ull) >> 48) & 0xFu;
-                row[j >> 5] |= nib << (j & 31);                 // j % 4 == 0: the nibble never straddles a word
-            }
+            j = pack_regular_row(p, d, row);
             if (j == d) { p += 2 * (size_t)d; continue; }
             p += 2 * (size_t)j;                                  // values [0, j) are consumed (each "v\t")
         }

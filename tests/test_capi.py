@@ -178,6 +178,33 @@ def test_dat_reader_fast_path_agrees_with_the_tokeniser(lib, tmp_path):
     del m
 
 
+def test_dat_reader_regular_file_in_parallel(lib, tmp_path):
+    """A .dat of exactly n rows of 2*d bytes is read by several threads, each pread()ing its rows (6 MB here:
+    3 threads); one irregular row anywhere sends the whole file to the general reader; both give the same bits,
+    and a bad value is still reported."""
+    from pangenomenem_amd import engine
+    rng = np.random.default_rng(9)
+    n, d = 6000, 500
+    base = str(tmp_path / "big")
+    x = (rng.random((n, d)) < 0.4).astype(np.uint8)
+    open(base + ".str", "w").write("S\t%d\t%d\n" % (n, d))
+    open(base + ".nei", "w").write("1\n" + "".join("%d\t0\n" % (i + 1) for i in range(n)))
+    open(base + ".m", "w").write("1 0.3 0.3 " + " ".join(["1"] * d + ["0.5"] * d + ["0"] * d) + " " + " ".join(["0.1"] * (3 * d)))
+    text = bytearray(b"".join(b"\t".join(b"1" if v else b"0" for v in r) + b"\n" for r in x))
+    assert len(text) == 2 * d * n
+    open(base + ".dat", "wb").write(text)
+    assert np.array_equal(engine.read_inputs(base, 3)["x"], x)
+    # same size, one row spelt with a space instead of a tab: general reader, same result
+    t2 = bytearray(text); t2[2 * d * 4321 + 1] = ord(" ")
+    open(base + ".dat", "wb").write(t2)
+    assert np.array_equal(engine.read_inputs(base, 3)["x"], x)
+    # a value that is neither 0 nor 1, in the last thread's share
+    t3 = bytearray(text); t3[2 * d * 5990 + 10] = ord("2")
+    open(base + ".dat", "wb").write(t3)
+    with pytest.raises(engine.NemGpuError, match="0/1"):
+        engine.read_inputs(base, 3)
+
+
 def test_restated_generator_is_glibc_random(lib):
     """csrc/nem_rng.hpp restates the generator behind the reference's random starts: libc random() after srandom(seed)
     (nem_exe.c:621, nem_rnd.c:40-63).  Checked against this host's libc draw for draw."""
