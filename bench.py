@@ -93,6 +93,11 @@ def pmc_traffic(kernel, n_loc, d):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON record: libraries that print banners to fd 1 (RCCL prints its
+    # version when a communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -232,7 +237,8 @@ def main():
             except Exception as exc:   # the checker is optional on the box; the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 1, "kind": "unavailable",
                                        "sample": "failed: %r" % (exc,)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if world > 1 or args.dist:
         import torch.distributed as dist

@@ -79,6 +79,17 @@ def main():
         b = os.path.join(OUT, "r01_%s_prof.json" % cfg)
         if os.path.isfile(b):
             shutil.copy(b, os.path.join(HERE, "r01_bench_%s_profiled.json" % cfg))
+    # the other measurements collect.sh leaves under gpurun_out/ (copied as they are; the drop-in record is written
+    # by tests/test_gpu_dropin_fullsize.py whenever the GPU tests run)
+    for name in ("r01_bench_20000x500.json", "r01_bench_50000x1000.json", "r01_bench_200000x5000.json",
+                 "r01_bench_dist_world1.json", "r01_pcie_inclusive.json", "r01_batch_chunks.json",
+                 "r01_dropin_whole_call.json"):
+        b = os.path.join(OUT, name)
+        if os.path.isfile(b) and os.path.getsize(b) > 0:
+            shutil.copy(b, os.path.join(HERE, name))
+    f = newest("r01_c2_fuzzy/*/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(HERE, "r01_c2_fuzzy_kernel_stats.csv"))
 
 
 if __name__ == "__main__":
