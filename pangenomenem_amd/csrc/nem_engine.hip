@@ -115,13 +115,12 @@ struct nemgpu_engine {
     // auto: on from 256 organisms (below that the chain is mostly the small-binade prefix that is stepped anyway
     // and the table build is pure overhead).  Measured on MI355X: 20k x 500 on par with plain stepping
     // (latency-bound, one wave per SIMD), 50k x 1000 1.7x, 200k x 5000 9x faster.
-    // parameter update folded into the density launch: per-organism dispersions (skd) always; one dispersion per
-    // class (sk_) only while InerToDispK_'s d-ordered sums provably never round (N*D <= 2^24: closed form) --
-    // beyond that every block would redo a D-step sequential chain, which k_finish does once
+    // parameter update folded into the density launch: per-organism dispersions (skd) and one dispersion per class
+    // (sk_).  Where InerToDispK_'s d-ordered sums can round (N*D > 2^24) every block redoes the two D-step chains
+    // -- at most 1024 steps, 4.4 us, in parallel in all blocks -- which is still cheaper than k_finish's launch.
     bool fused_update() const
     {
-        return d <= kFusedMaxD && (cfg.disper == NEMGPU_DISP_KD ||
-                                   (cfg.disper == NEMGPU_DISP_K_ && (long long)n_true * d <= (1ll << 24)));
+        return d <= kFusedMaxD && (cfg.disper == NEMGPU_DISP_KD || cfg.disper == NEMGPU_DISP_K_);
     }
     bool use_ff() const { return ff_mode < 0 ? d >= 256 : ff_mode != 0; }
 

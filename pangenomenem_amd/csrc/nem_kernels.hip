@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     __shared__ uint32_t sNz0[FD_CH / 32], sNz1[FD_CH / 32];
     __shared__ uint32_t sQ0[256], sQ1[256];
     __shared__ unsigned long long sTot2;
-    __shared__ float sEps;
+    __shared__ float sEps, sChain[2];
     __shared__ int sGeneral;
     if (a.stop != nullptr && *a.stop) return;
     int k, tile;
@@ -619,17 +619,32 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     bool eps_per_d = false;                              // epsilon differs between organisms -> general chain
     if (a.disper == NEMGPU_DISP_K_) {
         if (nkf > 0) {
-            if (tid == 0) {
-                const long long cap = 1ll << 24;
-                float e;
-                if ((long long)sTot2 <= cap && (long long)nkI * (long long)D <= cap) {
-                    e = (0.5f * (float)(long long)sTot2) / (nkf * (float)D);     // the d-ordered chains never round here
-                } else {
-                    float sn = 0.0f, si = 0.0f;
-                    for (int d = 0; d < D; d++) { sn += nkf; si += sVal[d]; }
-                    e = si / sn;
+            const long long cap = 1ll << 24;
+            if ((long long)sTot2 <= cap && (long long)nkI * (long long)D <= cap) {         // (block-uniform)
+                if (tid == 0) sEps = (0.5f * (float)(long long)sTot2) / (nkf * (float)D);  // the d-ordered chains never round here
+            } else {
+                // the two d-ordered chains of InerToDispK_ (nem_mod.c:1054-1058), each on a wave of its own: the
+                // inertia values sixteen at a time from LDS ahead of the dependent adds, the N_KD chain from a register
+                if (tid == 0) {
+                    float si = 0.0f;
+                    int d = 0;
+                    for (; d + 16 <= D; d += 16) {
+                        float v[16];
+#pragma unroll
+                        for (int t = 0; t < 16; t++) v[t] = sVal[d + t];
+#pragma unroll
+                        for (int t = 0; t < 16; t++) si += v[t];
+                    }
+                    for (; d < D; d++) si += sVal[d];
+                    sChain[0] = si;
+                } else if (tid == 64) {
+                    float sn = 0.0f;
+#pragma unroll 8
+                    for (int d = 0; d < D; d++) sn += nkf;
+                    sChain[1] = sn;
                 }
-                sEps = e;
+                __syncthreads();
+                if (tid == 0) sEps = sChain[0] / sChain[1];
             }
             __syncthreads();
             const float e = sEps;
