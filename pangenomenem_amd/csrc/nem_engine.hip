@@ -859,6 +859,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     rccl_release(e);
     drop_graphs(e);
+    if (g_alloc_engine == e) g_alloc_engine = nullptr;
     // park the stream, the first shared chunk and the pinned block for the next engine on this device
     char* keep = nullptr;
     if (e->own_stream && e->stream && e->flags_host)
