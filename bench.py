@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--families", type=int, default=20000, help="families per GPU")
     ap.add_argument("--organisms", type=int, default=500)
     ap.add_argument("--algo", default="ncem")
+    ap.add_argument("--disper", default="sk_", help="dispersion model (sk_ is BASELINE's; skd = PPanGGOLiN's free_dispersion)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
     ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
@@ -122,12 +123,12 @@ def main():
         eng.set_graph(nei)
         eng.set_params(prop, center, disp)
         # how many iterations does this workload need?  (reference call: clas, 1e-8, it_max 100)
-        eng.configure(algo=args.algo, beta=beta, disper="sk_", propor="pk", cvtest="clas", cvthres=1e-8, it_max=100)
+        eng.configure(algo=args.algo, beta=beta, disper=args.disper, propor="pk", cvtest="clas", cvthres=1e-8, it_max=100)
         first = eng.run()
         # restart period of the timed loop: at least 5 iterations (what the reference needs on this
         # config per SURVEY.md §6) so the restart overhead is amortised the way a real solve amortises it
         cycle = max(5, int(first["iters"]))
-        eng.configure(algo=args.algo, beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)
+        eng.configure(algo=args.algo, beta=beta, disper=args.disper, propor="pk", cvtest="none", it_max=100)
 
         def run_steps(count):
             done = 0
@@ -197,10 +198,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s per GPU: %d families x %d organisms, K=3, beta=0.5, contiguity graph "
-                            "(path + 5%% chords, weights 1..8), %s/sk_/pk, default .m init"
+                            "(path + 5%% chords, weights 1..8), %s/%s/pk, default .m init"
                             % ({(20000, 500): "BASELINE configs[1]", (50000, 1000): "BASELINE configs[2] shape",
-                                (200000, 5000): "BASELINE configs[3] shape"}.get((n_loc, d), "custom shape"),
-                               n_loc, d, args.algo),
+                                (200000, 5000): "BASELINE configs[3] shape"}.get((n_loc, d), "custom shape")
+                               if args.disper == "sk_" else "custom model",
+                               n_loc, d, args.algo, args.disper),
                 "families_total": n_tot, "organisms": d, "K": k, "beta": beta,
                 "cycle_iterations": cycle,
                 "parallelism": "1 GPU" if world == 1 else "families sharded over %d GPUs; per EM iteration two RCCL "
