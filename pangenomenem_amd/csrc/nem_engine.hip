@@ -133,6 +133,7 @@ struct nemgpu_engine {
     std::vector<Chunk> chunks;
     int shared_chunk = -1;                     // the chunk small buffers are carved from
     uint8_t* best_lab = nullptr; float* best_c = nullptr;   // nemgpu_run_random: the best start's partition
+    bool ctrl_pending = false; CtrlArgs ctrl_deferred{};     // loop control left to the next iteration's counts launch
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -396,11 +397,11 @@ int do_labels_post(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctr
 }
 
 // EstimPara (nem_mod.c:415-469) on the current partition; leaves FLAG_EMPTYK in the iteration flags.
-int do_mstep(nemgpu_engine* e)
+int do_mstep(nemgpu_engine* e, const CtrlArgs* prev_ctrl = nullptr)
 {
     if (e->ncem()) {
         if (!e->masks_valid) { int r = do_labels_post(e, e->cur, -1); if (r) return r; }
-        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, prev_ctrl, e->stream);
         launch_finish(finish_args(e, 1, e->stats), e->stream);
     } else {
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
@@ -469,17 +470,26 @@ int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctrl = 
 
 constexpr int kPipeDepth = 6;
 
-// enqueue one whole iteration whose current partition is buffer `cur`
-int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
+// enqueue one whole iteration whose current partition is buffer `cur`.  defer_ctrl: another iteration follows in
+// the same batch -- an NCEM iteration's loop control then runs in that iteration's counts launch (k_mstep_counts)
+// instead of in a last-block ticket at the tail of the last sweep round.
+int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_ctrl)
 {
     int r;
     const int saved = e->cur;
     e->cur = cur;
     const bool fused = !e->cfg.param_fix && e->ncem() && e->fused_update();
+    const bool counts_first = !e->cfg.param_fix && e->ncem();      // the iteration starts with k_mstep_counts
+    if (e->ctrl_pending && !counts_first) {                        // (not reached: the mode is fixed within a batch)
+        launch_ctrl(e->ctrl_deferred, e->stream);
+        e->ctrl_pending = false;
+    }
     if (fused) {
         // M-step counts, then ONE kernel: parameter update (per block, from the counts) + density
         if (!e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) { e->cur = saved; return r; } }
-        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, e->stream);
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr,
+                            e->ctrl_pending ? &e->ctrl_deferred : nullptr, e->stream);
+        e->ctrl_pending = false;
         launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
                              e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
         hipError_t le = hipGetLastError();
@@ -489,7 +499,8 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
         e->density_fresh = true;
     } else {
         if (!e->cfg.param_fix) {                                   // nem_alg.c:1806
-            if ((r = do_mstep(e))) { e->cur = saved; return r; }
+            if ((r = do_mstep(e, e->ctrl_pending ? &e->ctrl_deferred : nullptr))) { e->cur = saved; return r; }
+            e->ctrl_pending = false;
             if ((r = do_tables(e))) { e->cur = saved; return r; }
         }
         if ((r = do_density(e))) { e->cur = saved; return r; }
@@ -500,8 +511,12 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id)
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
-    // NCEM: the bookkeeping (masks, "moved", loop tests) rides in the last relaxation round's launch
-    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? &ca : nullptr, true))) { e->cur = saved; return r; }
+    // NCEM: the bookkeeping (masks, "moved", loop tests) rides in the last relaxation round's launch -- the loop
+    // tests in the next iteration's counts launch when there is one
+    const bool defer = defer_ctrl && counts_first;
+    CtrlArgs none{};
+    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? (defer ? &none : &ca) : nullptr, true))) { e->cur = saved; return r; }
+    if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (!e->ncem()) { if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; } }
     else e->masks_valid = true;
     e->cur = saved;
@@ -574,7 +589,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             e->stop_ptr = e->ctrl() + C_STOP;
             if (first && herr == hipSuccess) r = enqueue_init(e);
             for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)
-                r = enqueue_iteration(e, (base + j) % 3, sweep0 + j);
+                r = enqueue_iteration(e, (base + j) % 3, sweep0 + j, j + 1 < g);
             e->stop_ptr = nullptr;
             if (herr == hipSuccess && r == NEMGPU_OK)
                 herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
@@ -1269,7 +1284,7 @@ int nemgpu_shard_counts(nemgpu_engine* e, int32_t* stats_dev)
 {
     if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream);
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -1281,7 +1296,7 @@ int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, 
     HIPCHK(hipSetDevice(e->device));
     launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_cur_dev, nullptr, e->mask, e->iter_flags(), e->stop_ptr,
                        nullptr, e->stream);
-    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream);
+    launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
     HIPCHK(hipGetLastError());
     e->masks_valid = false;
     return NEMGPU_OK;

@@ -1185,11 +1185,19 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
 template <int R>
 __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, const uint64_t* __restrict__ xt,
                                                       const uint64_t* __restrict__ mask, int* __restrict__ stats,
-                                                      const int* __restrict__ stop)
+                                                      const int* __restrict__ stop, CtrlArgs prev_ctrl)
 {
     // R organism rows per block (row D = the all-ones row that counts the class sizes): each class-mask word is
     // loaded once for R rows, so the masks' L2 traffic (K * N/8 bytes per block) shrinks by R
     __shared__ int red[4][R][4];
+    // One block more than there are rows: the loop control of the iteration BEFORE this one (ctrl_logic), when its
+    // last sweep round left it to us -- there it costs a last-block ticket, two device-wide atomic round trips at the
+    // tail of the launch; here it runs beside the counting blocks.  They have read the stop word before it can be
+    // raised, so the counts of an iteration that will not happen are computed once for nothing.
+    if (prev_ctrl.ctrl != nullptr && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) ctrl_logic(prev_ctrl);
+        return;
+    }
     if (stop != nullptr && *stop) return;
     const int d0 = blockIdx.x * R;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1969,12 +1977,15 @@ void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab
 }
 
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
-                         const int* stop, hipStream_t s)
+                         const int* stop, const CtrlArgs* prev_ctrl, hipStream_t s)
 {
     // wide matrices: 4 organism rows per block (fewer re-reads of the class masks); narrow ones keep one row per
     // block so that the launch still spreads over the CUs
-    if (D + 1 >= 1024) hipLaunchKernelGGL(k_mstep_counts<4>, dim3((D + 1 + 3) / 4), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
-    else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop);
+    CtrlArgs ca{};
+    if (prev_ctrl != nullptr) ca = *prev_ctrl;
+    const int extra = ca.ctrl != nullptr ? 1 : 0;
+    if (D + 1 >= 1024) hipLaunchKernelGGL(k_mstep_counts<4>, dim3((D + 1 + 3) / 4 + extra), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop, ca);
+    else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1 + extra), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop, ca);
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k,
