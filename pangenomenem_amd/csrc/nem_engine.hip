@@ -524,7 +524,8 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
 }
 
 // the restart + the two initial sweeps as the head of a pipelined batch (buffers 0 -> 1 -> 2)
-int enqueue_init(nemgpu_engine* e)
+// defer_ctrl: an iteration follows in the same batch (see enqueue_iteration)
+int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
 {
     int r;
     // one launch: initial parameters back in place, loop control cleared, density tables built
@@ -550,7 +551,10 @@ int enqueue_init(nemgpu_engine* e)
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.is_init = 1;
     ca.blind = e->round_flags(kRoundCap - 1);
-    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? &ca : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    const bool defer = defer_ctrl && e->ncem() && !e->cfg.param_fix;
+    CtrlArgs none{};
+    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? (defer ? &none : &ca) : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (e->ncem()) e->masks_valid = true;
     else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }
     e->cur = 2;
@@ -587,7 +591,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             hipError_t herr = first ? hipSuccess                   // (the restart launch clears the loop control itself)
                                     : hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
             e->stop_ptr = e->ctrl() + C_STOP;
-            if (first && herr == hipSuccess) r = enqueue_init(e);
+            if (first && herr == hipSuccess) r = enqueue_init(e, g > 0);
             for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)
                 r = enqueue_iteration(e, (base + j) % 3, sweep0 + j, j + 1 < g);
             e->stop_ptr = nullptr;
