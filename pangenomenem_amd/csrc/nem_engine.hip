@@ -588,6 +588,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         if (exec == nullptr) {
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             r = NEMGPU_OK;
+            e->ctrl_pending = false;                               // (a batch never inherits a deferred loop control)
             hipError_t herr = first ? hipSuccess                   // (the restart launch clears the loop control itself)
                                     : hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
             e->stop_ptr = e->ctrl() + C_STOP;
