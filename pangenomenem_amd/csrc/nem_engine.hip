@@ -110,6 +110,7 @@ struct nemgpu_engine {
 
     // captured batches of the pipelined loop, keyed by (current buffer, iterations in the batch)
     hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
+    uint8_t graph_asked[2][3][8] = {};   // how often a batch shape was enqueued before it got a graph
     bool use_graphs = true;
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
     // auto: on from 256 organisms (below that the chain is mostly the small-binade prefix that is stepped anyway
@@ -583,8 +584,11 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
             if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
         }
-        const bool graphed = e->use_graphs && g < 8;
+        bool graphed = e->use_graphs && g < 8;
         hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
+        // the first batch of a shape goes out as plain launches: capturing and instantiating a graph costs more than
+        // it saves unless the batch is replayed, and a nem() call's engine enqueues most shapes once
+        if (graphed && exec == nullptr && e->graph_asked[first ? 1 : 0][base][g]++ == 0) graphed = false;
         if (exec == nullptr) {
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             r = NEMGPU_OK;

@@ -25,7 +25,7 @@ def main():
         eng = NemEngine(n, d, 3)
         eng.set_matrix_bits(bits); eng.set_graph(cfg["nei"]); eng.set_params(cfg["prop"], cfg["center"], cfg["disp"])
         eng.configure(algo="ncem", beta=0.5, disper="sk_", propor="pk")
-        eng.run()                                   # warm-up: buffers, graphs
+        eng.run(); eng.run()                        # warm-up: buffers; a batch shape gets its graph the second time it is enqueued
         rec = dict(config=name, families=n, organisms=d)
         t0 = time.perf_counter(); eng.set_matrix_bits(bits); t1 = time.perf_counter()
         eng.set_graph(cfg["nei"]); t2 = time.perf_counter()
