@@ -232,6 +232,10 @@ int nemio_sizes(const nemio_inputs* in, int* n, int* d, int* nnz, int* max_neigh
 int nemio_copy(const nemio_inputs* in, uint32_t* xbits, int32_t* nei_ptr, int32_t* nei_idx, float* nei_w,
                float* prop, float* center, float* disp);
 int nemio_write_uf(const char* path, const float* c_nk, int n, int k);
+/* Test hook: " %<width>.<dec>f" (dec <= 3) of a float exactly as printf prints it -- the formatter behind the
+   per-iteration <Fname>.log lines (WriteLogClasses' " %5.3f", " %7.3f", " %7.1f").  out: at least 64 bytes;
+   returns the length written, -1 on bad arguments. */
+int nemio_format_fixed(float v, int width, int dec, char* out);
 int nemio_write_cf(const char* path, const float* c_nk, int n, int k, int tie_rule, uint32_t seed);
 int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, int k, const float* center,
                    const float* prop, const float* disp);

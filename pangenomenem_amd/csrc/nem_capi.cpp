@@ -85,22 +85,51 @@ void log_header(FILE* fl, int k, int d)
     fprintf(fl, "\n");
 }
 
+// " %<width>.<dec>f" of a float, as printf prints it (dec <= 3).  A float times 10^dec is exact in a double (24 + 10
+// bits), so rint() -- to nearest, ties to even, printf's rule in the default rounding mode -- of that product is the
+// decimal rounding of the exact binary value; negative, -0.0, huge and non-finite values go to snprintf.
+static inline void put_fixed(std::string& out, float v, int width, int dec)
+{
+    static const double p10[4] = {1.0, 10.0, 100.0, 1000.0};
+    char buf[48];
+    if (v >= 0.0f && v < 1.0e9f && !std::signbit(v)) {
+        unsigned long long r = (unsigned long long)rint((double)v * p10[dec]);
+        char tmp[32];
+        int n = 0;
+        for (int i = 0; i < dec; i++) { tmp[n++] = (char)('0' + r % 10); r /= 10; }
+        if (dec > 0) tmp[n++] = '.';
+        do { tmp[n++] = (char)('0' + r % 10); r /= 10; } while (r != 0);
+        int m = 0;
+        buf[m++] = ' ';
+        for (int pad = width - n; pad > 0; pad--) buf[m++] = ' ';
+        while (n > 0) buf[m++] = tmp[--n];
+        out.append(buf, (size_t)m);
+    } else {
+        const int m = snprintf(buf, sizeof buf, " %*.*f", width, dec, (double)v);
+        out.append(buf, (size_t)m);
+    }
+}
+
 void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool sizes_known)
 {
     std::vector<float> prop(k), center((size_t)k * d), disp((size_t)k * d), nk(k);
     nemgpu_get_params(e, prop.data(), center.data(), disp.data(), nk.data());
-    fprintf(fl, " ");
-    fprintf(fl, " %5.3f", (double)beta);
-    fprintf(fl, " ");
-    for (int h = 0; h < k; h++) fprintf(fl, " %5.3f", (double)prop[h]);
-    fprintf(fl, " ");
-    for (size_t t = 0; t < (size_t)k * d; t++) fprintf(fl, " %7.3f", (double)center[t]);
-    fprintf(fl, " ");
-    for (size_t t = 0; t < (size_t)k * d; t++) fprintf(fl, " %7.3f", (double)disp[t]);
-    fprintf(fl, " ");
+    // WriteLogClasses' formats: " %5.3f" beta and proportions, " %7.3f" centres and dispersions, " %7.1f" NbObs_KD
+    std::string line;
+    line.reserve((size_t)k * d * 3 * 9 + 64);
+    line += " ";
+    put_fixed(line, beta, 5, 3);
+    line += " ";
+    for (int h = 0; h < k; h++) put_fixed(line, prop[h], 5, 3);
+    line += " ";
+    for (size_t t = 0; t < (size_t)k * d; t++) put_fixed(line, center[t], 7, 3);
+    line += " ";
+    for (size_t t = 0; t < (size_t)k * d; t++) put_fixed(line, disp[t], 7, 3);
+    line += " ";
     // NbObs_KD: zero until the first EstimPara (calloc, nem_exe.c:320), then N_K for every organism (no missing data)
-    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %7.1f", sizes_known ? (double)nk[h] : 0.0);
-    fprintf(fl, "\n");
+    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) put_fixed(line, sizes_known ? nk[h] : 0.0f, 7, 1);
+    line += "\n";
+    fwrite(line.data(), 1, line.size(), fl);
 }
 
 // The INIT_PARAM_FILE run with the reference's log: one EM iteration per engine call, two criteria evaluations
@@ -434,6 +463,17 @@ int nemio_copy(const nemio_inputs* h, uint32_t* xbits, int32_t* nei_ptr, int32_t
 }
 
 int nemio_write_uf(const char* path, const float* c, int n, int k) { return write_uf_file(path, c, n, k); }
+
+// test hook: the log writer's " %<width>.<dec>f" formatter; returns the length written (out: at least 64 bytes)
+int nemio_format_fixed(float v, int width, int dec, char* out)
+{
+    if (!out || dec < 0 || dec > 3 || width < 0 || width > 24) return -1;
+    std::string s;
+    put_fixed(s, v, width, dec);
+    memcpy(out, s.data(), s.size());
+    out[s.size()] = '\0';
+    return (int)s.size();
+}
 int nemio_write_cf(const char* path, const float* c, int n, int k, int tie_rule, uint32_t seed)
 {
     return write_cf_file(path, c, n, k, tie_rule, seed);

@@ -240,3 +240,27 @@ def test_uf_writer_fast_path_prints_like_printf(lib, tmp_path):
     assert engine.write_uf(path, vals) == 0
     want = "".join("".join(" %5.3f " % float(v) for v in row) + "\n" for row in vals)
     assert open(path).read() == want
+
+
+def test_log_formatter_prints_like_printf(lib):
+    """The per-iteration log lines are formatted without printf (" %5.3f", " %7.3f", " %7.1f"): same text as printf
+    for the exact binary value -- dyadic ties, neighbours of ties, class sizes up to 2^24 and beyond the field width,
+    and what goes to snprintf (negative, -0.0, huge, NaN, inf)."""
+    import ctypes as C
+    from pangenomenem_amd import build as nem_build
+    L = C.CDLL(nem_build.build())
+    L.nemio_format_fixed.restype = C.c_int
+    L.nemio_format_fixed.argtypes = [C.c_float, C.c_int, C.c_int, C.c_char_p]
+    rng = np.random.Generator(np.random.PCG64(3))
+    base = np.array([0.0, 0.5, 1.0, 0.0625, 0.1875, 0.0005, 0.0015, 0.9995, 0.99949998, 0.05, 0.25, 0.125, 1e-30, 7.5, 12.25,
+                     123.45, 99999.95, 999999.5, 16777216.0, 3.0e8, 9.9e8, 1.0e9, 5e12, -0.0, -1.5, np.nan, np.inf, -np.inf],
+                    np.float32)
+    vals = np.concatenate([base, np.nextafter(base[:12], np.float32(9)), np.nextafter(base[:12], np.float32(-9)),
+                           rng.random(2000).astype(np.float32), (rng.integers(0, 8193, 2000) / 8192.0).astype(np.float32),
+                           (rng.random(1000) * 20000).astype(np.float32), (rng.integers(0, 400001, 1000) / 20.0).astype(np.float32)])
+    out = C.create_string_buffer(64)
+    for width, dec in ((5, 3), (7, 3), (7, 1), (5, 0), (10, 2)):
+        for v in vals:
+            n = L.nemio_format_fixed(float(v), width, dec, out)
+            want = " %*.*f" % (width, dec, float(v))
+            assert n == len(want) and out.value.decode() == want, (width, dec, float(v), out.value, want)
