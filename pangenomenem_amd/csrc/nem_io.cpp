@@ -61,6 +61,14 @@ struct Tok {
     {
         ws();
         if (!*p) return false;
+        // up to 18 digits by hand (strtol's result for them), anything longer through strtol
+        const char* q = p;
+        const bool neg = (*q == '-');
+        if (*q == '-' || *q == '+') q++;
+        const char* d0 = q;
+        long acc = 0;
+        while (*q >= '0' && *q <= '9' && q - d0 < 18) acc = acc * 10 + (*q++ - '0');
+        if (q != d0 && !(*q >= '0' && *q <= '9')) { v = neg ? -acc : acc; p = q; return true; }
         char* end = nullptr;
         errno = 0;
         v = strtol(p, &end, 10);
@@ -68,11 +76,38 @@ struct Tok {
         p = end;
         return true;
     }
-    // fscanf("%f" / "%g")
+    // fscanf("%f" / "%g").  Plain decimals "[sign]digits[.digits]" with at most 15 significant and 8 fractional digits
+    // are converted by hand: digits / 10^k is one correctly rounded double operation on exact operands, and such a
+    // short decimal is either exactly a float midpoint (then the double holds it exactly and the cast rounds to even,
+    // like strtof) or at least 2^-24 / 10^8 > 2^-53 (relative) away from one, so the cast to float cannot land on the
+    // wrong side.  Exponents, hex, inf/nan, longer numbers: strtof.
     bool next_float(float& v)
     {
         ws();
         if (!*p) return false;
+        {
+            const char* q = p;
+            const bool neg = (*q == '-');
+            if (*q == '-' || *q == '+') q++;
+            unsigned long long digits = 0;
+            int nd = 0, nf = 0;
+            const char* d0 = q;
+            while (*q >= '0' && *q <= '9' && nd < 15) { digits = digits * 10 + (unsigned)(*q++ - '0'); nd++; }
+            bool ok = !(*q >= '0' && *q <= '9');
+            if (ok && *q == '.') {
+                q++;
+                while (*q >= '0' && *q <= '9' && nd < 15 && nf < 8) { digits = digits * 10 + (unsigned)(*q++ - '0'); nd++; nf++; }
+                ok = !(*q >= '0' && *q <= '9');
+            }
+            const bool any = (q - d0) > (nf > 0 || (q > d0 && q[-1] == '.') ? 1 : 0) || nd > 0;
+            if (ok && any && nd > 0 && *q != 'e' && *q != 'E' && *q != 'x' && *q != 'X' && *q != 'p' && *q != 'P') {
+                static const double p10[9] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8};
+                const double dv = (double)digits / p10[nf];
+                v = (float)(neg ? -dv : dv);
+                p = q;
+                return true;
+            }
+        }
         char* end = nullptr;
         v = strtof(p, &end);
         if (end == p) return false;
@@ -236,8 +271,12 @@ int read_nei_file(const std::string& base, NemInputs& in, std::string& err)
     long weighted = 0;
     tk.next_int(weighted);
     const int n = in.n;
-    std::vector<std::vector<int32_t>> idx(n);
-    std::vector<std::vector<float>> wts(n);
+    // every record's lists go behind each other into two flat arrays; where[i] / nb[i] = the LAST record of point i
+    std::vector<int32_t> flat_idx;
+    std::vector<float> flat_w;
+    flat_idx.reserve(buf.size() / 4);
+    flat_w.reserve(buf.size() / 4);
+    std::vector<long long> where((size_t)n, -1);
     std::vector<int> nb(n, 0);
     int nmax = 0;
     int line = 0;
@@ -246,8 +285,11 @@ int read_nei_file(const std::string& base, NemInputs& in, std::string& err)
         if (!tk.next_int(ipt)) { err = "Error in neighb. file : unreadable point index"; return NEMGPU_E_FILE; }
         if (!tk.next_int(nbv)) break;
         if (ipt < 1 || ipt > n || nbv < 0) { err = "Error in neighb. file : point index out of range"; return NEMGPU_E_FILE; }
-        std::vector<int32_t> iv((size_t)nbv, 0);      // calloc'ed NeighT[nbv] (genmemo.c:30)
-        std::vector<float> wv((size_t)nbv, 0.0f);
+        const size_t at = flat_idx.size();
+        flat_idx.resize(at + (size_t)nbv, 0);           // calloc'ed NeighT[nbv] (genmemo.c:30)
+        flat_w.resize(at + (size_t)nbv, 0.0f);
+        int32_t* iv = flat_idx.data() + at;
+        float* wv = flat_w.data() + at;
         int nv = 0;
         for (long t = 0; t < nbv && !tk.eof(); t++) {
             long j = 0;
@@ -270,8 +312,8 @@ int read_nei_file(const std::string& base, NemInputs& in, std::string& err)
         } else {
             for (int t = 0; t < nv; t++) wv[t] = 1.0f;
         }
-        iv.resize(nv); wv.resize(nv);
-        idx[ipt - 1].swap(iv); wts[ipt - 1].swap(wv); nb[ipt - 1] = nv;
+        flat_idx.resize(at + (size_t)nv); flat_w.resize(at + (size_t)nv);
+        where[(size_t)ipt - 1] = (long long)at; nb[ipt - 1] = nv;
         if (nv > nmax) nmax = nv;
         line++;
     }
@@ -281,8 +323,9 @@ int read_nei_file(const std::string& base, NemInputs& in, std::string& err)
     in.nei_idx.resize(in.nei_ptr[n]);
     in.nei_w.resize(in.nei_ptr[n]);
     for (int i = 0; i < n; i++) {
-        std::copy(idx[i].begin(), idx[i].end(), in.nei_idx.begin() + in.nei_ptr[i]);
-        std::copy(wts[i].begin(), wts[i].end(), in.nei_w.begin() + in.nei_ptr[i]);
+        if (nb[i] == 0) continue;
+        std::copy(flat_idx.begin() + where[i], flat_idx.begin() + where[i] + nb[i], in.nei_idx.begin() + in.nei_ptr[i]);
+        std::copy(flat_w.begin() + where[i], flat_w.begin() + where[i] + nb[i], in.nei_w.begin() + in.nei_ptr[i]);
     }
     return NEMGPU_OK;
 }

@@ -264,3 +264,41 @@ def test_log_formatter_prints_like_printf(lib):
             n = L.nemio_format_fixed(float(v), width, dec, out)
             want = " %*.*f" % (width, dec, float(v))
             assert n == len(want) and out.value.decode() == want, (width, dec, float(v), out.value, want)
+
+
+def test_tokeniser_numbers_equal_strtof_and_strtol(lib, tmp_path):
+    """The readers convert short plain decimals and integers by hand; every weight of a .nei written in all sorts of
+    spellings must come out as libc's strtof gives it (the reference reads them with fscanf("%f"))."""
+    import ctypes as C
+    from pangenomenem_amd import engine
+    libc = C.CDLL("libc.so.6")
+    libc.strtof.restype = C.c_float
+    libc.strtof.argtypes = [C.c_char_p, C.c_void_p]
+    rng = np.random.Generator(np.random.PCG64(21))
+    words = ["1", "8", "0.5", "1.5", "2.25", ".75", "3.", "+4", "0.1", "0.3333333", "16777217", "33554433", "0.00000001",
+             "123456.78901234", "99999999.9999999", "1e0", "2.5e-1", "1E2", "0x10", "7.00000000000000001", "000012.5",
+             "4294967297", "0.1234567890123456789", "5e-46", "1.17549435e-38", "3.4028235e38", "16777216.5", "8388608.5",
+             "0.50000003", "1.00000006", "2.00000012", "9007199254740993"]
+    for _ in range(3000):
+        nd = int(rng.integers(1, 16)); nf = int(rng.integers(0, min(nd, 9) + 1))
+        digs = "".join(rng.choice(list("0123456789"), nd))
+        w = digs[: nd - nf] + ("." + digs[nd - nf:] if nf else "")
+        if w.startswith("."): w = rng.choice(["", "0"]) + w
+        words.append(str(w))
+    for _ in range(1500):                                       # floats near ties: a float midpoint written in decimal
+        f = np.float32(rng.uniform(0.01, 2000.0))
+        mid = (float(f) + float(np.nextafter(f, np.float32(1e9)))) / 2
+        words.append(("%.8f" % mid).rstrip("0"))
+    words = [w for w in words if libc.strtof(w.encode(), None) != 0.0]   # (zero weights are dropped by the reader)
+    n = len(words)
+    base = str(tmp_path / "w")
+    open(base + ".str", "w").write("S\t%d\t1\n" % n)
+    open(base + ".dat", "w").write("\n".join("1" for _ in range(n)) + "\n")
+    open(base + ".m", "w").write("1 0.3 0.3 1 0.5 0 0.1 0.1 0.1")
+    open(base + ".nei", "w").write("1\n" + "".join("%d 1 %d %s\n" % (i + 1, (i + 1) % n + 1, w) for i, w in enumerate(words)))
+    got = engine.read_inputs(base, 3)
+    ptr, idx, wts = got["nei"]
+    assert list(ptr) == list(range(n + 1)) and list(idx) == [(i + 1) % n for i in range(n)]
+    want = np.array([libc.strtof(w.encode(), None) for w in words], np.float32)
+    bad = [(w, a, b) for w, a, b in zip(words, wts, want) if np.float32(a).tobytes() != np.float32(b).tobytes()]
+    assert not bad, bad[:5]
