@@ -4,6 +4,7 @@
 // writes (ppanggolin/ppanggolin.py:821-930) and return the same StatusET codes; writers emit
 // byte-identical text for identical values (same printf formats as SaveResults,
 // /root/reference/ppanggolin/NEM/nem_exe.c:1596-1781).
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -414,13 +415,15 @@ int write_uf_file(const std::string& path, const float* c, int n, int k)
 {
     FILE* fp = fopen(path.c_str(), "w");
     if (!fp) return NEMGPU_E_FILEOUT;
-    std::vector<char> buf((size_t)64 * k + 2);
+    const size_t row_max = (size_t)64 * k + 2;
+    std::vector<char> buf(std::max(row_max, (size_t)1 << 20));
+    char* o = buf.data();
     for (int i = 0; i < n; i++) {
-        char* o = buf.data();
+        if ((size_t)(buf.data() + buf.size() - o) < row_max) { fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp); o = buf.data(); }
         for (int kk = 0; kk < k; kk++) o = put_membership(o, c[(size_t)i * k + kk]);
         *o++ = '\n';
-        fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp);
     }
+    fwrite(buf.data(), 1, (size_t)(o - buf.data()), fp);
     fclose(fp);
     return NEMGPU_OK;
 }
@@ -460,10 +463,24 @@ int write_mf_file(const std::string& path, const float crit[6], float beta, int 
     fprintf(fp, "Beta (%s)\n", "fixed");
     fprintf(fp, "  %6.4f\n", beta);
     fprintf(fp, "Mu (%d), Pk, and disp (%d) of the %d classes\n\n", d, d, k);
+    // (a value equal to the one before it -- centres are 0, 0.5 or 1, a class's dispersions are often all the same --
+    //  reuses that one's text instead of going through printf again)
+    char txt[64];
+    int len = 0;
+    uint32_t last = 0;
+    bool have = false;
+    auto put = [&](const char* fmt, float v) {
+        uint32_t bits;
+        memcpy(&bits, &v, 4);
+        if (!have || bits != last) { len = snprintf(txt, sizeof txt, fmt, v); last = bits; have = true; }
+        fwrite(txt, 1, (size_t)len, fp);
+    };
     for (int kk = 0; kk < k; kk++) {
-        for (int j = 0; j < d; j++) fprintf(fp, " %10.3g ", center[(size_t)kk * d + j]);
+        have = false;
+        for (int j = 0; j < d; j++) put(" %10.3g ", center[(size_t)kk * d + j]);
         fprintf(fp, "  %5.3g  ", prop[kk]);
-        for (int j = 0; j < d; j++) fprintf(fp, " %10g ", disp[(size_t)kk * d + j]);
+        have = false;
+        for (int j = 0; j < d; j++) put(" %10g ", disp[(size_t)kk * d + j]);
         fputc('\n', fp);
     }
     fclose(fp);
