@@ -134,6 +134,7 @@ struct nemgpu_engine {
     std::vector<Chunk> chunks;
     int shared_chunk = -1;                     // the chunk small buffers are carved from
     uint8_t* best_lab = nullptr; float* best_c = nullptr;   // nemgpu_run_random: the best start's partition
+    uint32_t* xf_stage = nullptr;                            // nemgpu_set_matrix_bits: upload staging (small matrices)
     bool ctrl_pending = false; CtrlArgs ctrl_deferred{};     // loop control left to the next iteration's counts launch
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
@@ -932,13 +933,27 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
             for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
             pc[i] = c;
         }
+        // stable counting sort of every 256-family tile by popcount (0 .. d)
+        std::vector<int> slot((size_t)e->d + 2);
         for (int t0 = 0; t0 < e->n; t0 += 256) {
             const int t1 = std::min(t0 + 256, e->n);
-            std::stable_sort(perm.begin() + t0, perm.begin() + t1, [&](int a, int b) { return pc[a] < pc[b]; });
+            int lo = e->d, hi = 0;
+            for (int i = t0; i < t1; i++) { lo = std::min(lo, pc[i]); hi = std::max(hi, pc[i]); }
+            std::fill(slot.begin() + lo, slot.begin() + hi + 2, 0);
+            for (int i = t0; i < t1; i++) slot[pc[i] + 1]++;
+            for (int c = lo + 1; c <= hi; c++) slot[c + 1] += slot[c];       // slot[c] = first position of popcount c
+            for (int i = t0; i < t1; i++) perm[(size_t)t0 + slot[pc[i]]++] = i;
         }
     }
     e->host_bits.assign(xbits_host, xbits_host + words);
-    HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
+    // staging copy of the family-major bit rows: small ones live in the engine's chunk, large ones come and go
+    const bool staged_in_chunk = words * sizeof(uint32_t) < kChunkOwn;
+    if (staged_in_chunk) {
+        if (!e->xf_stage) { alloc_for(e); int r = dev_alloc(&e->xf_stage, words); if (r) return r; }
+        xf = e->xf_stage;
+    } else {
+        HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
+    }
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
         err = hipMemcpyAsync(e->perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
@@ -947,7 +962,7 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    (void)hipFree(xf);
+    if (!staged_in_chunk) (void)hipFree(xf);
     if (err != hipSuccess) { set_error(std::string("matrix upload failed: ") + hipGetErrorString(err)); return NEMGPU_E_DEVICE; }
     e->have_matrix = true;
     return NEMGPU_OK;
