@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "nem_internal.hpp"
@@ -972,20 +973,36 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
 {
     if (!e || !x_host) return NEMGPU_E_FUNCARG;
     std::vector<uint32_t> bits((size_t)e->n * e->wf, 0u);
-    uint64_t bad = 0;
-    for (int i = 0; i < e->n; i++) {
-        const uint8_t* row = x_host + (size_t)i * e->d;
-        uint32_t* out = bits.data() + (size_t)i * e->wf;
-        int j = 0;
-        for (; j + 8 <= e->d; j += 8) {                            // 8 values per load: bit 0 of each byte -> one byte
-            uint64_t w;
-            memcpy(&w, row + j, 8);
-            bad |= w;
-            const uint32_t b8 = (uint32_t)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-            out[j >> 5] |= b8 << (j & 31);                         // j % 8 == 0: the byte never straddles a word
+    auto pack_rows = [&](int r0, int r1, uint64_t* bad_out) {
+        uint64_t bad = 0;
+        for (int i = r0; i < r1; i++) {
+            const uint8_t* row = x_host + (size_t)i * e->d;
+            uint32_t* out = bits.data() + (size_t)i * e->wf;
+            int j = 0;
+            for (; j + 8 <= e->d; j += 8) {                        // 8 values per load: bit 0 of each byte -> one byte
+                uint64_t w;
+                memcpy(&w, row + j, 8);
+                bad |= w;
+                const uint32_t b8 = (uint32_t)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+                out[j >> 5] |= b8 << (j & 31);                     // j % 8 == 0: the byte never straddles a word
+            }
+            for (; j < e->d; j++) { bad |= row[j]; out[j >> 5] |= (uint32_t)(row[j] & 1u) << (j & 31); }
         }
-        for (; j < e->d; j++) { bad |= row[j]; out[j >> 5] |= (uint32_t)(row[j] & 1u) << (j & 31); }
+        *bad_out = bad;
+    };
+    // rows are independent: matrices of 4 MB and more are packed by up to 4 threads
+    const size_t bytes = (size_t)e->n * e->d;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::max(1u, std::min({4u, hw ? hw : 1u, (unsigned)(bytes >> 21)}));
+    uint64_t badv[4] = {0, 0, 0, 0};
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++)
+            th.emplace_back(pack_rows, (int)((long long)e->n * t / nt), (int)((long long)e->n * (t + 1) / nt), &badv[t]);
+        pack_rows(0, (int)((long long)e->n / nt), &badv[0]);
+        for (std::thread& x : th) x.join();
     }
+    const uint64_t bad = badv[0] | badv[1] | badv[2] | badv[3];
     if (bad & 0xFEFEFEFEFEFEFEFEull) { set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
     return nemgpu_set_matrix_bits(e, bits.data());
 }
@@ -1006,11 +1023,13 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     if ((r = dev_alloc(&e->nei_ptr, (size_t)e->n + 1))) return r;
     if ((r = dev_alloc(&e->nei_idx, (size_t)nnz))) return r;
     if ((r = dev_alloc(&e->nei_w, (size_t)nnz))) return r;
-    HIPCHK(copy_sync(e, e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice));
+    // three copies, one wait (the sources are the caller's: done before returning)
+    HIPCHK(hipMemcpyAsync(e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice, e->stream));
     if (nnz > 0) {
-        HIPCHK(copy_sync(e, e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-        HIPCHK(copy_sync(e, e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, e->stream));
     }
+    HIPCHK(hipStreamSynchronize(e->stream));
     e->nnz = nnz;
     e->has_graph = nnz > 0;
     drop_graphs(e);
