@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -150,7 +151,8 @@ int read_str_file(const std::string& base, NemInputs& in, std::string& err)
 // One row of the text ppanggolin.py:850 writes -- one character per value, one tab between values, a newline at
 // the end ("0\t1\t...\t1\n", 2*d bytes): 4 values per 8-byte load, validated and packed with integer arithmetic.
 // Returns how many values (a multiple of 4, or d) were taken.
-static inline int pack_regular_row(const char* p, int d, uint32_t* row)
+// `at`: index of the first value of p within the row (a multiple of 4), for rows whose head was packed elsewhere.
+static inline int pack_regular_row(const char* p, int d, uint32_t* row, int at = 0)
 {
     int j = 0;
     for (; j + 4 <= d; j += 4) {
@@ -160,9 +162,33 @@ static inline int pack_regular_row(const char* p, int d, uint32_t* row)
         const uint64_t seps = last ? 0x0A00090009000900ull : 0x0900090009000900ull;
         if ((w & 0xFFFEFFFEFFFEFFFEull) != (0x0030003000300030ull | seps)) break;
         const uint32_t nib = (uint32_t)(((w & 0x0001000100010001ull) * 0x0001000200040008ull) >> 48) & 0xFu;
-        row[j >> 5] |= nib << (j & 31);                 // j % 4 == 0: the nibble never straddles a word
+        row[(at + j) >> 5] |= nib << ((at + j) & 31);   // (at + j) % 4 == 0: the nibble never straddles a word
     }
     return j;
+}
+
+// The same row with 32-byte loads where the CPU has AVX2 + BMI2: 16 values per load -- the value bytes' low bits
+// moved to the sign positions, one movemask, the even bits squeezed together -- for all but the last 1..16 values
+// of the row (whose final separator is the newline); those are left to pack_regular_row.  Returns the number of
+// values taken (a multiple of 16), or -1 when the text is not of the regular form.
+__attribute__((target("avx2,bmi2"))) static int pack_regular_row_avx2(const char* p, int d, uint32_t* row)
+{
+    const __m256i keep = _mm256_set1_epi16((short)0xFFFE);          // value byte without its low bit, separator whole
+    const __m256i want = _mm256_set1_epi16((short)0x0930);          // '0' | '1' then a tab
+    int j = 0;
+    for (; j + 16 < d; j += 16) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 2 * (size_t)j));
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(v, keep), want)) != -1) return -1;
+        const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 7));   // bit 2i = value i
+        row[j >> 5] |= _pext_u32(m, 0x55555555u) << (j & 31);       // j % 16 == 0: never straddles a word
+    }
+    return j;
+}
+
+static bool cpu_has_avx2_bmi2()
+{
+    static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+    return yes;
 }
 
 // A file of exactly n rows of 2*d bytes (d a multiple of 4) is, if every row has the regular form, n rows at known
@@ -179,6 +205,7 @@ static bool read_dat_regular(const std::string& path, int n, int d, int wf, uint
     unsigned hw = std::thread::hardware_concurrency();
     const int nt = (int)std::max(1u, std::min({4u, hw ? hw : 1u, (unsigned)(((size_t)st.st_size >> 21) + 1)}));   // 2 MB and more per thread
     std::vector<char> ok((size_t)nt, 1);
+    const bool wide = cpu_has_avx2_bmi2();
     auto work = [&](int t) {
         const int r0 = (int)((long long)n * t / nt), r1 = (int)((long long)n * (t + 1) / nt);
         const int rows_per = (int)std::max<size_t>(1, ((size_t)256 << 10) / rowb);              // ~256 KB per pread
@@ -192,8 +219,13 @@ static bool read_dat_regular(const std::string& path, int n, int d, int wf, uint
                 if (g <= 0) { ok[(size_t)t] = 0; return; }
                 got += (size_t)g;
             }
-            for (int i = 0; i < nr; i++)
-                if (pack_regular_row(buf.data() + (size_t)i * rowb, d, xbits + (size_t)(r + i) * wf) != d) { ok[(size_t)t] = 0; return; }
+            for (int i = 0; i < nr; i++) {
+                const char* text = buf.data() + (size_t)i * rowb;
+                uint32_t* row = xbits + (size_t)(r + i) * wf;
+                int j0 = 0;
+                if (wide) { j0 = pack_regular_row_avx2(text, d, row); if (j0 < 0) { ok[(size_t)t] = 0; return; } }
+                if (j0 + pack_regular_row(text + 2 * (size_t)j0, d - j0, row, j0) != d) { ok[(size_t)t] = 0; return; }
+            }
         }
     };
     std::vector<std::thread> th;

@@ -205,6 +205,23 @@ def test_dat_reader_regular_file_in_parallel(lib, tmp_path):
         engine.read_inputs(base, 3)
 
 
+@pytest.mark.parametrize("d", [4, 8, 12, 16, 20, 28, 32, 36, 48, 52, 64, 68, 100, 128, 132, 256, 260])
+def test_dat_reader_regular_rows_of_every_length(lib, tmp_path, d):
+    """The regular-file reader takes 16 values per 32-byte load where the CPU allows and finishes each row 4 at a
+    time: every split of a row between the two must give the bits numpy gives."""
+    from pangenomenem_amd import engine
+    rng = np.random.default_rng(100 + d)
+    n = 37
+    base = str(tmp_path / "r")
+    x = (rng.random((n, d)) < 0.5).astype(np.uint8)
+    x[0] = 1; x[1] = 0
+    open(base + ".str", "w").write("S\t%d\t%d\n" % (n, d))
+    open(base + ".nei", "w").write("1\n" + "".join("%d\t0\n" % (i + 1) for i in range(n)))
+    open(base + ".m", "w").write("1 0.3 0.3 " + " ".join(["1"] * d + ["0.5"] * d + ["0"] * d) + " " + " ".join(["0.1"] * (3 * d)))
+    open(base + ".dat", "wb").write(b"".join(b"\t".join(b"1" if v else b"0" for v in r) + b"\n" for r in x))
+    assert np.array_equal(engine.read_inputs(base, 3)["x"], x)
+
+
 def test_restated_generator_is_glibc_random(lib):
     """csrc/nem_rng.hpp restates the generator behind the reference's random starts: libc random() after srandom(seed)
     (nem_exe.c:621, nem_rnd.c:40-63).  Checked against this host's libc draw for draw."""
