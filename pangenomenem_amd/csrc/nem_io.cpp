@@ -101,8 +101,8 @@ struct Tok {
                 while (*q >= '0' && *q <= '9' && nd < 15 && nf < 8) { digits = digits * 10 + (unsigned)(*q++ - '0'); nd++; nf++; }
                 ok = !(*q >= '0' && *q <= '9');
             }
-            const bool any = (q - d0) > (nf > 0 || (q > d0 && q[-1] == '.') ? 1 : 0) || nd > 0;
-            if (ok && any && nd > 0 && *q != 'e' && *q != 'E' && *q != 'x' && *q != 'X' && *q != 'p' && *q != 'P') {
+            (void)d0;
+            if (ok && nd > 0 && *q != 'e' && *q != 'E' && *q != 'x' && *q != 'X' && *q != 'p' && *q != 'P') {
                 static const double p10[9] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8};
                 const double dv = (double)digits / p10[nf];
                 v = (float)(neg ? -dv : dv);
