@@ -407,7 +407,7 @@ int do_mstep(nemgpu_engine* e, const CtrlArgs* prev_ctrl = nullptr)
         launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, prev_ctrl, e->stream);
         launch_finish(finish_args(e, 1, e->stats), e->stream);
     } else {
-        launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
+        launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
                            e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream);
         launch_finish(finish_args(e, 2, nullptr), e->stream);
     }

@@ -1528,9 +1528,59 @@ __device__ __forceinline__ FuzzyWalk fuzzy_walk(int n, int npad, int K, int D, i
     return w;
 }
 
+// The sums that take c_ik from the families where the lane's organism has a given bit -- the inertia candidates, the
+// median's prefix sum -- read that bit from the lane's OWN row of bits (`xt`, organism-major: one 64-bit word per 64
+// families) and the 64 memberships from LDS, four per broadcast read: a step is a sign-extended bit, an AND and an
+// add (the addend is c_ik or +0, and adding +0 leaves a sum that is >= +0 as it is), three instructions instead of
+// three readlanes, an add and a select.
+struct OwnWalk {
+    const float* c; const uint64_t* row; int n, K, k, nw64, lane; float* sC;
+    // group(i0, cnt, own): sC[0..cnt) holds the memberships of families i0 .. i0 + cnt - 1, bit j of `own` is the
+    // lane's organism's bit for family i0 + j
+    template <typename G> __device__ __forceinline__ void groups(G&& group)
+    {
+        // (two groups ahead: the bit words of a wave's 64 organisms are 64 different cache lines)
+        float cn = c[(size_t)min(lane, n - 1) * K + k], cn2 = c[(size_t)min(64 + lane, n - 1) * K + k];
+        uint64_t on = row[0], on2 = row[min(1, nw64 - 1)];
+        int g = 0;
+        for (int i0 = 0; i0 < n; i0 += 64, g++) {
+            const float cv = cn;
+            const uint64_t own = on;
+            cn = cn2; on = on2;
+            if (i0 + 128 < n) { cn2 = c[(size_t)min(i0 + 128 + lane, n - 1) * K + k]; on2 = row[g + 2]; }
+            __syncthreads();                             // (one wave per block: the previous group's reads are done)
+            sC[lane] = cv;
+            __syncthreads();
+            group(i0, min(64, n - i0), own);
+        }
+    }
+    // acc += c for the families whose bit in `sel` is set, in family order
+    __device__ __forceinline__ void masked_add(float& acc, int cnt, uint64_t sel) const
+    {
+        const uint32_t lo = (uint32_t)sel, hi = (uint32_t)(sel >> 32);
+        if (cnt == 64) {
+            const float4* s4 = reinterpret_cast<const float4*>(sC);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float4 v = s4[q];
+                const uint32_t w = q < 8 ? lo : hi;
+                const int b = (4 * q) & 31;
+                acc += __int_as_float(__float_as_int(v.x) & __builtin_amdgcn_sbfe((int)w, b, 1));
+                acc += __int_as_float(__float_as_int(v.y) & __builtin_amdgcn_sbfe((int)w, b + 1, 1));
+                acc += __int_as_float(__float_as_int(v.z) & __builtin_amdgcn_sbfe((int)w, b + 2, 1));
+                acc += __int_as_float(__float_as_int(v.w) & __builtin_amdgcn_sbfe((int)w, b + 3, 1));
+            }
+        } else {
+            for (int j = 0; j < cnt; j++)
+                acc += ((sel >> j) & 1ull) ? sC[j] : 0.0f;
+        }
+    }
+};
+
 // roles along blockIdx.x: [0,DB) in0, [DB,2DB) in1, [2DB,3DB) last zero of weight >= EPSILON,
 // [3DB,4DB) "some one has weight >= EPSILON", 4DB: N_k, 4DB+1: inertia for mu = 0.5
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+                                                      const uint64_t* __restrict__ xt, int nw64,
                                                       const float* __restrict__ c, float* __restrict__ nbobs_k,
                                                       float* __restrict__ in0_out, float* __restrict__ in1_out,
                                                       float* __restrict__ inh_k, int* __restrict__ lastz_out,
@@ -1542,10 +1592,11 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, in
     const int bx = role < 4 ? blockIdx.x - role * DB : 0;
     const int k = blockIdx.y;
     const int d = bx * 64 + threadIdx.x;
-    FuzzyWalk w = fuzzy_walk(n, npad, K, D, k, bx, xw, c);
-    if (role == 4) {
+    __shared__ float sC[64];
+    OwnWalk ow{c, xt + (size_t)min(d, D - 1) * nw64, n, K, k, nw64, (int)threadIdx.x, sC};
+    if (role == 4) {                                                     // N_k (nem_mod.c:1308): every membership
         float nk = 0.0f;
-        w.run([&](float cv, uint32_t, uint32_t, int j) { nk += lane_f32(cv, j); });          // nem_mod.c:1308
+        ow.groups([&](int, int cnt, uint64_t) { ow.masked_add(nk, cnt, ~0ull); });
         if (threadIdx.x == 0) nbobs_k[k] = nk;
         return;
     }
@@ -1554,52 +1605,50 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, in
         // (always, but for an odd subnormal) that is the float sum inh + c/2; groups holding such a c take the
         // double form.
         float inh = 0.0f;
-        w.groups([&](float cv, uint32_t, uint32_t, int cnt) {
+        ow.groups([&](int, int cnt, uint64_t) {
+            const float cv = sC[threadIdx.x];
             const float hv = cv * 0.5f;
-            if (__ballot(hv * 2.0f != cv) == 0) FuzzyWalk::lanes(cnt, [&](int j) { inh += lane_f32(hv, j); });
-            else FuzzyWalk::lanes(cnt, [&](int j) { inh = (float)((double)inh + (double)lane_f32(cv, j) * 0.5); });
+            const bool halves = __ballot(threadIdx.x < (unsigned)cnt && hv * 2.0f != cv) == 0;
+            __syncthreads();
+            if (halves) {
+                sC[threadIdx.x] = hv;
+                __syncthreads();
+                ow.masked_add(inh, cnt, ~0ull);
+            } else {
+                for (int j = 0; j < cnt; j++) inh = (float)((double)inh + (double)sC[j] * 0.5);
+            }
         });
         if (threadIdx.x == 0) inh_k[k] = inh;
         return;
     }
-    if (role == 2) {
-        // what ComputeMedian's tie rule looks for after the crossing (nem_mod.c:1470-1483): the index of the last
-        // zero whose weight is >= EPSILON (pass B compares it with where its chain crossed)
-        int last = -1, i0 = 0;
-        w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
-            const bool big = !((double)cv < kEpsilonD);                  // lane j = family i0 + j here
-            const uint32_t zl = big ? ~xl : 0u, zh = big ? ~xh : 0u;
-            int lj = -1;
-            FuzzyWalk::lanes(cnt, [&](int j) { lj = __builtin_amdgcn_inverse_ballot_w64(lane_mask(zl, zh, j)) ? j : lj; });
-            last = lj >= 0 ? i0 + lj : last;
-            i0 += 64;
+    if (role == 2 || role == 3) {
+        // The two facts ComputeMedian's tie rule needs (nem_mod.c:1470-1483) do not depend on the order of the
+        // families: the index of the last zero whose weight is >= EPSILON (pass B compares it with where its chain
+        // crossed) and whether some one has such a weight -- a ballot of the weights per 64 families against the
+        // lane's own word of bits.
+        int last = -1;
+        bool some = false;
+        ow.groups([&](int i0, int cnt, uint64_t own) {
+            const float cv = sC[threadIdx.x];
+            uint64_t big = __ballot(threadIdx.x < (unsigned)cnt && !((double)cv < kEpsilonD));
+            const uint64_t z = ~own & big, o = own & big;
+            if (z != 0) last = i0 + 63 - __clzll((long long)z);
+            some |= (o != 0);
         });
-        if (d < D) lastz_out[k * D + d] = last;
+        if (d < D) {
+            if (role == 2) lastz_out[k * D + d] = last;
+            else any1_out[k * D + d] = some ? 1 : 0;
+        }
         return;
     }
-    if (role == 3) {
-        uint64_t any1 = 0;
-        w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
-            const bool big = !((double)cv < kEpsilonD);
-            const uint32_t ol = big ? xl : 0u, oh = big ? xh : 0u;
-            FuzzyWalk::lanes(cnt, [&](int j) { any1 |= lane_mask(ol, oh, j); });
-        });
-        if (d < D) any1_out[k * D + d] = __builtin_amdgcn_inverse_ballot_w64(any1) ? 1 : 0;
-        return;
-    }
-    const uint32_t flip = role == 1 ? ~0u : 0u;                          // role 1 sums over the zeros
+    const uint64_t flip = role == 1 ? ~0ull : 0ull;                      // role 1 sums over the zeros
     float acc = 0.0f;
-    w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
-        const uint32_t ml = xl ^ flip, mh = xh ^ flip;
-        FuzzyWalk::lanes(cnt, [&](int j) {
-            const float nx = acc + lane_f32(cv, j);                      // nem_mod.c:1683 with |x - mu| = 1
-            acc = __builtin_amdgcn_inverse_ballot_w64(lane_mask(ml, mh, j)) ? nx : acc;
-        });
-    });
+    ow.groups([&](int, int cnt, uint64_t own) { ow.masked_add(acc, cnt, own ^ flip); });   // nem_mod.c:1683, |x - mu| = 1
     if (d < D) (role == 0 ? in0_out : in1_out)[k * D + d] = acc;
 }
 
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+                                                      const uint64_t* __restrict__ xt, int nw64,
                                                       const float* __restrict__ c, const float* __restrict__ nbobs_k,
                                                       const float* __restrict__ in0, const float* __restrict__ in1,
                                                       const float* __restrict__ inh_k, const int* __restrict__ lastz,
@@ -1636,16 +1685,17 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
     // on the family's lane mask) over 64 families, tests the crossing once per group, and only a group in which
     // some lane crossed is walked again, from the saved start, to find that lane's family and value.
     float run = 0.0f, cum = 0.0f;
-    int istar = n, i0 = 0;                               // family at which the chain crossed
+    int istar = n;                                       // family at which the chain crossed
     uint64_t crossed = 0;
-    w.groups([&](float cv, uint32_t xl, uint32_t xh, int cnt) {
+    __shared__ float sC[64];
+    OwnWalk ow{c, xt + (size_t)min(d, D - 1) * nw64, n, K, k, nw64, (int)threadIdx.x, sC};
+    ow.groups([&](int i0, int cnt, uint64_t own) {
         const float start = run;
-        FuzzyWalk::lanes(cnt, [&](int j) {
-            const float nx = run + lane_f32(cv, j);
-            run = __builtin_amdgcn_inverse_ballot_w64(lane_mask(xl, xh, j)) ? run : nx;
-        });
+        ow.masked_add(run, cnt, ~own);                   // the zeros' memberships, in family order
         const uint64_t newly = __ballot(!(run < half)) & ~crossed;
         if (newly != 0) {
+            float cv; uint32_t xl, xh;                   // this group again, family by family (lane j = family i0 + j)
+            w.load(i0, cv, xl, xh);
             float r2 = start;
             int cj = -1;
             uint64_t seen = ~newly;
@@ -1661,7 +1711,6 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
             istar = cj >= 0 ? i0 + cj : istar;
             crossed |= newly;
         }
-        i0 += 64;
     });
     const bool ph0 = __builtin_amdgcn_inverse_ballot_w64(crossed);
     const bool gt0 = (double)cum > half_eps;             // cum is the value at the crossing
@@ -1988,15 +2037,15 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
     else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1 + extra), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop, ca);
 }
 
-void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k,
-                        float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center, float* iner,
-                        const int* stop, hipStream_t s)
+void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
+                        float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
+                        float* iner, const int* stop, hipStream_t s)
 {
     const int DB = (D + 63) / 64;
-    hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, n, npad, K, D, xw, c, nbobs_k, in0, in1, inh_k,
-                       lastz, any1, stop);
-    hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, n, npad, K, D, xw, c, nbobs_k, in0, in1, inh_k, lastz,
-                       any1, center, iner, stop);
+    hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1,
+                       inh_k, lastz, any1, stop);
+    hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k,
+                       lastz, any1, center, iner, stop);
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,

@@ -103,9 +103,9 @@ void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab
                         uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s);
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
                          const int* stop, const CtrlArgs* prev_ctrl, hipStream_t s);
-void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const float* c, float* nbobs_k,
-                        float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center, float* iner,
-                        const int* stop, hipStream_t s);
+void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
+                        float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
+                        float* iner, const int* stop, hipStream_t s);
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
                        const CtrlArgs* ctrl, hipStream_t s);
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s);
