@@ -43,18 +43,26 @@ __device__ __forceinline__ int stat_sum(const int* __restrict__ stats, int idx, 
     return s;
 }
 
+// Sum over the 64 lanes, in every lane.  Six data-parallel-primitive adds (no LDS round trips: a __shfl_down
+// reduction is six ds_bpermute latencies, ~0.3 us at the tail of kernels that last a few microseconds) and a
+// readlane of lane 63, where the row_bcast steps leave the total.
 __device__ inline int wave_reduce_add(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
+// the same for a non-negative 64-bit sum below 2^52: two 32-bit reductions of its low 20 and its high bits
 __device__ inline long long wave_reduce_add_ll(long long v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    const int lo = wave_reduce_add((int)(v & 0xFFFFF));
+    const int hi = wave_reduce_add((int)(v >> 20));
+    return ((long long)hi << 20) + (long long)lo;
 }
 
 // ------------------------------------------------------------------------------------------
