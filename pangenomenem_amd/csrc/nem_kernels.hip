@@ -1220,18 +1220,26 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int r = 0; r < R; r++) acc[c][r] = 0;
-        for (int j = threadIdx.x; j < nw64; j += 256) {
-            uint64_t xv[R];
+        // two words per thread and trip, all their loads requested before any is used (the masks were written by the
+        // launch before this one: every trip of a one-word loop would wait for memory on its own)
+        for (int j = threadIdx.x; j < nw64; j += 512) {
+            const int j2 = j + 256;
+            const bool two = j2 < nw64;
+            uint64_t xv[R], xw2[R], m[4], m2[4];
 #pragma unroll
-            for (int r = 0; r < R; r++) xv[r] = (d0 + r < D) ? rows[r][j] : ~0ull;
+            for (int r = 0; r < R; r++) {
+                xv[r] = (d0 + r < D) ? rows[r][j] : ~0ull;
+                xw2[r] = two ? ((d0 + r < D) ? rows[r][j2] : ~0ull) : 0ull;
+            }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (c < kn) {
-                    const uint64_t m = mask[(size_t)(k0 + c) * nw64 + j];
-#pragma unroll
-                    for (int r = 0; r < R; r++) acc[c][r] += __popcll(xv[r] & m);
-                }
+                m[c] = (c < kn) ? mask[(size_t)(k0 + c) * nw64 + j] : 0ull;
+                m2[c] = (c < kn && two) ? mask[(size_t)(k0 + c) * nw64 + j2] : 0ull;
             }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[c][r] += __popcll(xv[r] & m[c]) + __popcll(xw2[r] & m2[c]);
         }
         __syncthreads();
 #pragma unroll
