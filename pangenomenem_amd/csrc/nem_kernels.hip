@@ -949,6 +949,10 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     constexpr int KA = KT > 0 ? KT : kMaxKernelK;
     bool zero_density = false;
     bool changed = false;
+    // this site's own labels, requested with everything else at the head of the block: asked for where they are
+    // used -- behind the label store, which they might alias -- they would be one more memory latency at the tail
+    int my_guess = 0, my_old = 0, my_new = 255;
+    if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi]; }
     if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
     __syncthreads();
     if (active && !skip) {
@@ -1045,7 +1049,8 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
                 kmax = chosen;
             }
         }
-        changed = (kmax != (int)a.lab_guess[gi]);
+        changed = (kmax != my_guess);
+        my_new = kmax;
         a.lab_out[gi] = (uint8_t)kmax;
     } else {
         const float* g = a.c_guess + (size_t)gi * K;
@@ -1079,8 +1084,10 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     if (NCEM && a.post_on) {                             // k_labels_post's work, see SweepArgs
         int lab = 255, moved = 0;
         if (active) {
-            lab = a.post_from_guess ? a.lab_guess[gi] : a.lab_out[gi];   // (lab_out[gi]: this thread's own store)
-            if (a.post_moved) moved = (lab != (int)a.lab_old[gi]);
+            // (a round that skipped its sites and posts its own output reads that output back: not a case the
+            //  engine enqueues, the verification round posts its guess)
+            lab = a.post_from_guess ? my_guess : (my_new != 255 ? my_new : (int)a.lab_out[gi]);
+            if (a.post_moved) moved = (lab != my_old);
         }
         const int wave = i >> 6;
         if (wave < a.post_nw64) {
