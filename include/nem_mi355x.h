@@ -207,6 +207,12 @@ int nemgpu_rccl_unique_id(uint8_t id128[128]);
 int nemgpu_rccl_attach(nemgpu_engine* e, const uint8_t id128[128], int world, int rank);
 int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
                                uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off);
+/* One in-place all-gather of `stride`-byte blocks of buf_dev (world * stride bytes, device memory) through the
+   engine's own communicator, waited for with a deadline; collective.  The caller compares the result with the same
+   gather through torch.distributed before trusting the native path.  A timeout aborts and detaches the communicator. */
+int nemgpu_rccl_selftest(nemgpu_engine* e, uint8_t* buf_dev, int stride, int timeout_ms);
+/* ranks of the engine's native communicator as RCCL reports them (ncclCommCount); 0 when none is attached */
+int nemgpu_rccl_ranks(const nemgpu_engine* e);
 
 /* Test hook: load a partition (row-major [n_total x k], HOST) as the current state
    (argmax labels for ncem engines). */
@@ -273,6 +279,14 @@ int nemgpu_chain_device(const double* x, long long n, float init, int device, fl
    per process) for the next nemgpu_create on the same device -- a nem() call creates and destroys an engine, and
    creating these costs as much as a small EM run.  This frees whatever is parked. */
 void nemgpu_release_cached(void);
+
+/* hipGraph policy of the pipelined EM loop.  By default a batch shape (initial sweeps or not, buffer phase, number of
+   iterations) goes out as plain launches the first time and is captured + instantiated the second time it is
+   enqueued; capture_on_first != 0 captures at once (benchmarks prime every shape of their timed region this way). */
+int nemgpu_set_graph_policy(nemgpu_engine* e, int capture_on_first);
+/* out[0] batches sent as plain launches, out[1] batches captured + instantiated, out[2] graph replays,
+   out[3] sweeps the host had to finish round by round */
+int nemgpu_graph_counters(const nemgpu_engine* e, int out[4]);
 
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,16 @@ namespace {
 // Line layout: StartLogFile (nem_alg.c:1478-1498), the INIT_PARAM_FILE preamble (:1151-1158), WriteLogHeader
 // (:1883-1945), and per iteration "%4d " + criteria before and after the E-step sweep (WriteLogCrit, :2620-2646,
 // called at :2361 and :2398) + WriteLogClasses (:1993-2052).
+// asctime(localtime()) share static buffers; nem() may run on several threads at once (nem_many)
+std::string date_line()
+{
+    time_t timer = time(nullptr);
+    struct tm tmv;
+    char buf[64];
+    if (localtime_r(&timer, &tmv) == nullptr || asctime_r(&tmv, buf) == nullptr) return "\n";
+    return buf;                                                              // ends with '\n' like asctime()
+}
+
 float log_mult(int npt)
 {
     return (float)exp(-((int)(log(npt / 1000.) / log(10))) * log(10));      // :1495, :2638
@@ -137,8 +148,7 @@ void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool size
 int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res)
 {
     const float mult = log_mult(n);
-    time_t timer = time(nullptr);
-    fprintf(fl, "NEM log file  -  %s\n", asctime(localtime(&timer)));
+    fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
     fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)mult);
     fprintf(fl, "Initializing parameters from given value :\n");
     fprintf(fl, "%4d ", 0);
@@ -326,7 +336,15 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     nemgpu_engine* e = nullptr;
     nemgpu_result res{};
     bool full_log = false;
-    int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, 0, nullptr);
+    // which GPU: NEM_MI355X_DEVICE when set; otherwise processes spread over the node's GPUs by pid (PPanGGOLiN runs
+    // its chunks in a multiprocessing.Pool, ppanggolin.py:1039-1095: every worker would otherwise land on GPU 0)
+    int device = 0;
+    {
+        const int ndev = nemgpu_device_count();
+        if (const char* s = getenv("NEM_MI355X_DEVICE")) device = atoi(s);
+        else if (ndev > 1) device = (int)((unsigned long)getpid() % (unsigned long)ndev);
+    }
+    int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, device, nullptr);
     if (rc == NEMGPU_OK) rc = nemgpu_set_matrix_bits(e, in.xbits.data());
     if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
     if (rc == NEMGPU_OK && !random_init) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
@@ -383,8 +401,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         if (dolog && !full_log) {                                           // header-only <Fname>.log (never parsed by PPanGGOLiN)
             FILE* fl = fopen((base + ".log").c_str(), "w");
             if (fl) {
-                time_t t = time(nullptr);
-                fprintf(fl, "NEM log file  -  %s\n", asctime(localtime(&t)));
+                fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
                 fprintf(fl, "  MI355X engine: per-iteration criteria are not logged; iterations = %d\n", res.iters);
                 fclose(fl);
             }

@@ -6,8 +6,10 @@
 // entry point returns NEMGPU_E_DEVICE when HIP is unusable.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -113,6 +115,8 @@ struct nemgpu_engine {
     hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
     uint8_t graph_asked[2][3][8] = {};   // how often a batch shape was enqueued before it got a graph
     bool use_graphs = true;
+    bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
+    int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
     // auto: on from 256 organisms (below that the chain is mostly the small-binade prefix that is stepped anyway
     // and the table build is pure overhead).  Measured on MI355X: 20k x 500 on par with plain stepping
@@ -165,6 +169,18 @@ struct ParkedSet { int device; hipStream_t stream; char* chunk; int* flags_host;
 std::mutex g_park_mutex;
 std::vector<ParkedSet> g_parked;
 constexpr size_t kParkMax = 16;
+
+// A forked child inherits a HIP runtime it cannot use (and handles parked by its parent that mean nothing to it).
+// PPanGGOLiN's multiprocessing.Pool forks (ppanggolin.py:1039): if the parent has already run nem(), the workers must
+// be started with the spawn / forkserver method -- a child of a GPU-using parent fails fast here instead of hanging.
+std::atomic<bool> g_hip_used{false}, g_forked_after_hip{false};
+std::once_flag g_atfork_once;
+void atfork_child()
+{
+    if (g_hip_used.load()) g_forked_after_hip.store(true);
+    new (&g_park_mutex) std::mutex();                       // the parent may have held it at fork time
+    new (&g_parked) std::vector<ParkedSet>();               // parent's handles: leaked on purpose, never touched
+}
 
 constexpr size_t kChunkShared = (size_t)16 << 20;       // small buffers share 16 MB chunks
 constexpr size_t kChunkOwn = (size_t)4 << 20;           // from 4 MB on a buffer gets a chunk of its own
@@ -590,8 +606,9 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
         // the first batch of a shape goes out as plain launches: capturing and instantiating a graph costs more than
         // it saves unless the batch is replayed, and a nem() call's engine enqueues most shapes once
-        if (graphed && exec == nullptr && e->graph_asked[first ? 1 : 0][base][g]++ == 0) graphed = false;
+        if (graphed && exec == nullptr && e->graph_asked[first ? 1 : 0][base][g]++ == 0 && !e->capture_first) graphed = false;
         if (exec == nullptr) {
+            if (graphed) e->n_captured++; else e->n_plain++;
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             r = NEMGPU_OK;
             e->ctrl_pending = false;                               // (a batch never inherits a deferred loop control)
@@ -613,6 +630,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
                     e->graphs[first ? 1 : 0][base][g] = exec;
                 } else {
                     exec = nullptr;
+                    e->n_captured--;
                     e->use_graphs = false;                         // fall back to plain launches for good
                     if (herr == hipSuccess && cerr != hipSuccess) herr = cerr;
                 }
@@ -626,7 +644,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             if (r) return r;
             HIPCHK(herr);
         }
-        if (exec != nullptr) HIPCHK(hipGraphLaunch(exec, e->stream));
+        if (exec != nullptr) { HIPCHK(hipGraphLaunch(exec, e->stream)); e->n_replayed++; }
         HIPCHK(hipStreamSynchronize(e->stream));
         const int* c = e->h_ctrl();
         const int done = c[C_ITERS], commits = c[C_COMMITS];
@@ -643,6 +661,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after two rounds; every
             // iteration behind it returned at the stop word.  Finish it from the host, then go on.
             e->cur = 1;
+            e->n_host_rounds++;
             SweepCtx sc;
             sc.use_nei = true;
             SweepArgs& a = sc.a;
@@ -675,6 +694,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             // iteration #commits of this batch ran its M-step, density and relaxation rounds 0 and 1 and is
             // not at the fixed point yet: continue its rounds from the host, then redo the bookkeeping.
             const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
+            e->n_host_rounds++;
             SweepCtx sc;
             sc.use_nei = true;
             SweepArgs& a = sc.a;
@@ -810,12 +830,19 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
         set_error("nemgpu_create: more than 2^24 families (the reference's float class sizes stop being integers)");
         return NEMGPU_E_ARG;
     }
+    std::call_once(g_atfork_once, [] { pthread_atfork(nullptr, nullptr, atfork_child); });
+    if (g_forked_after_hip.load()) {
+        set_error("this process was forked from one that had already used the GPU: HIP is unusable in a forked child "
+                  "(start the workers with multiprocessing's 'spawn' or 'forkserver' method)");
+        return NEMGPU_E_DEVICE;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no usable HIP device: this library has no CPU fallback");
         return NEMGPU_E_DEVICE;
     }
     if (device < 0 || device >= ndev) { set_error("nemgpu_create: bad device index"); return NEMGPU_E_ARG; }
+    g_hip_used.store(true);
     HIPCHK(hipSetDevice(device));
     nemgpu_engine* e = new nemgpu_engine();
     e->n_total = n_total; e->n_true = n_total; e->d = d; e->k = k; e->lo = site_lo; e->hi = site_hi; e->n = site_hi - site_lo;
@@ -1493,6 +1520,8 @@ struct RcclApi {
     int (*comm_init_rank)(void**, int, nccl_uid_t, int) = nullptr;             // ncclCommInitRank(comm*, nranks, id, rank)
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*comm_destroy)(void*) = nullptr;
+    int (*comm_count)(const void*, int*) = nullptr;                            // ncclCommCount
+    int (*comm_abort)(void*) = nullptr;                                        // ncclCommAbort
     const char* (*error_string)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1513,6 +1542,8 @@ int nemgpu_rccl_open(const char* librccl_path)
     g_rccl.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.comm_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (int (*)(const void*, int*))dlsym(h, "ncclCommCount");
+    g_rccl.comm_abort = (int (*)(void*))dlsym(h, "ncclCommAbort");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_gather || !g_rccl.comm_destroy) {
         set_error("librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
         dlclose(h);
@@ -1554,6 +1585,15 @@ int nemgpu_rccl_attach(nemgpu_engine* e, const uint8_t id128[128], int world, in
     return NEMGPU_OK;
 }
 
+// ranks of the engine's native communicator as RCCL itself reports them (ncclCommCount); 0 when none is attached
+int nemgpu_rccl_ranks(const nemgpu_engine* e)
+{
+    if (!e || !e->rccl_comm || !g_rccl.comm_count) return 0;
+    int n = 0;
+    if (g_rccl.comm_count(e->rccl_comm, &n) != 0) return 0;
+    return n;
+}
+
 namespace {
 int rccl_allgather_blocks(nemgpu_engine* e, uint8_t* buf)
 {
@@ -1563,6 +1603,32 @@ int rccl_allgather_blocks(nemgpu_engine* e, uint8_t* buf)
     return NEMGPU_OK;
 }
 }  // namespace
+
+// One in-place all-gather of `stride`-byte blocks through the engine's own communicator, waited for with a deadline:
+// the caller (every rank, collectively) compares the result with the same gather through torch.distributed before
+// trusting the native path with the EM.  On a timeout the communicator is aborted and detached (the engine then has
+// no native path) and NEMGPU_E_DEVICE is returned.
+int nemgpu_rccl_selftest(nemgpu_engine* e, uint8_t* buf_dev, int stride, int timeout_ms)
+{
+    if (!e || !buf_dev || stride <= 0) return NEMGPU_E_FUNCARG;
+    if (!e->rccl_comm) { set_error("nemgpu_rccl_attach first"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    int rc = g_rccl.all_gather(buf_dev + (size_t)e->sh_rank * stride, buf_dev, (size_t)stride, /*ncclUint8*/ 1,
+                               e->rccl_comm, e->stream);
+    if (rc != 0) return rccl_fail("ncclAllGather (self-test)", rc);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(e->stream);
+        if (q == hipSuccess) return NEMGPU_OK;
+        if (q != hipErrorNotReady) { set_error(std::string("self-test: ") + hipGetErrorString(q)); return NEMGPU_E_DEVICE; }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (g_rccl.comm_abort) (void)g_rccl.comm_abort(e->rccl_comm);
+    e->rccl_comm = nullptr;
+    set_error("native RCCL self-test timed out: communicator aborted");
+    return NEMGPU_E_DEVICE;
+}
 
 // One whole batch of the sharded EM -- [the two initial sweeps +] n_iters iterations, all-gathers included --
 // enqueued on the engine's stream without returning to the caller in between (what ShardedNem._enqueue_batch
@@ -1785,6 +1851,25 @@ int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256)
 {
     if (!q0_256 || !q1_256) return NEMGPU_E_FUNCARG;
     for (int E = 0; E < 256; E++) nemk::ff_entry(l1, -l0, E, q0_256[E], q1_256[E]);
+    return NEMGPU_OK;
+}
+
+// capture_on_first != 0: a batch shape of the pipelined loop is captured into a hipGraph the FIRST time it is
+// enqueued (default: the second time -- a nem() call's engine enqueues most shapes once and capturing costs more
+// than it saves unless the batch is replayed).  Benchmarks prime every shape of their timed region with it.
+int nemgpu_set_graph_policy(nemgpu_engine* e, int capture_on_first)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    e->capture_first = capture_on_first != 0;
+    return NEMGPU_OK;
+}
+
+// out[0] batches enqueued as plain launches, out[1] batches captured + instantiated (one-off cost), out[2] graph
+// replays, out[3] sweeps the host had to finish round by round (more than the two enqueued relaxation rounds)
+int nemgpu_graph_counters(const nemgpu_engine* e, int out[4])
+{
+    if (!e || !out) return NEMGPU_E_FUNCARG;
+    out[0] = e->n_plain; out[1] = e->n_captured; out[2] = e->n_replayed; out[3] = e->n_host_rounds;
     return NEMGPU_OK;
 }
 

@@ -163,6 +163,25 @@ class GpuStepper:
             self.eng._chk(self.eng.lib.nemgpu_rccl_attach(self.eng._h, ctypes.addressof(host), comm.world, comm.rank))
         except Exception:
             ok = 0
+        if comm.allreduce_max_int(0 if ok else 1) != 0:
+            return False
+        # Self-test before the EM relies on it: one all-gather of per-rank patterns through the engine's own
+        # communicator (waited for with a deadline; a timeout aborts that communicator) against the same gather
+        # through torch.distributed.  Any mismatch or failure on any rank keeps every rank on the torch path.
+        stride = 256
+        try:
+            pattern = ((torch.arange(stride, device=self.device, dtype=torch.int32) * 7 + 13 * comm.rank + 1) % 251).to(torch.uint8)
+            buf = torch.zeros(stride * comm.world, dtype=torch.uint8, device=self.device)
+            buf[comm.rank * stride:(comm.rank + 1) * stride] = pattern
+            want = torch.zeros_like(buf)
+            dist.all_gather_into_tensor(want, pattern, group=comm.group)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            torch.cuda.synchronize(self.device)
+            rc = self.eng.lib.nemgpu_rccl_selftest(self.eng._h, ctypes.c_void_p(buf.data_ptr()), stride, 20000)
+            ok = 1 if (rc == 0 and bool(torch.equal(buf, want))) else 0
+        except Exception:
+            ok = 0
         self.native = comm.allreduce_max_int(0 if ok else 1) == 0
         return self.native
 
@@ -439,11 +458,12 @@ class ShardedNem:
         self._graphs, self._seen = {}, set()      # kernel arguments are baked into captured batches
 
     def iters_to_converge(self, it_max=100):
+        """EM iterations this job needs from its initial parameters (the reference's clas test, 1e-8); at least 1."""
         keep = self.cvtest
         self.set_cvtest("clas")
         res = self.run(it_max)
         self.set_cvtest(keep)
-        return max(5, int(res["iters"]))
+        return max(1, int(res["iters"]))
 
     def run_steps(self, count, cycle):
         done = 0
@@ -454,18 +474,21 @@ class ShardedNem:
             done += m
 
     @classmethod
-    def synthetic(cls, n_loc, d, k, beta, rank, world, local_rank, algo="ncem"):
-        """Weak-scaling job: every rank owns an n_loc x d shard of BASELINE configs[1]'s generator; the
-        contiguity graph is the global path + chords over all n_loc*world families."""
+    def synthetic(cls, n_total, d, k, beta, rank, world, device, algo="ncem", spectrum="ushape", seed=2, comm=None):
+        """One synthetic n_total x d problem (the generators of pangenomenem_amd/synth.py, the same matrix on every
+        rank count) sharded in contiguous family blocks: every rank draws the global matrix from the shared seed
+        and keeps its rows; the contiguity graph is the global path + chords."""
         from . import synth
         if algo != "ncem":
             raise ValueError("the sharded path is NCEM-only (fuzzy sums are order-dependent, SURVEY.md §8e)")
-        n_total = n_loc * world
         lo, hi, _ = shard_bounds(n_total, world, rank)
         blk, stride = slot_layout(n_total, world, k + k * d)
-        x_local, _ = synth.bernoulli_pa_matrix(hi - lo, d, 2 + 1000 * rank)
-        nei = slice_graph(synth.contiguity_graph(n_total, 2), lo, hi, blk, stride)
+        gen = synth.ushaped_pa_matrix if spectrum == "ushape" else synth.bernoulli_pa_matrix
+        x, _ = gen(n_total, d, seed)
+        x_local = np.ascontiguousarray(x[lo:hi])
+        del x
+        nei = slice_graph(synth.contiguity_graph(n_total, seed), lo, hi, blk, stride)
         prop, center, disp = synth.default_init(d)
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)
-        st = GpuStepper(x_local, nei, k, n_total, world, rank, prop, center, disp, local_rank, cfg)
-        return cls(st, Comm(), n_total, beta, cvtest="none")
+        st = GpuStepper(x_local, nei, k, n_total, world, rank, prop, center, disp, device, cfg)
+        return cls(st, comm or Comm(), n_total, beta, cvtest="none")

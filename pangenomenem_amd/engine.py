@@ -78,6 +78,10 @@ def load_library():
     lib.nemgpu_calibrate_fetch.argtypes = [C.c_size_t, C.c_int]
     lib.nemgpu_set_stream.argtypes = [vp, vp]
     lib.nemgpu_set_fast_forward.argtypes = [vp, C.c_int]
+    lib.nemgpu_set_graph_policy.argtypes = [vp, C.c_int]
+    lib.nemgpu_graph_counters.argtypes = [vp, ip]
+    lib.nemgpu_rccl_ranks.argtypes = [vp]
+    lib.nemgpu_rccl_selftest.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.nemgpu_ff_table.argtypes = [C.c_double, C.c_double, vp, vp]
     lib.nemgpu_shard_end_enqueue.argtypes = [vp]
     lib.nemgpu_stats_words.argtypes = [vp]
@@ -335,6 +339,18 @@ class NemEngine:
     def set_fast_forward(self, mode):
         """E1 binade fast-forward: 1 always, 0 never, -1 automatic (default); results are bit-identical."""
         self._chk(self.lib.nemgpu_set_fast_forward(self._h, int(mode)))
+
+    def set_graph_policy(self, capture_on_first=True):
+        """Capture a batch shape of the pipelined loop into a hipGraph the first time it is enqueued."""
+        self._chk(self.lib.nemgpu_set_graph_policy(self._h, int(bool(capture_on_first))))
+
+    def graph_counters(self):
+        out = (C.c_int * 4)()
+        self._chk(self.lib.nemgpu_graph_counters(self._h, out))
+        return dict(plain=out[0], captured=out[1], replayed=out[2], host_finished_sweeps=out[3])
+
+    def rccl_ranks(self):
+        return int(self.lib.nemgpu_rccl_ranks(self._h))
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))

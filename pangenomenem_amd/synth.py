@@ -30,6 +30,24 @@ def bernoulli_pa_matrix(n, d, seed, mix=(0.30, 0.20, 0.50), p=(0.97, 0.5, 0.03))
     return x, z
 
 
+def ushaped_pa_matrix(n, d, seed, a=0.3, b=0.3):
+    """Family-frequency spectrum of a real pangenome: U-shaped (many rare families, many near-universal ones, a
+    broad shell in between).  Family i is present in each organism with its own probability p_i ~ Beta(a, b).
+    Unlike the three well-separated latent classes of bernoulli_pa_matrix -- on which NEM is at its fixed point
+    after ONE iteration from PPanGGOLiN's default .m -- the shell boundaries move for several EM iterations
+    (7 at 20 000 x 500 with the reference), so an EM benchmark on it times real pre-convergence iterations."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pz = rng.beta(a, b, size=n).astype(np.float32)
+    x = np.empty((n, d), np.uint8)
+    step = max(1, (1 << 26) // max(d, 1))
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        x[r0:r1] = rng.random((r1 - r0, d), dtype=np.float32) < pz[r0:r1, None]
+    empty = np.flatnonzero(x.sum(axis=1) == 0)
+    x[empty, rng.integers(0, d, size=len(empty))] = 1
+    return x, pz
+
+
 def grouped_pa_matrix(n, d, seed, groups=10, p_in=0.95, p_out=0.05):
     """`groups`-latent-class matrix for the K-sweep (C5): class c present with p_in in organism
     group c and p_out elsewhere, so no class empties for K <= groups."""
