@@ -42,6 +42,13 @@ def run_partitioning_arrays(x, nei, beta, free_dispersion=False, Q=3, init="para
             res = eng.run_random(50, rng_seed)
     finally:
         eng.close()
+    return partition_dicts(res, names, Q, init)
+
+
+def partition_dicts(res, names, Q=3, init="param_file_default"):
+    """What run_partitioning makes of a finished NEM run (ppanggolin.py:1886-1980), from the run's full-precision
+    results instead of the `.uf` / `.mf` text: res = dict(status, c [n, Q], center [Q, d], disp [Q, d], prop [Q])."""
+    n = len(names)
     partitions = ["U"] * n
     all_parameters = {}
     if res["status"] != 0:                                    # empty class: nem() writes no files, everything stays 'U'
