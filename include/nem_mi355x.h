@@ -74,10 +74,13 @@ enum { NEMGPU_ALGO_NEM = 0, NEMGPU_ALGO_NCEM = 1 };
 enum { NEMGPU_DISP___ = 0, NEMGPU_DISP_K_ = 1, NEMGPU_DISP__D = 2, NEMGPU_DISP_KD = 3 };
 enum { NEMGPU_PROP__ = 0, NEMGPU_PROP_K = 1 };
 enum { NEMGPU_CV_NONE = 0, NEMGPU_CV_CLAS = 1 };
-/* NCEM tie rule (ComputeMAP, nem_alg.c:590-645). The reference draws random() seeded with
-   time(NULL) (nem_exe.c:353,621), which no caller can reproduce; the engine offers
-   FIRST (= TIE_FIRST) and HASH (counter-based: kmaxes[mix32(seed, sweep, site) % (nequal+1)]). */
-enum { NEMGPU_TIE_FIRST = 1, NEMGPU_TIE_HASH = 2 };
+/* NCEM tie rule (ComputeMAP, nem_alg.c:590-645; numeric values of TIE_RANDOM / TIE_FIRST follow TieET).
+   LIBC = the reference's TIE_RANDOM: kmaxes[random() % (nequal+1)] on glibc's random() after srandom(tie_seed)
+   (nem_exe.c:621; the reference seeds with time(NULL), :353), drawn in site order exactly as the sequential
+   sweep draws them -- with the seed fixed, labels equal the reference's even where classes tie.
+   FIRST = TIE_FIRST.  HASH: counter-based, kmaxes[mix32(seed, sweep, site) % (nequal+1)] (stateless; the
+   family-sharded multi-GPU path uses it). */
+enum { NEMGPU_TIE_LIBC = 0, NEMGPU_TIE_FIRST = 1, NEMGPU_TIE_HASH = 2 };
 /* status codes = StatusET (nem_typ.h:106-117) */
 enum { NEMGPU_OK = 0, NEMGPU_W_EMPTYCLASS = 2, NEMGPU_E_ARG = 3, NEMGPU_E_MEMORY = 4,
        NEMGPU_E_FILEIN = 5, NEMGPU_E_FILEOUT = 6, NEMGPU_E_FILE = 7, NEMGPU_E_FUNCARG = 8,
@@ -106,6 +109,7 @@ typedef struct {
     int   sweep_rounds;         /* total relaxation rounds spent in E-step sweeps */
     float crit[6];     /* D G U M L Z (ComputeCrit, nem_alg.c:2678-2757) */
     double loop_seconds;        /* wall time of the EM iteration loop (host clock, synchronised) */
+    int   tie_draws;            /* TIE_LIBC: random() draws consumed so far (a .cf writer continues the stream there) */
 } nemgpu_result;
 
 const char* nemgpu_last_error(void);

@@ -280,8 +280,14 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     int dp = get_enum(dispersion, DisperStr, 4);
     if (dp == -1) lg.pr(" Unknown dispersion %s\n", dispersion ? dispersion : "(null)");
     cfg.disper = dp;
-    cfg.tie_rule = NEMGPU_TIE_HASH;
-    cfg.tie_seed = (uint32_t)time(nullptr);                                 // NemPara.Seed = time(NULL), :353
+    // TieRule = TIE_RANDOM on random() after srandom(NemPara.Seed), Seed = time(NULL) (:353, :621): the same stream here,
+    // drawn in the same order; NEM_MI355X_SEED fixes the seed, NEM_MI355X_TIE=hash|first selects a stateless rule
+    cfg.tie_rule = NEMGPU_TIE_LIBC;
+    if (const char* s = getenv("NEM_MI355X_TIE")) {
+        if (!strcmp(s, "hash")) cfg.tie_rule = NEMGPU_TIE_HASH;
+        else if (!strcmp(s, "first")) cfg.tie_rule = NEMGPU_TIE_FIRST;
+    }
+    cfg.tie_seed = (uint32_t)time(nullptr);
     if (const char* s = getenv("NEM_MI355X_SEED")) cfg.tie_seed = (uint32_t)strtoul(s, nullptr, 10);
 
     const std::string outname = base + (hard ? ".cf" : ".uf");              // :437-440
@@ -393,7 +399,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         std::vector<float> c((size_t)in.n * nk), prop(nk), center((size_t)nk * in.d), disp((size_t)nk * in.d);
         nemgpu_get_partition(e, c.data());
         nemgpu_get_params(e, prop.data(), center.data(), disp.data(), nullptr);
-        int w1 = hard ? write_cf_file(outname, c.data(), in.n, nk, cfg.tie_rule, cfg.tie_seed)
+        int w1 = hard ? write_cf_file(outname, c.data(), in.n, nk, cfg.tie_rule, cfg.tie_seed, res.tie_draws)
                       : write_uf_file(outname, c.data(), in.n, nk);
         int w2 = write_mf_file(base + ".mf", res.crit, cfg.beta, in.d, nk, center.data(), prop.data(), disp.data());
         if (w1 != NEMGPU_OK) fprintf(stderr, "Could not open file '%s' in write mode\n", outname.c_str());
@@ -493,7 +499,7 @@ int nemio_format_fixed(float v, int width, int dec, char* out)
 }
 int nemio_write_cf(const char* path, const float* c, int n, int k, int tie_rule, uint32_t seed)
 {
-    return write_cf_file(path, c, n, k, tie_rule, seed);
+    return write_cf_file(path, c, n, k, tie_rule, seed, 0);
 }
 int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, int k, const float* center,
                    const float* prop, const float* disp)

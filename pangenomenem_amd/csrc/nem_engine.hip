@@ -92,6 +92,15 @@ struct nemgpu_engine {
     float* logpkfki = nullptr;
 
     uint8_t* lab[3] = {nullptr, nullptr, nullptr};   // NCEM partitions (labels), n_total each
+    // TIE_LIBC (the reference's tie stream): draws per sweep block of each label buffer; the stream's table on the
+    // device (draws draw_tab0 .. +draw_cap-1 of glibc random() after srandom(tie_seed)); {draws made, draw_tab0} for
+    // the pipelined loop (device words); draws made so far (host)
+    int* tie_cnt[3] = {nullptr, nullptr, nullptr};
+    uint32_t* draw_tab = nullptr; int draw_cap = 0; long draw_tab0 = 0; bool draw_valid = false;
+    std::vector<uint32_t> draw_host; nemk::GlibcRandom draw_gen{1}; long draw_gen_pos = 0;
+    int* draw_ctl = nullptr;
+    int draws = 0; bool tie_heavy = false;
+    bool libc() const { return cfg.algo == NEMGPU_ALGO_NCEM && cfg.tie_rule == NEMGPU_TIE_LIBC; }
     float* cbuf[3] = {nullptr, nullptr, nullptr};    // fuzzy partitions, n_total*k each
     int cur = 0;
     uint64_t* mask = nullptr;
@@ -222,6 +231,7 @@ int dev_alloc(T** p, size_t count)
 
 // blocking copy on the engine's stream
 hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+void drop_graphs(nemgpu_engine* e);
 
 int ensure_state_buffers(nemgpu_engine* e)
 {
@@ -229,6 +239,8 @@ int ensure_state_buffers(nemgpu_engine* e)
     if (e->ncem()) {
         for (int b = 0; b < 3; b++)
             if (!e->lab[b]) { int r = dev_alloc(&e->lab[b], (size_t)e->n_total); if (r) return r; }
+        for (int b = 0; b < 3; b++)
+            if (!e->tie_cnt[b]) { int r = dev_alloc(&e->tie_cnt[b], (size_t)e->n / 256 + 2); if (r) return r; }
     } else {
         for (int b = 0; b < 3; b++)
             if (!e->cbuf[b]) { int r = dev_alloc(&e->cbuf[b], (size_t)e->n_total * e->k); if (r) return r; }
@@ -299,6 +311,7 @@ int do_density(nemgpu_engine* e)
 struct SweepCtx {
     SweepArgs a{};
     bool use_nei = false;
+    bool multi = false;  // the sweep needs verified relaxation rounds: it reads neighbours, or its ties share a draw stream
     int r = 0;           // rounds launched so far
     int checked = 0;     // rounds whose flags the host has examined
     int slot_base = 0;   // first flag slot of the round window (the blind initial sweep takes a slot of its own)
@@ -313,6 +326,68 @@ int clear_sweep_flags(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
+// ---- TIE_LIBC: the reference's random() stream ------------------------------------------------
+// The device reads draws from a table that covers a window of the stream; the host keeps the generator behind it.
+// Makes draws [lo, lo + count) available (regenerating / sliding / growing the window as needed).
+int ensure_draw_window(nemgpu_engine* e, long lo, long count)
+{
+    if (e->draw_valid && e->draw_tab0 <= lo && lo + count <= e->draw_tab0 + e->draw_cap) return NEMGPU_OK;
+    long cap = std::max<long>(e->draw_cap, 1024);
+    while (cap < 2 * count) cap *= 2;
+    if (!e->draw_valid || lo < e->draw_tab0) {               // a new stream (seed / restart below the window)
+        e->draw_gen.seed(e->cfg.tie_seed); e->draw_gen_pos = 0; e->draw_host.clear(); e->draw_tab0 = 0;
+    }
+    // slide the host window to start at lo
+    const long have_end = e->draw_tab0 + (long)e->draw_host.size();
+    if (lo >= have_end) {
+        while (e->draw_gen_pos < lo) { (void)e->draw_gen.next(); e->draw_gen_pos++; }
+        e->draw_host.clear();
+    } else if (lo > e->draw_tab0) {
+        e->draw_host.erase(e->draw_host.begin(), e->draw_host.begin() + (lo - e->draw_tab0));
+    }
+    e->draw_tab0 = lo;
+    while ((long)e->draw_host.size() < cap) { e->draw_host.push_back((uint32_t)e->draw_gen.next()); e->draw_gen_pos++; }
+    if (cap > e->draw_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        alloc_for(e);
+        int r = dev_alloc(&e->draw_tab, (size_t)cap);        // (a smaller table stays in its chunk until the engine goes)
+        if (r) return r;
+        e->draw_cap = (int)cap;
+        drop_graphs(e);                                      // table pointer and length are kernel arguments
+    }
+    HIPCHK(hipMemcpyAsync(e->draw_tab, e->draw_host.data(), (size_t)e->draw_cap * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->draw_valid = true;
+    return NEMGPU_OK;
+}
+long draw_need(const nemgpu_engine* e) { return e->tie_heavy ? 8l * e->n + 1024 : 1024; }
+
+// one draw on the host (RandNemAlgo's MakeRandomPara shares the stream with the ties)
+int host_draw(nemgpu_engine* e, uint32_t* out)
+{
+    int r = ensure_draw_window(e, e->draws, draw_need(e));
+    if (r) return r;
+    *out = e->draw_host[(size_t)(e->draws - e->draw_tab0)];
+    e->draws++;
+    return NEMGPU_OK;
+}
+
+// the draw-stream side of a sweep's arguments; by_value: the host knows how many draws were made (else the device does)
+void sweep_draw_args(nemgpu_engine* e, SweepArgs& a, bool by_value)
+{
+    a.draw_tab = e->draw_tab; a.draw_tab_len = e->draw_cap;
+    a.draw_base = e->draws; a.draw_tab0 = (int)e->draw_tab0;
+    a.draw_ctl = by_value ? nullptr : e->draw_ctl;
+    a.draw_extra = nullptr;
+}
+// the device words the pipelined loop reads the stream position from (outside any graph capture)
+int publish_draw_ctl(nemgpu_engine* e)
+{
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->draw_ctl, e->draws, 1, e->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(e->draw_ctl + 1), (int)e->draw_tab0, 1, e->stream));
+    return NEMGPU_OK;
+}
+
 int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
 {
     const bool ncem = e->ncem();
@@ -322,8 +397,10 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         const int r = c.r;
         const int gb = (r == 0) ? P : ((r - 1) % 2 == 0 ? Q : R);
         const int ob = (r % 2 == 0) ? Q : R;
-        if (ncem) { c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[gb]; c.a.lab_out = e->lab[ob]; }
-        else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
+        if (ncem) {
+            c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[gb]; c.a.lab_out = e->lab[ob];
+            c.a.tie_cnt_guess = e->tie_cnt[gb]; c.a.tie_cnt_out = e->tie_cnt[ob];
+        } else { c.a.c_old = e->cbuf[P]; c.a.c_guess = e->cbuf[gb]; c.a.c_out = e->cbuf[ob]; }
         c.a.flags = e->round_flags(c.slot_base + r);
         c.a.fold_ticket = e->sweep_next + 32;
         c.a.prev_changed = (r == r0) ? nullptr : (e->round_flags(c.slot_base + r - 1) + FLAG_CHANGED);
@@ -346,6 +423,7 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
     c.slot_base = slot_base;
     if (post_ctrl != nullptr && e->ncem()) { c.post = true; c.post_moved = post_moved; c.post_ctrl = *post_ctrl; }
     c.use_nei = e->has_graph && beta != 0.0f;
+    c.multi = c.use_nei || e->libc();
     SweepArgs& a = c.a;
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
     a.use_nei = c.use_nei ? 1 : 0;
@@ -354,9 +432,13 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
     a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = e->sweep_counter++;
     a.sweep_id_ptr = (e->stop_ptr != nullptr && !id_by_value) ? e->sweep_next : nullptr;   // pipelined loop: the device keeps count
+    if (e->libc()) {
+        if (e->stop_ptr == nullptr) { int r = ensure_draw_window(e, e->draws, draw_need(e)); if (r) return r; }
+        sweep_draw_args(e, a, e->stop_ptr == nullptr);
+    }
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
-    return sweep_launch_rounds(e, c, c.use_nei ? kRoundBatch : 1);
+    return sweep_launch_rounds(e, c, c.multi ? kRoundBatch : 1);
 }
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
@@ -369,13 +451,23 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
         HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
                               e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        if (!c.use_nei) { done_at = 0; break; }
+        if (!c.multi) { done_at = 0; break; }
+        bool tab_short = false;
         for (int q = c.checked; q < c.r; q++) {
-            if (e->h_round(q)[FLAG_CHANGED] == 0) { done_at = q; break; }
+            if (e->h_round(c.slot_base + q)[FLAG_CHANGED] == 0) { done_at = q; break; }
+            if (e->h_round(c.slot_base + q)[FLAG_NTIES] & (1 << 30)) tab_short = true;
         }
         c.checked = c.r;
         if (done_at >= 0) break;
         if (extra) *extra = true;
+        if (tab_short) {
+            // a site needed a draw beyond the table: those rounds were void (they flagged a change).  From now on
+            // the window covers whatever a batch of sweeps can draw.
+            e->tie_heavy = true;
+            int rr = ensure_draw_window(e, e->draws, draw_need(e));
+            if (rr) return rr;
+            sweep_draw_args(e, c.a, true);
+        }
         if (c.r % kRoundCap == 0 || c.r % kRoundCap + kRoundBatch > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
@@ -387,7 +479,8 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
         if (rr) return rr;
     }
     // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
-    const int* f = e->h_round(done_at);
+    const int* f = e->h_round(c.slot_base + done_at);
+    if (e->libc()) e->draws += f[FLAG_NTIES] & ((1 << 30) - 1);
     if (f[FLAG_NZERO] > 0) {
         e->zero_density += f[FLAG_NZERO];
         if (e->first_zero < 0) e->first_zero = e->n_total - f[FLAG_FIRSTZERO];
@@ -489,6 +582,27 @@ int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctrl = 
 
 constexpr int kPipeDepth = 6;
 
+// A sweep of the pipelined loop whose two enqueued rounds did not reach the fixed point (or, TIE_LIBC, ran out of
+// the draw table): the context from which the host goes on with rounds 2, 3, ... (current partition = e->cur)
+int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id)
+{
+    sc = SweepCtx();
+    sc.use_nei = e->has_graph && e->cfg.beta != 0.0f;
+    sc.multi = true;
+    SweepArgs& a = sc.a;
+    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = sc.use_nei ? 1 : 0;
+    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
+    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id; a.sweep_id_ptr = nullptr;
+    sc.r = 2; sc.checked = 2;
+    if (e->libc()) {
+        if ((e->h_round(0)[FLAG_NTIES] | e->h_round(1)[FLAG_NTIES]) & (1 << 30)) e->tie_heavy = true;
+        int r = ensure_draw_window(e, e->draws, draw_need(e));
+        if (r) return r;
+        sweep_draw_args(e, a, true);
+    }
+    return NEMGPU_OK;
+}
+
 // enqueue one whole iteration whose current partition is buffer `cur`.  defer_ctrl: another iteration follows in
 // the same batch -- an NCEM iteration's loop control then runs in that iteration's counts launch (k_mstep_counts)
 // instead of in a last-block ticket at the tail of the last sweep round.
@@ -528,8 +642,9 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     e->sweep_counter = sweep_id;
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
-    ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
+    ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
     // NCEM: the bookkeeping (masks, "moved", loop tests) rides in the last relaxation round's launch -- the loop
     // tests in the next iteration's counts launch when there is one
     const bool defer = defer_ctrl && counts_first;
@@ -566,8 +681,9 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     e->cur = 1;
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
-    ca.param_fix = e->cfg.param_fix; ca.use_nei = (e->has_graph && e->cfg.beta != 0.0f) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
+    ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
+    ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
     ca.is_init = 1;
     ca.blind = e->round_flags(kRoundCap - 1);
     const bool defer = defer_ctrl && e->ncem() && !e->cfg.param_fix;
@@ -592,6 +708,14 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
     }
     bool first = with_init;
+    if (first && e->libc()) {
+        // TIE_LIBC: the two initial sweeps draw from the same stream one after the other (the blind one first), so they
+        // run from the host, sweep by sweep; the iterations behind them are pipelined as usual
+        if ((r = reset_device(e))) return r;
+        e->tables_fresh = false; e->density_fresh = false;
+        if ((r = init_partition(e))) return r;
+        first = false;
+    }
     while ((n_iters > 0 || first) && !e->converged && e->status == NEMGPU_OK) {
         const int g = std::min(n_iters, kPipeDepth);
         const int base = first ? 2 : e->cur;
@@ -601,6 +725,10 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         if (!first) {
             if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
             if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
+        }
+        if (e->libc()) {
+            if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;      // (may drop the graphs)
+            if ((r = publish_draw_ctl(e))) return r;
         }
         bool graphed = e->use_graphs && g < 8;
         hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
@@ -649,6 +777,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         const int* c = e->h_ctrl();
         const int done = c[C_ITERS], commits = c[C_COMMITS];
         e->iters += done;
+        e->draws += c[C_DRAWS];
         e->sweep_rounds += c[C_SWEEP_ROUNDS];
         if (c[C_NZERO] > 0) {
             e->zero_density += c[C_NZERO];
@@ -663,12 +792,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             e->cur = 1;
             e->n_host_rounds++;
             SweepCtx sc;
-            sc.use_nei = true;
-            SweepArgs& a = sc.a;
-            a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = 1;
-            a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
-            a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = 1u; a.sweep_id_ptr = nullptr;
-            sc.r = 2; sc.checked = 2;
+            if ((r = host_rounds_ctx(e, sc, 1u))) return r;
             if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
             if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
             e->sweep_rounds += 1;                                  // + the blind sweep
@@ -696,13 +820,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
             e->n_host_rounds++;
             SweepCtx sc;
-            sc.use_nei = true;
-            SweepArgs& a = sc.a;
-            a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = 1;
-            a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
-            a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep0 + (uint32_t)(done - 1);
-            a.sweep_id_ptr = nullptr;
-            sc.r = 2; sc.checked = 2;
+            if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1)))) return r;
             if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
             int rounds = 0;
             if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
@@ -788,6 +906,7 @@ int reset_state(nemgpu_engine* e)
     e->cur = 0; e->sweep_counter = 0;
     e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
     e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
+    e->draws = 0;                                                  // srandom(seed): the stream starts over
     return NEMGPU_OK;
 }
 
@@ -797,6 +916,7 @@ void fill_result(nemgpu_engine* e, nemgpu_result* res)
     res->status = e->status; res->iters = e->iters; res->converged = e->converged; res->emptyk = e->emptyk;
     res->zero_density_sites = e->zero_density; res->first_zero_density_site = e->first_zero;
     res->sweep_rounds = e->sweep_rounds;
+    res->tie_draws = e->draws;
 }
 
 }  // namespace
@@ -899,6 +1019,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
         set_error("hipHostMalloc failed"); r = NEMGPU_E_DEVICE;
     }
     if (r != NEMGPU_OK) { nemgpu_destroy(e); return r; }
+    e->draw_ctl = e->sweep_next + 8;                               // two of the spare words ahead of the ticket counters
     *out = e;
     return NEMGPU_OK;
 }
@@ -1083,7 +1204,9 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     if (cfg->cvtest != NEMGPU_CV_NONE && cfg->cvtest != NEMGPU_CV_CLAS) { set_error("convergence must be none or clas"); return NEMGPU_E_ARG; }
     if (cfg->cvtest == NEMGPU_CV_CLAS && !(cfg->cvthres > 0)) { set_error("convergence threshold must be > 0"); return NEMGPU_E_ARG; }
     if (cfg->it_max < 0) { set_error("it_max must be >= 0"); return NEMGPU_E_ARG; }
-    if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
+    if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH && cfg->tie_rule != NEMGPU_TIE_LIBC) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
+    if (cfg->tie_rule == NEMGPU_TIE_LIBC && e->sh_stride != 0) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_ARG; }
+    if (cfg->tie_seed != e->cfg.tie_seed || cfg->tie_rule != e->cfg.tie_rule) e->draw_valid = false;
     e->cfg = *cfg;
     HIPCHK(hipSetDevice(e->device));
     drop_graphs(e);                                                // kernel arguments are baked into captured batches
@@ -1124,6 +1247,7 @@ int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
     // reset + ComputePartitionFromPara(Needinit=1) + up to n_iters EM iterations as ONE pipelined batch sequence
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    e->draws = 0;
     int r = iterate(e, n_iters, true);
     if (r) return r;
     fill_result(e, res);
@@ -1137,6 +1261,7 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
     int r;
     HIPCHK(hipStreamSynchronize(e->stream));
     auto t0 = std::chrono::steady_clock::now();
+    e->draws = 0;                                                  // one nem() call = one srandom(seed), nem_exe.c:621
     if ((r = iterate(e, e->cfg.it_max, true))) return r;           // restart + initial sweeps + EM loop, pipelined
     HIPCHK(hipStreamSynchronize(e->stream));
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1183,6 +1308,16 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
     HIPCHK(copy_sync(e, dispsam.data(), e->disp, sizeof(float) * d, hipMemcpyDeviceToHost));
 
     GlibcRandom rng(seed);
+    if (e->libc() && e->cfg.tie_seed != seed) { e->cfg.tie_seed = seed; e->draw_valid = false; }   // one stream (nem_exe.c:621)
+    // RandomInteger (nem_rnd.c:40-63); with TIE_LIBC the starts' draws and the sweeps' tie draws are ONE stream
+    auto draw_integer = [&](int mini, int maxi, int* out) -> int {
+        if (mini >= maxi) { *out = maxi; return NEMGPU_OK; }
+        if (!e->libc()) { *out = rng.integer(mini, maxi); return NEMGPU_OK; }
+        uint32_t v = 0;
+        int rr = host_draw(e, &v);
+        *out = (int)(v % (uint32_t)(maxi - mini + 1)) + mini;
+        return rr;
+    };
     std::vector<float> prop((size_t)k), center(kd), disp(kd);
     auto bit = [&](int i, int j) { return (float)((e->host_bits[(size_t)i * wf + (j >> 5)] >> (j & 31)) & 1u); };
     alloc_for(e);
@@ -1201,7 +1336,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
             int ipt = 0;
             bool again = true;
             for (int ndraw = 0; again && ndraw < 100; ndraw++) {                                             // :1419
-                ipt = rng.integer(0, n - 1);
+                if ((r = draw_integer(0, n - 1, &ipt))) { cleanup(); return r; }
                 again = false;
                 for (int g = 0; g < h && !again; g++) {
                     bool different = false;
@@ -1342,6 +1477,7 @@ int nemgpu_shard_begin(nemgpu_engine* e)
     if (!e) return NEMGPU_E_FUNCARG;
     if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
     if (e->sh_stride == 0) { set_error("nemgpu_shard_layout must be called first"); return NEMGPU_E_FUNCARG; }
+    if (e->libc()) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
     e->stop_ptr = e->ctrl() + C_STOP;
@@ -1710,6 +1846,7 @@ int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)
             lab[i] = (uint8_t)best;
         }
         HIPCHK(copy_sync(e, e->lab[e->cur], lab.data(), lab.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(e->tie_cnt[e->cur], 0, ((size_t)e->n / 256 + 2) * sizeof(int), e->stream));
     } else {
         HIPCHK(copy_sync(e, e->cbuf[e->cur], c_nk, sizeof(float) * (size_t)e->n_total * e->k, hipMemcpyHostToDevice));
     }
@@ -1724,6 +1861,7 @@ int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels)
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(copy_sync(e, labels, e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->n; i++) labels[i] &= 0x7F;              // (bit 7: the site drew, TIE_LIBC)
     return NEMGPU_OK;
 }
 
@@ -1737,7 +1875,7 @@ int nemgpu_get_partition(nemgpu_engine* e, float* c_nk)
         std::vector<uint8_t> lab((size_t)e->n);
         HIPCHK(copy_sync(e, lab.data(), e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
         for (int i = 0; i < e->n; i++)                             // LabelToClassVector, nem_alg.c:649-664
-            for (int k = 0; k < e->k; k++) c_nk[(size_t)i * e->k + k] = (lab[i] == k) ? 1.0f : 0.0f;
+            for (int k = 0; k < e->k; k++) c_nk[(size_t)i * e->k + k] = ((lab[i] & 0x7F) == k) ? 1.0f : 0.0f;
     } else {
         if (!e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
         HIPCHK(copy_sync(e, c_nk, e->cbuf[e->cur] + (size_t)e->lo * e->k, sizeof(float) * (size_t)e->n * e->k,

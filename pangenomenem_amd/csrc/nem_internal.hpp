@@ -44,7 +44,7 @@ int read_nei_file(const std::string& base, NemInputs& in, std::string& err);
 int read_param_file(const std::string& base, int k, NemInputs& in, std::string& err);
 
 int write_uf_file(const std::string& path, const float* c_nk, int n, int k);
-int write_cf_file(const std::string& path, const float* c_nk, int n, int k, int tie_rule, uint32_t seed);
+int write_cf_file(const std::string& path, const float* c_nk, int n, int k, int tie_rule, uint32_t seed, long draws_before = 0);
 int write_mf_file(const std::string& path, const float crit[6], float beta, int d, int k,
                   const float* center, const float* prop, const float* disp);
 

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include "nem_internal.hpp"
+#include "nem_rng.hpp"
 
 namespace nemk {
 
@@ -461,10 +462,13 @@ int write_uf_file(const std::string& path, const float* c, int n, int k)
 }
 
 // SaveResults, hard branch: nem_exe.c:1634-1670 (MAP label + 1 per point, one line)
-int write_cf_file(const std::string& path, const float* c, int n, int k, int tie_rule, uint32_t seed)
+// TIE_LIBC: the ties go on drawing from the run's stream, `draws_before` draws into random() after srandom(seed)
+int write_cf_file(const std::string& path, const float* c, int n, int k, int tie_rule, uint32_t seed, long draws_before)
 {
     FILE* fp = fopen(path.c_str(), "w");
     if (!fp) return NEMGPU_E_FILEOUT;
+    GlibcRandom rng(seed);
+    bool rng_ready = false;
     for (int i = 0; i < n; i++) {
         const float* row = c + (size_t)i * k;
         int kmax = 0; float u = row[0];
@@ -474,6 +478,13 @@ int write_cf_file(const std::string& path, const float* c, int n, int k, int tie
             for (int kk = kmax + 1; kk < k; kk++) if (row[kk] == u) eq[++ne] = kk;
             if (ne > 0) {
                 kmax = eq[mix32_host(seed, 0xFFFFFFFFu, (uint32_t)i) % (uint32_t)(ne + 1)];
+            }
+        } else if (tie_rule == NEMGPU_TIE_LIBC) {
+            int eq[kMaxK]; int ne = 0; eq[0] = kmax;
+            for (int kk = kmax + 1; kk < k; kk++) if (row[kk] == u) eq[++ne] = kk;
+            if (ne > 0) {
+                if (!rng_ready) { for (long t = 0; t < draws_before; t++) (void)rng.next(); rng_ready = true; }
+                kmax = eq[rng.integer(0, ne)];                       // RandomInteger(0, nequal), nem_alg.c:635
             }
         }
         fprintf(fp, "%d ", kmax + 1);

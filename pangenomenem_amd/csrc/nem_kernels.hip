@@ -834,6 +834,11 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
     }
     c[C_FOLD] = f[FLAG_NZERO] > 0;
+    if (a.draw_ctl != nullptr) {                                  // TIE_LIBC: the sweep's draws move the stream on
+        const int nt = f[FLAG_NTIES] & ((1 << 30) - 1);
+        a.draw_ctl[0] += nt;
+        c[C_DRAWS] += nt;
+    }
     c[C_COMMITS] += 1;
     if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
         const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
@@ -921,6 +926,46 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0
 // solution, bit for bit.  Round r reads guess_r and writes out_r; rounds after the first
 // unchanged one exit immediately (prev_changed == 0).
 // ------------------------------------------------------------------------------------------
+// One site's row: ComputeLocalProba (nem_alg.c:2576-2613) from the class contexts.  cf = the normalised row;
+// returns true when the site hit the "density = 0" branch.
+template <int KA>
+__device__ __forceinline__ bool local_proba(const SweepArgs& a, int K, const double* pkf, const float* ctx, float* cf)
+{
+    double cinum[KA];
+    double cum = 0.0;
+#pragma unroll
+    for (int k = 0; k < KA; k++) {
+        if (k < K) {                                     // nem_alg.c:2581-2584
+            double v = pkf[k];
+            if (a.use_nei) v = v * exp((double)a.beta * (double)ctx[k]);
+            cinum[k] = v;
+            cum = cum + v;
+        }
+    }
+    if (cum > 0) {                                       // nem_alg.c:2589-2601
+        if (cum > kEpsilonD) {
+            const double invz = 1 / cum;
+#pragma unroll
+            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * cinum[k]);
+        } else {
+            const double invz = 1 / (cum / kEpsilonD);
+#pragma unroll
+            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * (cinum[k] / kEpsilonD));
+        }
+        return false;
+    }
+    const float u = (float)(1.0 / K);                    // nem_alg.c:2603-2607
+#pragma unroll
+    for (int k = 0; k < KA; k++) if (k < K) cf[k] = u;
+    return true;                                         // counted by the caller, once per block
+}
+
+// Labels are bytes: class in the low 7 bits; bit 7 = "this site's C-step drew a random number" (TIE_LIBC only), so
+// that a guess of the new partition carries the guess of who draws with it.
+constexpr int kLabMask = 0x7F, kLabDrew = 0x80;
+constexpr int kTabShort = 1 << 30;                       // in a round's FLAG_NTIES word: the draw table was too short
+constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
+
 template <int KT, bool NCEM, int BS>
 __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
 {
@@ -942,6 +987,8 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         return;
     }
     __shared__ int s_nzero, s_first;
+    __shared__ uint8_t s_lab[NCEM ? BS : 1];             // the block's labels while it iterates
+    __shared__ uint64_t s_drew[BS / 64];                 // TIE_LIBC: per wave, which of its sites drew
     const int i = blockIdx.x * BS + threadIdx.x;
     const bool active = i < a.n_local;
     const int gi = a.lo + (active ? i : 0);
@@ -951,119 +998,203 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     bool changed = false;
     // this site's own labels, requested with everything else at the head of the block: asked for where they are
     // used -- behind the label store, which they might alias -- they would be one more memory latency at the tail
-    int my_guess = 0, my_old = 0, my_new = 255;
-    if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi]; }
+    int my_guess = 0, my_old = 0, my_new = 255;           // my_guess: the whole byte; my_old: the class
+    if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi] & kLabMask; }
     if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
+    if (NCEM) s_lab[threadIdx.x] = (uint8_t)my_guess;
     __syncthreads();
-    if (active && !skip) {
 
+    if (NCEM) {
+    // ------------------------------------------------------------------------------------------
+    // NCEM.  A plain round would evaluate every site once against the guess.  Most Gauss-Seidel dependencies are
+    // index-adjacent (the contiguity path), i.e. inside the block: so the block goes on evaluating its sites against
+    // ITS OWN latest labels for the lower-indexed neighbours it holds (the guess for all others) until nothing in
+    // the block changes -- Jacobi steps on a lower-triangular system, final for the block's first t sites after t
+    // steps.  Exactness is untouched: the first step is the plain round, so the block reproduces its guess iff
+    // the plain round would, and the sweep still ends with a round that changes nothing anywhere.  What it buys is
+    // rounds: label changes run down the path inside one launch instead of one launch per hop.
+    // ------------------------------------------------------------------------------------------
+    const bool libc = a.tie_rule == NEMGPU_TIE_LIBC;
+    const int blk_lo = a.lo + blockIdx.x * BS;           // first label slot of this block
+    double pkf[KA];
+#pragma unroll
+    for (int k = 0; k < KA; k++) if (k < K) pkf[k] = active && !skip ? a.pkfki[(size_t)k * a.npad + i] : 0.0;
+    // the first four neighbours live in registers: index, weight, and the label when it cannot change in here
+    int nb = 0, ne = 0;
+    int dyn[4]; float wn[4]; int fl[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { dyn[u] = -1; wn[u] = 0.0f; fl[u] = 255; }
+    if (active && !skip && a.use_nei) {
+        nb = a.nei_ptr[i]; ne = a.nei_ptr[i + 1];
+        int jn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool ok = nb + u < ne;
+            jn[u] = ok ? a.nei_idx[nb + u] : gi;
+            wn[u] = ok ? a.nei_w[nb + u] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (nb + u < ne) {
+                if (jn[u] < gi && jn[u] >= blk_lo) dyn[u] = jn[u] - blk_lo;
+                else fl[u] = ((jn[u] < gi) ? a.lab_guess[jn[u]] : a.lab_old[jn[u]]) & kLabMask;
+            }
+        }
+    }
+    const bool long_row = ne - nb > 4;
+    int lower_draws = -1;                                // TIE_LIBC: draws of the blocks below this one (lazily)
+    bool tab_short = false;                              // TIE_LIBC: a draw fell outside the table: the round is void
+    int cur = my_guess;                                  // this site's byte in s_lab
+    int seen[4] = {-1, -1, -1, -1};                      // labels the last evaluation used for the dyn neighbours
+    uint64_t seen_drew = ~0ull; int seen_wave_draws = -1;
+    for (int it = 0; it < kInnerCap; it++) {
+        int below_in_block = 0;
+        uint64_t drew_lt = 0;
+        if (libc) {                                      // who drew, per wave (block-uniform branch)
+            const uint64_t bal = __ballot((s_lab[threadIdx.x] & kLabDrew) != 0);
+            if ((threadIdx.x & 63) == 0) s_drew[threadIdx.x >> 6] = bal;
+            __syncthreads();
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) below_in_block += (int)__popcll(s_drew[w]);
+            drew_lt = s_drew[threadIdx.x >> 6] & ((1ull << (threadIdx.x & 63)) - 1ull);
+        }
+        int nxt = cur;
+        if (active && !skip) {
+            int lab[4];
+            bool same = it > 0 && !long_row;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                lab[u] = dyn[u] >= 0 ? (s_lab[dyn[u]] & kLabMask) : fl[u];
+                same = same && (dyn[u] < 0 || lab[u] == seen[u]);
+            }
+            if (libc) same = same && drew_lt == seen_drew && below_in_block == seen_wave_draws;
+            if (!same) {
+                float ctx[KA];
+#pragma unroll
+                for (int k = 0; k < KA; k++) ctx[k] = 0.0f;
+                // (the adds keep the .nei order, SumNeighsOfClass nem_alg.c:2865-2875; w*1 = w, w*0: additive identity)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    seen[u] = lab[u];
+                    if (nb + u < ne) {
+#pragma unroll
+                        for (int k = 0; k < KA; k++)
+                            if (k < K) ctx[k] = ctx[k] + ((lab[u] == k) ? wn[u] : -0.0f);
+                    }
+                }
+                for (int t = nb + 4; t < ne; t++) {      // rows longer than four neighbours: from memory
+                    const int j = a.nei_idx[t];
+                    const float wt = a.nei_w[t];
+                    int l;
+                    if (j < gi && j >= blk_lo) l = s_lab[j - blk_lo] & kLabMask;
+                    else l = ((j < gi) ? a.lab_guess[j] : a.lab_old[j]) & kLabMask;
+#pragma unroll
+                    for (int k = 0; k < KA; k++)
+                        if (k < K) ctx[k] = ctx[k] + ((l == k) ? wt : -0.0f);
+                }
+                float cf[KA];
+                zero_density = local_proba<KA>(a, K, pkf, ctx, cf);
+                // ComputeMAP, nem_alg.c:603-640
+                int kmax = 0; float ukmax = cf[0];
+#pragma unroll
+                for (int k = 1; k < KA; k++) if (k < K && cf[k] > ukmax) { ukmax = cf[k]; kmax = k; }
+                int drew = 0;
+                if (a.tie_rule != NEMGPU_TIE_FIRST) {
+                    int nequal = 0;
+#pragma unroll
+                    for (int k = 1; k < KA; k++) if (k < K && k > kmax && cf[k] == ukmax) nequal++;
+                    if (nequal > 0) {
+                        uint32_t r;
+                        if (libc) {
+                            // the reference's stream (nem_rnd.c:53-61): this site's draw is number
+                            //   draws before the sweep + sites below it that drew in this sweep
+                            if (lower_draws < 0) {
+                                lower_draws = 0;
+                                for (int b = 0; b < (int)blockIdx.x; b++) lower_draws += a.tie_cnt_guess[b];
+                            }
+                            int base = a.draw_base, tab0 = a.draw_tab0;
+                            if (a.draw_ctl != nullptr) { base = a.draw_ctl[0]; tab0 = a.draw_ctl[1]; }
+                            if (a.draw_extra != nullptr) base += *a.draw_extra & (kTabShort - 1);
+                            const int at = base + lower_draws + below_in_block + (int)__popcll(drew_lt) - tab0;
+                            if (at >= 0 && at < a.draw_tab_len) r = a.draw_tab[at];
+                            else { r = 0; tab_short = true; }
+                            drew = kLabDrew;
+                        } else {
+                            const uint32_t sid = a.sweep_id_ptr != nullptr ? (uint32_t)*a.sweep_id_ptr : a.sweep_id;
+                            // the hash is keyed by the TRUE family index (label slots of a sharded run carry a flag tail per rank)
+                            const uint32_t site = a.slot_stride > 0 ? (uint32_t)(gi - (gi / a.slot_stride) * a.slot_pad) : (uint32_t)gi;
+                            r = mix32(a.tie_seed, sid, site);
+                        }
+                        const int pick = (int)(r % (uint32_t)(nequal + 1));
+                        int seen_eq = 0, chosen = kmax;
+#pragma unroll
+                        for (int k = 1; k < KA; k++)
+                            if (k < K && k > kmax && cf[k] == ukmax) { seen_eq++; if (seen_eq == pick) chosen = k; }
+                        kmax = chosen;
+                    }
+                }
+                nxt = kmax | drew;
+                seen_drew = drew_lt; seen_wave_draws = below_in_block;
+            }
+        }
+        __syncthreads();                                 // every read of s_lab / s_drew of this step is done
+        const bool moved_now = nxt != cur;
+        cur = nxt;
+        s_lab[threadIdx.x] = (uint8_t)cur;
+        if (!__syncthreads_or(moved_now)) break;
+    }
+    if (active && !skip) {
+        changed = (cur != my_guess) || tab_short;         // (a void round never passes for the fixed point)
+        my_new = cur & kLabMask;
+        a.lab_out[gi] = (uint8_t)cur;
+        if (tab_short) atomicOr(&a.flags[FLAG_NTIES], kTabShort);
+    }
+    if (libc && !skip) {
+        // the block's draws of this round, next to the labels they belong to: a guess is (labels, counts)
+        const uint64_t bal = __ballot(active && (cur & kLabDrew) != 0);
+        if ((threadIdx.x & 63) == 0) s_drew[threadIdx.x >> 6] = bal;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cnt = 0;
+            for (int w = 0; w < BS / 64; w++) cnt += (int)__popcll(s_drew[w]);
+            if (cnt != a.tie_cnt_guess[blockIdx.x]) changed = true;
+            a.tie_cnt_out[blockIdx.x] = cnt;
+            if (cnt > 0) atomicAdd(&a.flags[FLAG_NTIES], cnt);
+        }
+    }
+    } else if (active && !skip) {
+    // ------------------------------------------------------------------------------------------
+    // fuzzy NEM: one evaluation of every site against the guess
+    // ------------------------------------------------------------------------------------------
     float ctx[KA];
-    double cinum[KA];
+    double pkf[KA];
 #pragma unroll
     for (int k = 0; k < KA; k++) ctx[k] = 0.0f;
     // the densities do not depend on the graph: requested first, so that they travel while the neighbour lists do
 #pragma unroll
-    for (int k = 0; k < KA; k++) if (k < K) cinum[k] = a.pkfki[(size_t)k * a.npad + i];
-
+    for (int k = 0; k < KA; k++) if (k < K) pkf[k] = a.pkfki[(size_t)k * a.npad + i];
     if (a.use_nei) {
         const int b = a.nei_ptr[i], e = a.nei_ptr[i + 1];
-        if (NCEM) {
-            // four neighbours per trip: index and weight loads together, then the label gathers together (the adds
-            // keep the .nei order, SumNeighsOfClass nem_alg.c:2865-2875)
-            for (int t = b; t < e; t += 4) {
-                int jn[4]; float wn[4]; int ln[4];
+        for (int t = b; t < e; t++) {
+            const int j = a.nei_idx[t];
+            const float wt = a.nei_w[t];
+            const float* row = ((j < gi) ? a.c_guess : a.c_old) + (size_t)j * K;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool ok = t + u < e;
-                    jn[u] = ok ? a.nei_idx[t + u] : gi;
-                    wn[u] = ok ? a.nei_w[t + u] : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) ln[u] = (jn[u] < gi) ? a.lab_guess[jn[u]] : a.lab_old[jn[u]];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (t + u < e) {
-#pragma unroll
-                        for (int k = 0; k < KA; k++)
-                            if (k < K) ctx[k] = ctx[k] + ((ln[u] == k) ? wn[u] : -0.0f);   // w*1 = w ; w*0: additive identity
-                    }
-                }
-            }
-        } else {
-            for (int t = b; t < e; t++) {
-                const int j = a.nei_idx[t];
-                const float wt = a.nei_w[t];
-                const float* row = ((j < gi) ? a.c_guess : a.c_old) + (size_t)j * K;
-#pragma unroll
-                for (int k = 0; k < KA; k++)
-                    if (k < K) ctx[k] = ctx[k] + (wt * row[k]);
-            }
-        }
-    }
-
-    double cum = 0.0;
-#pragma unroll
-    for (int k = 0; k < KA; k++) {
-        if (k < K) {                                     // nem_alg.c:2581-2584
-            double v = cinum[k];
-            if (a.use_nei) v = v * exp((double)a.beta * (double)ctx[k]);
-            cinum[k] = v;
-            cum = cum + v;
+            for (int k = 0; k < KA; k++)
+                if (k < K) ctx[k] = ctx[k] + (wt * row[k]);
         }
     }
     float cf[KA];
-    if (cum > 0) {                                       // nem_alg.c:2589-2601
-        if (cum > kEpsilonD) {
-            const double invz = 1 / cum;
+    zero_density = local_proba<KA>(a, K, pkf, ctx, cf);
+    const float* g = a.c_guess + (size_t)gi * K;
+    float* o = a.c_out + (size_t)gi * K;
 #pragma unroll
-            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * cinum[k]);
-        } else {
-            const double invz = 1 / (cum / kEpsilonD);
-#pragma unroll
-            for (int k = 0; k < KA; k++) if (k < K) cf[k] = (float)(invz * (cinum[k] / kEpsilonD));
-        }
-    } else {                                             // nem_alg.c:2603-2607
-        const float u = (float)(1.0 / K);
-#pragma unroll
-        for (int k = 0; k < KA; k++) if (k < K) cf[k] = u;
-        zero_density = true;                             // counted by the caller, once per block
-    }
-
-    if (NCEM) {                                          // ComputeMAP, nem_alg.c:603-640
-        int kmax = 0; float ukmax = cf[0];
-#pragma unroll
-        for (int k = 1; k < KA; k++) if (k < K && cf[k] > ukmax) { ukmax = cf[k]; kmax = k; }
-        if (a.tie_rule == NEMGPU_TIE_HASH) {
-            int nequal = 0;
-#pragma unroll
-            for (int k = 1; k < KA; k++) if (k < K && k > kmax && cf[k] == ukmax) nequal++;
-            if (nequal > 0) {
-                const uint32_t sid = a.sweep_id_ptr != nullptr ? (uint32_t)*a.sweep_id_ptr : a.sweep_id;
-                // the hash is keyed by the TRUE family index (label slots of a sharded run carry a flag tail per rank)
-                const uint32_t site = a.slot_stride > 0 ? (uint32_t)(gi - (gi / a.slot_stride) * a.slot_pad) : (uint32_t)gi;
-                int pick = (int)(mix32(a.tie_seed, sid, site) % (uint32_t)(nequal + 1));
-                int seen = 0, chosen = kmax;
-#pragma unroll
-                for (int k = 1; k < KA; k++)
-                    if (k < K && k > kmax && cf[k] == ukmax) { seen++; if (seen == pick) chosen = k; }
-                kmax = chosen;
-            }
-        }
-        changed = (kmax != my_guess);
-        my_new = kmax;
-        a.lab_out[gi] = (uint8_t)kmax;
-    } else {
-        const float* g = a.c_guess + (size_t)gi * K;
-        float* o = a.c_out + (size_t)gi * K;
-#pragma unroll
-        for (int k = 0; k < KA; k++) {
-            if (k < K) {
-                changed |= (__float_as_uint(cf[k]) != __float_as_uint(g[k]));
-                o[k] = cf[k];
-            }
+    for (int k = 0; k < KA; k++) {
+        if (k < K) {
+            changed |= (__float_as_uint(cf[k]) != __float_as_uint(g[k]));
+            o[k] = cf[k];
         }
     }
-    }   // active
+    }
     if (__any(changed) && (threadIdx.x & 63) == 0 && a.flags[FLAG_CHANGED] == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
     // zero-density sites (nem_alg.c:2603-2613): count and first index, one pair of atomics per block
     const uint64_t zmask = __ballot(zero_density);
@@ -1086,7 +1217,7 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
         if (active) {
             // (a round that skipped its sites and posts its own output reads that output back: not a case the
             //  engine enqueues, the verification round posts its guess)
-            lab = a.post_from_guess ? my_guess : (my_new != 255 ? my_new : (int)a.lab_out[gi]);
+            lab = a.post_from_guess ? (my_guess & kLabMask) : (my_new != 255 ? my_new : ((int)a.lab_out[gi] & kLabMask));
             if (a.post_moved) moved = (lab != my_old);
         }
         const int wave = i >> 6;
@@ -1148,7 +1279,7 @@ __global__ void k_moved_global(int n_true, int blk, int stride, const uint8_t* _
     int moved = 0;
     if (f < n_true) {
         const size_t slot = (size_t)(f / blk) * stride + (f % blk);
-        moved = lab_new[slot] != lab_old[slot];
+        moved = (lab_new[slot] & 0x7F) != (lab_old[slot] & 0x7F);
     }
     if (__any(moved) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
     if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
@@ -1182,8 +1313,8 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
         const int i = wave * 64 + lane;
         int lab = 255, moved = 0;
         if (i < n_local) {
-            lab = lab_new[lo + i];
-            if (lab_old != nullptr) moved = (lab != (int)lab_old[lo + i]);
+            lab = lab_new[lo + i] & 0x7F;                    // (bit 7: the site drew, TIE_LIBC)
+            if (lab_old != nullptr) moved = (lab != ((int)lab_old[lo + i] & 0x7F));
         }
         for (int k = 0; k < K; k++) {
             uint64_t m = __ballot(lab == k);
@@ -1774,7 +1905,7 @@ __global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* _
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * K) return;
     const int i = (int)(t / K), k = (int)(t - (size_t)i * K);
-    c[t] = (lab[i] == k) ? 1.0f : 0.0f;
+    c[t] = ((lab[i] & 0x7F) == k) ? 1.0f : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -12,7 +12,8 @@ constexpr int kTicketWords = 32 * 33;   // last-block ticket: top counter + 32 g
 constexpr double kEpsilonD = 1e-20;   // EPSILON, reference nem_typ.h:63
 
 // per-round flag slot of an E2 sweep
-enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_ROUND_STRIDE = 4 };
+// FLAG_NTIES (TIE_LIBC): random draws the round's sites made; bit 30: a draw fell outside the draw table
+enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_NTIES = 3, FLAG_ROUND_STRIDE = 4 };
 // per-iteration flag block.  FLAG_EMPTYK is overwritten by every k_mstep_disp; FLAG_MOVED and the
 // relaxation-round window that follows this block are zeroed by k_density, which precedes every
 // sweep of the EM loop (so no memset launches are needed).
@@ -22,7 +23,7 @@ enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 
 // C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
 // zero-density sites" (how the next sweeps tally them, see k_sweep); it survives a restart.
 enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
-       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_WORDS = 16 };
+       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_WORDS = 16 };
 
 struct CtrlArgs {
     int* ctrl; const int* iter_flags; const int* round0; const int* round1;
@@ -34,6 +35,7 @@ struct CtrlArgs {
     const uint8_t* q_flags; const uint8_t* r_flags; int n_ranks, flag_stride;
     int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
     const int* blind;              // is_init: flag slot of the blind beta = 0 sweep (its zero-density tally), or nullptr
+    int* draw_ctl;                 // TIE_LIBC: {draws made so far, first draw of the table} (device), else nullptr
 };
 void launch_ctrl(const CtrlArgs& a, hipStream_t s);
 
@@ -66,6 +68,14 @@ struct SweepArgs {
     uint8_t* publish_byte; int* publish_ticket;
     // zero-density tally of a large grid (see k_sweep): last-block counters to fold it through, or nullptr
     int* fold_ticket;
+    // TIE_LIBC (the reference's own tie stream, nem_alg.c:617-637 -> nem_rnd.c:53-61): the site that ties draws
+    // random() number  draws before the sweep + sites below it that drew in this sweep.  draw_tab holds draws
+    // draw_tab0 .. draw_tab0 + draw_tab_len - 1 of the stream; draws-before-the-sweep and draw_tab0 come from
+    // draw_ctl[0..1] (device, pipelined loop) or by value; draw_extra: a count to add (a preceding sweep's draws
+    // that no loop control has booked yet).  tie_cnt_*: draws per block of the guess / of this round's output.
+    const uint32_t* draw_tab; int draw_tab_len, draw_base, draw_tab0;
+    const int* draw_ctl; const int* draw_extra;
+    const int* tie_cnt_guess; int* tie_cnt_out;
 };
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
                          const int* stop, const CtrlArgs* ctrl, hipStream_t s);

@@ -16,7 +16,7 @@ ALGO = {"nem": 0, "ncem": 1}
 DISP = {"s__": 0, "sk_": 1, "s_d": 2, "skd": 3}
 PROP = {"p_": 0, "pk": 1}
 CVT = {"none": 0, "clas": 1}
-TIE = {"first": 1, "hash": 2}
+TIE = {"libc": 0, "first": 1, "hash": 2}
 STATUS_OK, STATUS_W_EMPTYCLASS, STATUS_E_DEVICE = 0, 2, 9
 
 
@@ -33,7 +33,8 @@ class Config(C.Structure):
 class Result(C.Structure):
     _fields_ = [("status", C.c_int), ("iters", C.c_int), ("converged", C.c_int), ("emptyk", C.c_int),
                 ("zero_density_sites", C.c_int), ("first_zero_density_site", C.c_int),
-                ("sweep_rounds", C.c_int), ("crit", C.c_float * 6), ("loop_seconds", C.c_double)]
+                ("sweep_rounds", C.c_int), ("crit", C.c_float * 6), ("loop_seconds", C.c_double),
+                ("tie_draws", C.c_int)]
 
 
 _lib = None
@@ -190,7 +191,7 @@ class NemEngine:
         return dict(status=r.status, iters=r.iters, converged=bool(r.converged), emptyk=r.emptyk,
                     n_zero_density=r.zero_density_sites, first_zero_density_site=r.first_zero_density_site,
                     sweep_rounds=r.sweep_rounds, crit=np.array(list(r.crit), np.float32),
-                    loop_seconds=r.loop_seconds)
+                    loop_seconds=r.loop_seconds, tie_draws=r.tie_draws)
 
     def run(self):
         r = Result()

@@ -145,6 +145,33 @@ def test_random_starts_match_oracle(gpu_lib, oracle, n, d, k, algo, disper, star
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,k,starts,seed", [(600, 6, 3, 6, 21), (1500, 4, 4, 5, 8)])
+def test_random_starts_with_the_reference_tie_stream(gpu_lib, oracle, reference, n, d, k, starts, seed):
+    """INIT_RANDOM with TieRule = TIE_RANDOM as in the reference: the starts' centre draws and the C-steps' tie draws
+    are ONE random() stream (few organisms => many identical families => many ties), so every start's draws depend
+    on how many ties the starts before it met.  Engine == oracle == the compiled reference, draw for draw."""
+    from pangenomenem_amd.engine import NemEngine
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed, p=(0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, seed)
+    eng = NemEngine(n, d, k)
+    eng.set_matrix(x)
+    eng.set_graph(nei)
+    eng.configure(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=20, tie="libc", seed=seed)
+    got = eng.run_random(n_starts=starts, rng_seed=seed)
+    want = oracle.run_random(x, nei, k, n_starts=starts, rng_seed=seed, algo="ncem", disper="sk_", beta=0.5, it_max=20,
+                             tie="libc")
+    ref = reference.classify_random(x, nei, k, n_starts=starts, rng_seed=seed, algo="ncem", disper="sk_", beta=0.5,
+                                    it_max=20)
+    assert got["tie_draws"] > starts * k                     # ties did draw
+    for other in (want, ref):
+        assert got["status"] == other["status"] and got["best_start"] == other["best_start"]
+        assert np.array_equal(got["c"], other["c"])
+        assert np.array_equal(got["center"], other["center"])
+        for key in ("disp", "prop"):
+            assert maxdiff(got[key], other[key]) <= TOL, key
+    eng.close()
+
+
 def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
     # D > 32768: the class masks of the uniform chain no longer fit its LDS staging, every class takes the general
     # chain; K = 32 is the engine's maximum

@@ -54,7 +54,7 @@ def random_problem(seed):
     cfg = dict(algo=str(rng.choice(["ncem", "nem"])), beta=float(rng.choice([0.0, 0.3, 1.0, 2.5])),
                disper=str(rng.choice(["sk_", "skd", "s__", "s_d"])), propor=str(rng.choice(["pk", "p_"])),
                it_max=int(rng.choice([0, 1, 3, 7, 15])), param_fix=bool(rng.random() < 0.15),
-               tie=str(rng.choice(["hash", "first"])), seed=int(rng.integers(0, 1000)))
+               tie=str(rng.choice(["hash", "first", "libc"])), seed=int(rng.integers(0, 1000)))
     return x, nei, k, prop, center, disp.astype(np.float32), cfg
 
 
@@ -112,8 +112,8 @@ def test_random_large_problem(gpu_lib, oracle, seed):
     assert np.array_equal(got["center"], want["center"]), ctx
 
 
-@pytest.mark.parametrize("n,d", [(12000, 2800), (66000, 2800)])
-def test_every_density_underflows(gpu_lib, oracle, n, d):
+@pytest.mark.parametrize("n,d,tie", [(12000, 2800, "hash"), (66000, 2800, "hash"), (12000, 2800, "libc")])
+def test_every_density_underflows(gpu_lib, oracle, n, d, tie):
     """Wide matrices drive every density to zero (exp(-dk) underflows): every site takes the uniform-posterior
     branch of nem_alg.c:2603-2613 and is counted.  Grids of 47 (256-site) and 65 (1024-site) blocks: the tally
     goes through the last-block counters from the second sweep on, and must still equal the reference's."""
@@ -122,7 +122,8 @@ def test_every_density_underflows(gpu_lib, oracle, n, d):
     x, _ = synth.bernoulli_pa_matrix(n, d, 5)
     nei = synth.contiguity_graph(n, 5)
     prop, center, disp = synth.default_init(d)
-    cfg = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=3, tie="hash", seed=3)
+    # (tie = libc: every site of every sweep draws from the reference's stream -- the draw table slides batch by batch)
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=3, tie=tie, seed=3)
     want = oracle.run(x, nei, 3, prop, center, disp, **cfg)
     got = solve(x, nei, 3, prop, center, disp, **cfg)
     assert want["n_zero_density"] > n // 2               # the regime this test is about
