@@ -43,7 +43,7 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 namespace {
 constexpr int kRoundCap = 64;     // relaxation rounds per flag window
-constexpr int kRoundBatch = 2;    // rounds enqueued between host checks (round 0 + its verification)
+constexpr int kRoundBatchMax = 4;
 }  // namespace
 
 struct nemgpu_engine {
@@ -124,6 +124,9 @@ struct nemgpu_engine {
     hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
     uint8_t graph_asked[2][3][8] = {};   // how often a batch shape was enqueued before it got a graph
     bool use_graphs = true;
+    // relaxation rounds enqueued per sweep before anybody looks (round 0, its verification, and one more that costs
+    // an early-exit launch when it is not needed and a host round trip when it is missing); NEM_MI355X_ROUNDS=2..4
+    int round_batch = 3;
     bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
     int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
@@ -407,7 +410,8 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         c.a.stop = e->stop_ptr;
         c.a.post_on = 0;
         if (c.post && ncem && r0 == 0 && b == count - 1) {
-            c.a.post_on = 1; c.a.post_from_guess = (r > 0) ? 1 : 0; c.a.post_moved = c.post_moved ? 1 : 0;
+            // (the sweep's final labels are in buffer Q, the out buffer of even rounds)
+            c.a.post_on = 1; c.a.post_from_guess = (r % 2 == 1) ? 1 : 0; c.a.post_moved = c.post_moved ? 1 : 0;
             c.a.post_nw64 = e->nw64; c.a.post_mask = e->mask; c.a.post_flags = e->iter_flags(); c.a.post_ctrl = c.post_ctrl;
         }
         launch_sweep(c.a, ncem, e->stream);
@@ -438,7 +442,7 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
     }
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
-    return sweep_launch_rounds(e, c, c.multi ? kRoundBatch : 1);
+    return sweep_launch_rounds(e, c, c.multi ? e->round_batch : 1);
 }
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
@@ -468,14 +472,14 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
             if (rr) return rr;
             sweep_draw_args(e, c.a, true);
         }
-        if (c.r % kRoundCap == 0 || c.r % kRoundCap + kRoundBatch > kRoundCap) {
+        if (c.r % kRoundCap == 0 || c.r % kRoundCap + e->round_batch > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
             HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * FLAG_ROUND_STRIDE * sizeof(int), e->stream));
             while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
             c.checked = c.r;
         }
-        int rr = sweep_launch_rounds(e, c, kRoundBatch);
+        int rr = sweep_launch_rounds(e, c, e->round_batch);
         if (rr) return rr;
     }
     // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
@@ -593,9 +597,9 @@ int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id)
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = sc.use_nei ? 1 : 0;
     a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id; a.sweep_id_ptr = nullptr;
-    sc.r = 2; sc.checked = 2;
+    sc.r = e->round_batch; sc.checked = e->round_batch;   // (the enqueued rounds all changed something)
     if (e->libc()) {
-        if ((e->h_round(0)[FLAG_NTIES] | e->h_round(1)[FLAG_NTIES]) & (1 << 30)) e->tie_heavy = true;
+        for (int q = 0; q < e->round_batch; q++) if (e->h_round(q)[FLAG_NTIES] & (1 << 30)) e->tie_heavy = true;
         int r = ensure_draw_window(e, e->draws, draw_need(e));
         if (r) return r;
         sweep_draw_args(e, a, true);
@@ -641,7 +645,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     SweepCtx c;
     e->sweep_counter = sweep_id;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->round_batch;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -680,7 +684,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->round_batch;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -793,7 +797,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             e->n_host_rounds++;
             SweepCtx sc;
             if ((r = host_rounds_ctx(e, sc, 1u))) return r;
-            if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
+            if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
             if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
             e->sweep_rounds += 1;                                  // + the blind sweep
             e->cur = 2; e->sweep_counter = 2;
@@ -821,7 +825,7 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
             e->n_host_rounds++;
             SweepCtx sc;
             if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1)))) return r;
-            if ((r = sweep_launch_rounds(e, sc, kRoundBatch))) return r;
+            if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
             int rounds = 0;
             if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
             HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
@@ -976,6 +980,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     e->cfg.cvtest = NEMGPU_CV_CLAS; e->cfg.cvthres = 1e-8f; e->cfg.it_max = 100; e->cfg.param_fix = 0;
     e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
     if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
+    if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     ParkedSet parked{-1, nullptr, nullptr, nullptr};
@@ -1578,7 +1583,7 @@ int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, con
     if (!e || !labels_old_dev || !labels_q_dev || !labels_r_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.round1 = e->round_flags(1);
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = 2;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = beta != 0.0f ? 1 : 0; ca.cvtest = e->cfg.cvtest; ca.ncem = 1;
     ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.q_flags = labels_q_dev + e->sh_blk; ca.r_flags = labels_r_dev + e->sh_blk;

@@ -797,22 +797,29 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     if (a.is_init) *a.sweep_next = 2;                             // sweeps 0 and 1 are the two initial ones
     else { c[C_ITERS] += 1; *a.sweep_next += 1; }                 // the tie-break hash is keyed by the sweep number
     const int emptyk = a.iter_flags[FLAG_EMPTYK];
-    int ch0 = a.round0[FLAG_CHANGED], ch1 = a.round1[FLAG_CHANGED];
-    if (a.q_flags != nullptr) {                                   // sharded: any rank's flag byte
-        ch0 = 0; ch1 = 0;
+    // which of the enqueued relaxation rounds changed nothing (= the sweep's fixed point)?  -1: none of them
+    const int nr = a.n_rounds > 0 ? a.n_rounds : 2;
+    int last = -1;
+    if (!a.use_nei) last = 0;                                     // one round, nothing to verify
+    else if (a.q_flags != nullptr) {                              // sharded: any rank's flag byte, two rounds
+        int ch0 = 0, ch1 = 0;
         for (int r = 0; r < a.n_ranks; r++) ch0 |= a.q_flags[(size_t)r * a.flag_stride];
         if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
+        last = !ch0 ? 0 : (!ch1 ? 1 : -1);
+    } else {
+        for (int r = 0; r < nr; r++)
+            if (a.round0[r * FLAG_ROUND_STRIDE + FLAG_CHANGED] == 0) { last = r; break; }
     }
+    const int* f = a.round0 + (last > 0 ? last : 0) * FLAG_ROUND_STRIDE;
     if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
         if (a.blind != nullptr && a.blind[FLAG_NZERO] > 0) {      // the blind sweep's zero-density sites come first
             c[C_NZERO] += a.blind[FLAG_NZERO];
             if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = a.blind[FLAG_FIRSTZERO];
         }
-        if (a.use_nei && ch0 != 0 && ch1 != 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
-        const int* fi = (a.use_nei && ch0 != 0) ? a.round1 : a.round0;
-        c[C_SWEEP_ROUNDS] += (a.use_nei && ch0 != 0) ? 3 : 2;     // blind sweep + this one
-        if (fi[FLAG_NZERO] > 0) { c[C_NZERO] += fi[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = fi[FLAG_FIRSTZERO]; }
-        c[C_FOLD] = fi[FLAG_NZERO] > 0;                           // how the next sweeps tally such sites, see k_sweep
+        if (last < 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
+        c[C_SWEEP_ROUNDS] += last + 2;                            // blind sweep + this one
+        if (f[FLAG_NZERO] > 0) { c[C_NZERO] += f[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO]; }
+        c[C_FOLD] = f[FLAG_NZERO] > 0;                            // how the next sweeps tally such sites, see k_sweep
         return;
     }
     const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -822,13 +829,8 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         c[C_STOP] = 1;
         return;
     }
-    const int* f = a.round0;
-    int rounds = 1;
-    if (a.use_nei && ch0 != 0) {
-        if (ch1 != 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
-        f = a.round1; rounds = 2;
-    }
-    c[C_SWEEP_ROUNDS] += rounds;
+    if (last < 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
+    c[C_SWEEP_ROUNDS] += last + 1;
     if (f[FLAG_NZERO] > 0) {
         c[C_NZERO] += f[FLAG_NZERO];
         if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];

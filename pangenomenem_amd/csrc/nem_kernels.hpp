@@ -26,7 +26,8 @@ enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPT
        C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_WORDS = 16 };
 
 struct CtrlArgs {
-    int* ctrl; const int* iter_flags; const int* round0; const int* round1;
+    int* ctrl; const int* iter_flags; const int* round0;   // round0: flag slot of relaxation round 0 (round r: r slots on)
+    int n_rounds;                  // relaxation rounds enqueued per sweep (0: two)
     int param_fix, use_nei, cvtest, ncem; float cvthres;
     int* sweep_next;               // device word: number of the next sweep (tie-break hash key)
     int* ticket;                   // last-block-done counter (self-resetting)
