@@ -140,6 +140,15 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg);
 /* Whole run: INIT_PARAM_FILE start + EM loop + final criteria (single-GPU engines only). */
 int nemgpu_run(nemgpu_engine* e, nemgpu_result* res);
 
+/* Several whole runs (nemgpu_run each) in LOCK STEP: every step of the EM -- M-step counts, density, relaxation
+   rounds, criteria -- is ONE launch for all `count` problems (problem = blockIdx.z; every loop kernel has a twin that
+   reads an array of argument blocks), and the host synchronises once per batch of iterations for everybody.  What
+   PPanGGOLiN's chunk loop (ppanggolin.py:1045-1086) needs: many independent problems of one kind, each far too small
+   to fill the chip.  The engines must be complete (matrix, graph, parameters, configuration), whole problems, on one
+   device; sizes and configurations may differ (members whose launch sequences differ are grouped).  Each problem's
+   result is bit-identical to its nemgpu_run.  results: `count` entries. */
+int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results);
+
 /* Whole run from random starts (the reference's init_mode = INIT_RANDOM, RandNemAlgo nem_alg.c:1574-1742): n_starts
    starts (the reference uses 50), centres drawn from the data with the reference's generator -- glibc random()
    after srandom(seed), restated in csrc/nem_rng.hpp -- best start by criterion M, EstimPara on the best partition.

@@ -2,15 +2,19 @@
 
 PPanGGOLiN partitions pangenomes of more than 500 organisms by solving many 500-organism chunks and voting
 (ppanggolin/ppanggolin.py:995-1097); the reference runs them in a multiprocessing.Pool because its nem() is
-neither re-entrant nor thread-safe.  A 20 000 x 500 problem fills a fraction of an MI355X (one wave per SIMD in
-the density kernel, launch-bound everywhere else), so the native way to run chunks is concurrently, one engine
-and one HIP stream per worker thread of a single process: the text parsing of the workers runs on different host
-cores (the C ABI releases the GIL), their kernels interleave on the GPU.  This library's nem() keeps no global
-state, so the same works through the drop-in entry point.
+neither re-entrant nor thread-safe.  One 20 000 x 500 problem fills a fraction of an MI355X (one wave per SIMD in
+the density kernel, launch-bound everywhere else), so the native way to run chunks is as ONE batch on the device:
+
+  * ``solve_many``  -- the in-memory route: every problem gets its engine (uploads on ``workers`` host threads), then
+    ``nemgpu_run_many`` runs all EM loops in LOCK STEP: each step of the loop -- M-step counts, density, relaxation
+    rounds, criteria -- is one launch for all problems (problem = blockIdx.z), one host synchronisation per batch
+    of iterations for everybody.  ``group`` bounds how many problems share a launch.
+  * ``nem_many``    -- the drop-in route (five ASCII files per problem): nem() keeps no global state, so the calls
+    run on worker threads, text parsing on different host cores, kernels interleaved on the GPU.
 """
 from concurrent.futures import ThreadPoolExecutor
 
-from .engine import solve
+from .engine import NemEngine, run_many
 from .nem import nem
 
 
@@ -20,7 +24,32 @@ def nem_many(calls, workers=8):
         return list(pool.map(lambda kw: nem(**kw), calls))
 
 
-def solve_many(problems, workers=8, **cfg):
-    """In-memory variant: problems = [(x, nei, k, prop, center, disp), ...]; returns the list of solve() results."""
+def _build(problem, device, cfg):
+    x, nei, k, prop, center, disp = problem
+    eng = NemEngine(x.shape[0], x.shape[1], k, device=device)
+    try:
+        eng.set_matrix(x)
+        eng.set_graph(nei)
+        eng.set_params(prop, center, disp)
+        eng.configure(**cfg)
+    except Exception:
+        eng.close()
+        raise
+    return eng
+
+
+def solve_many(problems, workers=8, group=64, device=0, **cfg):
+    """problems = [(x, nei, k, prop, center, disp), ...]; returns their solve() results, each bit-identical to the
+    problem solved alone.  workers: host threads building the engines (bit-packing and uploads); group: problems
+    per lock-step batch."""
+    out = []
+    group = max(1, int(group))
     with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
-        return list(pool.map(lambda p: solve(*p, **cfg), problems))
+        for g0 in range(0, len(problems), group):
+            engines = list(pool.map(lambda p: _build(p, device, cfg), problems[g0:g0 + group]))
+            try:
+                out.extend(run_many(engines))
+            finally:
+                for e in engines:
+                    e.close()
+    return out

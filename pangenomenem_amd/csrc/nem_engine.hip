@@ -147,12 +147,18 @@ struct nemgpu_engine {
     // Device memory comes from a few large zeroed chunks (one hipMalloc + one fill each) that buffers are carved
     // from and that live as long as the engine: a nem() call creates and destroys an engine, and ~50 hipMalloc /
     // fill / hipFree triples were a fifth of its time at configs[1].
-    struct Chunk { char* base; size_t size, used; };
+    struct Chunk { char* base; size_t size, used; bool owned = true; };
     std::vector<Chunk> chunks;
     int shared_chunk = -1;                     // the chunk small buffers are carved from
     uint8_t* best_lab = nullptr; float* best_c = nullptr;   // nemgpu_run_random: the best start's partition
     uint32_t* xf_stage = nullptr;                            // nemgpu_set_matrix_bits: upload staging (small matrices)
     bool ctrl_pending = false; CtrlArgs ctrl_deferred{};     // loop control left to the next iteration's counts launch
+    // lock-step batches (iterate_many): a state-only twin of another engine -- matrix, graph and draw table are the
+    // parent's, everything it allocates is carved from a slab the parent owns
+    nemgpu_engine* parent = nullptr;
+    bool carve_all = false;
+    bool flags_host_borrowed = false;
+    char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;   // argument blocks of the zipped launches (lead engine)
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -216,6 +222,12 @@ int dev_alloc(T** p, size_t count)
     if (count == 0) count = 1;
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
     int r;
+    if (e->carve_all && e->shared_chunk >= 0 && e->chunks[e->shared_chunk].size - e->chunks[e->shared_chunk].used >= bytes) {
+        nemgpu_engine::Chunk& c = e->chunks[e->shared_chunk];
+        *p = reinterpret_cast<T*>(c.base + c.used);
+        c.used += bytes;
+        return NEMGPU_OK;
+    }
     if (bytes >= kChunkOwn) {
         if ((r = chunk_new(e, bytes))) return r;
         e->chunks.back().used = bytes;
@@ -324,7 +336,8 @@ struct SweepCtx {
 
 int clear_sweep_flags(nemgpu_engine* e)
 {
-    HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
+    if (current_recorder()) launch_fill(e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, 0, e->stream);
+    else HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
     e->flags_clean = true;
     return NEMGPU_OK;
 }
@@ -386,6 +399,11 @@ void sweep_draw_args(nemgpu_engine* e, SweepArgs& a, bool by_value)
 // the device words the pipelined loop reads the stream position from (outside any graph capture)
 int publish_draw_ctl(nemgpu_engine* e)
 {
+    if (current_recorder()) {
+        launch_fill(e->draw_ctl, 1, e->draws, e->stream);
+        launch_fill(e->draw_ctl + 1, 1, (int)e->draw_tab0, e->stream);
+        return NEMGPU_OK;
+    }
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->draw_ctl, e->draws, 1, e->stream));
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(e->draw_ctl + 1), (int)e->draw_tab0, 1, e->stream));
     return NEMGPU_OK;
@@ -447,14 +465,17 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
 // batch read a partition that was not final yet and must be redone by the caller).
-int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra)
+int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, bool flags_ready = false)
 {
     int done_at = -1;
     if (extra) *extra = false;
     for (;;) {
-        HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
-                              e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        if (!flags_ready) {                                  // (a lock-step batch has fetched every member's flags already)
+            HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
+                                  e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        flags_ready = false;
         if (!c.multi) { done_at = 0; break; }
         bool tab_short = false;
         for (int q = c.checked; q < c.r; q++) {
@@ -541,6 +562,8 @@ int read_iter_flags(nemgpu_engine* e)
 int reset_device(nemgpu_engine* e);
 int reset_state(nemgpu_engine* e);
 void drop_graphs(nemgpu_engine* e);
+int criteria_enqueue(nemgpu_engine* e, int buf);
+void fill_result(nemgpu_engine* e, nemgpu_result* res);
 
 // ComputePartitionFromPara(Needinit = 1), nem_alg.c:1967-1981
 int init_partition(nemgpu_engine* e)
@@ -700,40 +723,198 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     return NEMGPU_OK;
 }
 
-int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
+// ---- TIE_LIBC start: the two initial sweeps draw from ONE stream, the blind one first, so each is completed (its
+// rounds verified from the host, its draws booked) before the next is enqueued.  Three enqueue steps with a host step
+// after the first two; recordable like everything else.
+int libc_init_a(nemgpu_engine* e, SweepCtx& c)
 {
     int r;
+    FinishArgs t = finish_args(e, 0, nullptr);                 // initial parameters back in place, loop control cleared, tables
+    t.reset_prop = e->prop0; t.reset_center = e->center0; t.reset_disp = e->disp0;
+    t.reset_ctrl = e->ctrl(); t.reset_ctrl_words = C_WORDS; t.reset_sweep_next = e->sweep_next;
+    launch_finish(t, e->stream);
+    e->tables_fresh = true; e->density_fresh = false;
+    e->cur = 0; e->sweep_counter = 0;
+    if ((r = do_density(e))) return r;
+    return sweep_enqueue(e, 0.0f, c);                          // blind sweep 0 -> 1
+}
+int libc_init_b(nemgpu_engine* e, SweepCtx& c)
+{
+    e->cur = 1;
+    return sweep_enqueue(e, e->cfg.beta, c);                   // 1 -> 2
+}
+int libc_init_c(nemgpu_engine* e)
+{
+    int r;
+    e->cur = 2;
+    e->masks_valid = false;
+    if ((r = do_labels_post(e, 2, -1))) return r;
+    launch_fill(e->sweep_next, 1, (int)e->sweep_counter, e->stream);
+    return NEMGPU_OK;
+}
+
+// ---- one batch of the pipelined loop, in three pieces so that the same code drives ONE engine (iterate) or SEVERAL
+// in lock step (iterate_many: the pieces' launches are recorded per engine and issued once for all of them) ----------
+struct LoopCursor {
+    int remaining = 0;            // iterations still allowed
+    bool first = false;           // the next batch starts with the restart + the two initial sweeps
+    // the batch in flight
+    int g = 0, base = 0; uint32_t sweep0 = 0; bool batch_first = false;
+    bool active() const { return remaining > 0 || first; }
+};
+
+// host half of a restart (the device half is the head of the first batch)
+int loop_begin(nemgpu_engine* e, LoopCursor& lc, int n_iters, bool with_init)
+{
+    int r;
+    lc = LoopCursor();
+    lc.remaining = n_iters; lc.first = with_init;
     if (with_init) {
         if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
         if ((r = ensure_state_buffers(e))) return r;
-        // host half of a restart (the device half is the head of the first batch)
         e->cur = 0; e->sweep_counter = 0;
         e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
         e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
     }
-    bool first = with_init;
-    if (first && e->libc()) {
-        // TIE_LIBC: the two initial sweeps draw from the same stream one after the other (the blind one first), so they
-        // run from the host, sweep by sweep; the iterations behind them are pipelined as usual
-        if ((r = reset_device(e))) return r;
-        e->tables_fresh = false; e->density_fresh = false;
-        if ((r = init_partition(e))) return r;
-        first = false;
+    return NEMGPU_OK;
+}
+bool loop_wants_batch(const nemgpu_engine* e, const LoopCursor& lc)
+{
+    return lc.active() && !e->converged && e->status == NEMGPU_OK;
+}
+
+// what the next batch is; the state every batch may rely on (issued / recorded ahead of it)
+int batch_plan(nemgpu_engine* e, LoopCursor& lc)
+{
+    int r;
+    lc.g = std::min(lc.remaining, kPipeDepth);
+    lc.batch_first = lc.first;
+    lc.base = lc.first ? 2 : e->cur;
+    lc.sweep0 = lc.first ? 2u : e->sweep_counter;
+    // class masks of the current labels, fresh tables when the parameters are fixed (otherwise k_finish rebuilds them
+    // inside the batch)
+    if (!lc.first) {
+        if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+        if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
     }
-    while ((n_iters > 0 || first) && !e->converged && e->status == NEMGPU_OK) {
-        const int g = std::min(n_iters, kPipeDepth);
-        const int base = first ? 2 : e->cur;
-        const uint32_t sweep0 = first ? 2u : e->sweep_counter;
-        // state every captured batch may rely on: class masks of the current labels, fresh tables when the
-        // parameters are fixed (otherwise k_finish rebuilds them inside the batch)
-        if (!first) {
-            if (e->ncem() && !e->cfg.param_fix && !e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
-            if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
+    if (e->libc()) {
+        if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;      // (may drop the graphs)
+        if ((r = publish_draw_ctl(e))) return r;
+    }
+    return NEMGPU_OK;
+}
+
+// the batch's launches (issued, captured or recorded by the caller's choice), ending with the copy of the control block
+int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
+{
+    int r = NEMGPU_OK;
+    e->ctrl_pending = false;                               // (a batch never inherits a deferred loop control)
+    hipError_t herr = hipSuccess;
+    if (!lc.batch_first) {                                 // (the restart launch clears the loop control itself)
+        if (current_recorder()) launch_fill(e->ctrl(), C_WORDS, 0, e->stream);
+        else herr = hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
+    }
+    e->stop_ptr = e->ctrl() + C_STOP;
+    if (lc.batch_first && herr == hipSuccess) r = enqueue_init(e, lc.g > 0);
+    for (int j = 0; j < lc.g && r == NEMGPU_OK && herr == hipSuccess; j++)
+        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g);
+    e->stop_ptr = nullptr;
+    if (herr == hipSuccess && r == NEMGPU_OK && with_copy)
+        herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    if (r) return r;
+    HIPCHK(herr);
+    return NEMGPU_OK;
+}
+
+// after the batch has run (stream synchronised, control block on the host): account for it, finish from the host what
+// the pipeline could not
+int batch_finish(nemgpu_engine* e, LoopCursor& lc)
+{
+    int r;
+    const int* c = e->h_ctrl();
+    const int done = c[C_ITERS], commits = c[C_COMMITS];
+    const bool first = lc.batch_first;
+    const int base = lc.base;
+    const uint32_t sweep0 = lc.sweep0;
+    e->iters += done;
+    e->draws += c[C_DRAWS];
+    e->sweep_rounds += c[C_SWEEP_ROUNDS];
+    if (c[C_NZERO] > 0) {
+        e->zero_density += c[C_NZERO];
+        if (e->first_zero < 0) e->first_zero = e->n_total - c[C_FIRSTZERO];
+    }
+    e->flags_clean = false;
+    e->tables_fresh = e->cfg.param_fix;                        // (the fused density kernel does not rebuild the table buffers)
+    if (e->ncem()) e->masks_valid = true;
+    if (first && c[C_NEED_ROUNDS] == 2) {
+        // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after the enqueued rounds; every
+        // iteration behind it returned at the stop word.  Finish it from the host, then go on.
+        e->cur = 1;
+        e->n_host_rounds++;
+        SweepCtx sc;
+        if ((r = host_rounds_ctx(e, sc, 1u))) return r;
+        if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
+        if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
+        e->sweep_rounds += 1;                                  // + the blind sweep
+        e->cur = 2; e->sweep_counter = 2;
+        e->masks_valid = false;
+        if (e->ncem()) { if ((r = do_labels_post(e, 2, -1))) return r; }
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, 2, 1, e->stream));
+        lc.first = false;
+        return NEMGPU_OK;
+    }
+    lc.first = false;
+    e->cur = (base + commits) % 3;
+    e->sweep_counter = sweep0 + (uint32_t)done;
+    lc.remaining -= done;
+    if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
+        e->status = NEMGPU_W_EMPTYCLASS;
+        e->emptyk = c[C_EMPTYK];
+        e->masks_valid = false;                                // the speculative E-step rebuilt them for a discarded partition
+        return NEMGPU_OK;
+    }
+    if (c[C_CONVERGED]) { e->converged = 1; return NEMGPU_OK; }
+    if (c[C_NEED_ROUNDS]) {
+        // iteration #commits of this batch ran its M-step, density and the enqueued relaxation rounds and is
+        // not at the fixed point yet: continue its rounds from the host, then redo the bookkeeping.
+        const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
+        e->n_host_rounds++;
+        SweepCtx sc;
+        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1)))) return r;
+        if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
+        int rounds = 0;
+        if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
+        HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
+        if ((r = post_sweep(e, newbuf, oldbuf))) return r;
+        if ((r = read_iter_flags(e))) return r;
+        e->cur = newbuf;
+        if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
+            const int moved = e->h_iter()[FLAG_MOVED];
+            if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
+            else e->converged = !moved;
         }
-        if (e->libc()) {
-            if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;      // (may drop the graphs)
-            if ((r = publish_draw_ctl(e))) return r;
-        }
+    }
+    return NEMGPU_OK;
+}
+
+int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
+{
+    int r;
+    LoopCursor lc;
+    if ((r = loop_begin(e, lc, n_iters, with_init))) return r;
+    if (lc.first && e->libc()) {
+        // TIE_LIBC: the two initial sweeps run from the host, sweep by sweep; the iterations behind them are pipelined
+        SweepCtx c;
+        if ((r = libc_init_a(e, c)) || (r = sweep_complete(e, c, nullptr, nullptr))) return r;
+        if ((r = libc_init_b(e, c)) || (r = sweep_complete(e, c, nullptr, nullptr))) return r;
+        if ((r = libc_init_c(e))) return r;
+        HIPCHK(hipGetLastError());
+        lc.first = false;
+    }
+    while (loop_wants_batch(e, lc)) {
+        if ((r = batch_plan(e, lc))) return r;
+        const int g = lc.g, base = lc.base;
+        const bool first = lc.batch_first;
         bool graphed = e->use_graphs && g < 8;
         hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
         // the first batch of a shape goes out as plain launches: capturing and instantiating a graph costs more than
@@ -742,104 +923,209 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         if (exec == nullptr) {
             if (graphed) e->n_captured++; else e->n_plain++;
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            r = NEMGPU_OK;
-            e->ctrl_pending = false;                               // (a batch never inherits a deferred loop control)
-            hipError_t herr = first ? hipSuccess                   // (the restart launch clears the loop control itself)
-                                    : hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream);
-            e->stop_ptr = e->ctrl() + C_STOP;
-            if (first && herr == hipSuccess) r = enqueue_init(e, g > 0);
-            for (int j = 0; j < g && r == NEMGPU_OK && herr == hipSuccess; j++)
-                r = enqueue_iteration(e, (base + j) % 3, sweep0 + j, j + 1 < g);
-            e->stop_ptr = nullptr;
-            if (herr == hipSuccess && r == NEMGPU_OK)
-                herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost,
-                                      e->stream);
+            r = batch_enqueue(e, lc, true);
             if (graphed) {
                 hipGraph_t graph = nullptr;
                 hipError_t cerr = hipStreamEndCapture(e->stream, &graph);
-                if (herr == hipSuccess && r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr &&
+                if (r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr &&
                     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     e->graphs[first ? 1 : 0][base][g] = exec;
                 } else {
                     exec = nullptr;
                     e->n_captured--;
                     e->use_graphs = false;                         // fall back to plain launches for good
-                    if (herr == hipSuccess && cerr != hipSuccess) herr = cerr;
+                    if (r == NEMGPU_OK && cerr != hipSuccess) { set_error(std::string("graph capture failed: ") + hipGetErrorString(cerr)); }
                 }
                 if (graph) (void)hipGraphDestroy(graph);
-                if (exec == nullptr && r == NEMGPU_OK && herr == hipSuccess) {   // redo this batch ungraphed
-                    e->sweep_counter = sweep0;
+                if (exec == nullptr && r == NEMGPU_OK) {           // redo this batch ungraphed
+                    e->sweep_counter = lc.sweep0;
                     if (first) e->cur = 0;
                     continue;
                 }
             }
             if (r) return r;
-            HIPCHK(herr);
         }
         if (exec != nullptr) { HIPCHK(hipGraphLaunch(exec, e->stream)); e->n_replayed++; }
         HIPCHK(hipStreamSynchronize(e->stream));
-        const int* c = e->h_ctrl();
-        const int done = c[C_ITERS], commits = c[C_COMMITS];
-        e->iters += done;
-        e->draws += c[C_DRAWS];
-        e->sweep_rounds += c[C_SWEEP_ROUNDS];
-        if (c[C_NZERO] > 0) {
-            e->zero_density += c[C_NZERO];
-            if (e->first_zero < 0) e->first_zero = e->n_total - c[C_FIRSTZERO];
-        }
-        e->flags_clean = false;
-        e->tables_fresh = e->cfg.param_fix;                        // (the fused density kernel does not rebuild the table buffers)
-        if (e->ncem()) e->masks_valid = true;
-        if (first && c[C_NEED_ROUNDS] == 2) {
-            // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after two rounds; every
-            // iteration behind it returned at the stop word.  Finish it from the host, then go on.
-            e->cur = 1;
-            e->n_host_rounds++;
-            SweepCtx sc;
-            if ((r = host_rounds_ctx(e, sc, 1u))) return r;
-            if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
-            if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
-            e->sweep_rounds += 1;                                  // + the blind sweep
-            e->cur = 2; e->sweep_counter = 2;
-            e->masks_valid = false;
-            if (e->ncem()) { if ((r = do_labels_post(e, 2, -1))) return r; }
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->sweep_next, 2, 1, e->stream));
-            first = false;
-            continue;
-        }
-        first = false;
-        e->cur = (base + commits) % 3;
-        e->sweep_counter = sweep0 + (uint32_t)done;
-        n_iters -= done;
-        if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
-            e->status = NEMGPU_W_EMPTYCLASS;
-            e->emptyk = c[C_EMPTYK];
-            e->masks_valid = false;                                // the speculative E-step rebuilt them for a discarded partition
-            break;
-        }
-        if (c[C_CONVERGED]) { e->converged = 1; break; }
-        if (c[C_NEED_ROUNDS]) {
-            // iteration #commits of this batch ran its M-step, density and relaxation rounds 0 and 1 and is
-            // not at the fixed point yet: continue its rounds from the host, then redo the bookkeeping.
-            const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
-            e->n_host_rounds++;
-            SweepCtx sc;
-            if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1)))) return r;
-            if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
-            int rounds = 0;
-            if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
-            HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
-            if ((r = post_sweep(e, newbuf, oldbuf))) return r;
-            if ((r = read_iter_flags(e))) return r;
-            e->cur = newbuf;
-            if (e->cfg.cvtest == NEMGPU_CV_CLAS) {
-                const int moved = e->h_iter()[FLAG_MOVED];
-                if (e->ncem()) e->converged = moved ? (1.0f < e->cfg.cvthres) : (0.0f < e->cfg.cvthres);
-                else e->converged = !moved;
-            }
-        }
+        if ((r = batch_finish(e, lc))) return r;
     }
     return NEMGPU_OK;
+}
+
+// ============================================================================================
+// Lock-step batches: B independent problems, ONE launch per step for all of them.
+// PPanGGOLiN solves many NEM problems of the same kind -- one per 500-organism chunk (ppanggolin.py:1045-1086),
+// fifty random starts of one problem in RandNemAlgo (nem_alg.c:1574-1742) -- and one problem of that size leaves
+// the chip >95 % empty.  Every engine of a batch runs the code it would run alone, with its launches RECORDED
+// (nem_kernels.hpp); the records of all members agree position by position (same kernels, own arguments), so each
+// position goes out once, problem = blockIdx.z, and the host synchronises once per batch for everybody.  Members
+// whose sequences differ (another batch length, a missing bookkeeping step) form groups of their own.
+// ============================================================================================
+int zip_reserve(nemgpu_engine* lead, size_t bytes)
+{
+    if (lead->zip_cap >= bytes) return NEMGPU_OK;
+    HIPCHK(hipStreamSynchronize(lead->stream));
+    if (lead->zip_host) (void)hipHostFree(lead->zip_host);
+    if (lead->zip_dev) (void)hipFree(lead->zip_dev);
+    lead->zip_host = nullptr; lead->zip_dev = nullptr; lead->zip_cap = 0;
+    size_t cap = (size_t)1 << 20;
+    while (cap < bytes) cap *= 2;
+    HIPCHK(hipHostMalloc((void**)&lead->zip_host, cap));
+    HIPCHK(hipMalloc((void**)&lead->zip_dev, cap));
+    lead->zip_cap = cap;
+    return NEMGPU_OK;
+}
+
+// issue the recorded sequences of `members` (indices into recs / E) on the lead's stream
+int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const std::vector<int>& members)
+{
+    if (members.empty()) return NEMGPU_OK;
+    // groups of members with the same sequence of (kernel, variant, block, grid height)
+    std::vector<std::vector<int>> groups;
+    for (int m : members) {
+        bool placed = false;
+        for (auto& g : groups) {
+            const std::vector<OpRecord>& a = recs[g[0]].ops; const std::vector<OpRecord>& b = recs[m].ops;
+            bool same = a.size() == b.size();
+            for (size_t t = 0; same && t < a.size(); t++)
+                same = a[t].kind == b[t].kind && a[t].variant == b[t].variant && a[t].block == b[t].block && a[t].gy == b[t].gy &&
+                       a[t].nbytes == b[t].nbytes;
+            if (same) { g.push_back(m); placed = true; break; }
+        }
+        if (!placed) groups.push_back({m});
+    }
+    size_t total = 0;
+    for (const auto& g : groups)
+        for (const OpRecord& o : recs[g[0]].ops) total += ((size_t)((o.nbytes + 15) & ~15) + 16) * g.size() + 64;
+    int r = zip_reserve(lead, total);
+    if (r) return r;
+    struct Launch { int kind, variant, B, stride; size_t args_off, gx_off; unsigned max_gx, gy, block; };
+    std::vector<Launch> launches;
+    size_t off = 0;
+    for (const auto& g : groups) {
+        const int B = (int)g.size();
+        for (size_t t = 0; t < recs[g[0]].ops.size(); t++) {
+            const OpRecord& o0 = recs[g[0]].ops[t];
+            const int stride = (o0.nbytes + 15) & ~15;
+            Launch L{o0.kind, o0.variant, B, stride, off, 0, 0, o0.gy, o0.block};
+            for (int b = 0; b < B; b++) memcpy(lead->zip_host + off + (size_t)b * stride, recs[g[b]].ops[t].args, (size_t)o0.nbytes);
+            off += (size_t)B * stride;
+            L.gx_off = off;
+            int* gx = reinterpret_cast<int*>(lead->zip_host + off);
+            for (int b = 0; b < B; b++) { gx[b] = (int)recs[g[b]].ops[t].gx; L.max_gx = std::max(L.max_gx, recs[g[b]].ops[t].gx); }
+            off += ((size_t)B * sizeof(int) + 15) & ~(size_t)15;
+            launches.push_back(L);
+        }
+    }
+    if (off == 0) return NEMGPU_OK;
+    HIPCHK(hipMemcpyAsync(lead->zip_dev, lead->zip_host, off, hipMemcpyHostToDevice, lead->stream));
+    for (const Launch& L : launches)
+        launch_zipped(L.kind, L.variant, L.B, lead->zip_dev + L.args_off, L.stride, reinterpret_cast<const int*>(lead->zip_dev + L.gx_off),
+                      L.max_gx, L.gy, L.block, lead->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+// record `fn(engine)` for every member, issue the records zipped, fetch every member's flag block, wait
+template <typename F>
+int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, std::vector<Recorder>& recs, F&& fn, bool fetch_flags)
+{
+    if (members.empty()) return NEMGPU_OK;
+    nemgpu_engine* lead = E[0];
+    HIPCHK(hipStreamSynchronize(lead->stream));                // (the argument slab of the previous step is free again)
+    int r = NEMGPU_OK;
+    for (int m : members) {
+        recs[m].ops.clear();
+        set_recorder(&recs[m]);
+        r = fn(m);
+        set_recorder(nullptr);
+        if (r) return r;
+    }
+    if ((r = zip_and_launch(lead, recs, members))) return r;
+    if (fetch_flags)
+        for (int m : members)
+            HIPCHK(hipMemcpyAsync(E[m]->flags_host, E[m]->flags_dev, E[m]->flag_words() * sizeof(int), hipMemcpyDeviceToHost, lead->stream));
+    HIPCHK(hipStreamSynchronize(lead->stream));
+    return NEMGPU_OK;
+}
+
+// the EM loops of several engines in lock step (all on E[0]'s stream); L: their cursors after loop_begin
+int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
+{
+    int r;
+    const int B = (int)E.size();
+    std::vector<Recorder> recs((size_t)B);
+    std::vector<int> members;
+    // TIE_LIBC members: the two initial sweeps, completed one after the other (see libc_init_a)
+    members.clear();
+    for (int i = 0; i < B; i++) if (L[i].first && E[i]->libc()) members.push_back(i);
+    if (!members.empty()) {
+        std::vector<SweepCtx> ctx((size_t)B);
+        if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_a(E[m], ctx[m]); }, true))) return r;
+        for (int m : members) if ((r = sweep_complete(E[m], ctx[m], nullptr, nullptr, true))) return r;
+        if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_b(E[m], ctx[m]); }, true))) return r;
+        for (int m : members) if ((r = sweep_complete(E[m], ctx[m], nullptr, nullptr, true))) return r;
+        if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_c(E[m]); }, false))) return r;
+        for (int m : members) L[m].first = false;
+    }
+    for (;;) {
+        members.clear();
+        for (int i = 0; i < B; i++) if (loop_wants_batch(E[i], L[i])) members.push_back(i);
+        if (members.empty()) break;
+        r = lockstep(E, members, recs, [&](int m) {
+            int rr = batch_plan(E[m], L[m]);
+            if (rr == NEMGPU_OK) rr = batch_enqueue(E[m], L[m], false);
+            return rr;
+        }, true);
+        if (r) return r;
+        for (int m : members) { E[m]->n_plain++; if ((r = batch_finish(E[m], L[m]))) return r; }
+    }
+    return NEMGPU_OK;
+}
+
+// several whole runs (nemgpu_run) in lock step; every engine complete (matrix, graph, parameters, configuration), all on
+// one device.  They are run on E[0]'s stream for the duration.
+int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
+{
+    int r;
+    const int B = (int)E.size();
+    nemgpu_engine* lead = E[0];
+    std::vector<hipStream_t> own((size_t)B);
+    for (int i = 0; i < B; i++) {
+        if (E[i]->device != lead->device) { set_error("a batch lives on one device"); return NEMGPU_E_ARG; }
+        if (E[i]->lo != 0 || E[i]->hi != E[i]->n_total) { set_error("sharded engines cannot join a batch"); return NEMGPU_E_ARG; }
+        HIPCHK(hipStreamSynchronize(E[i]->stream));
+        own[i] = E[i]->stream;
+        E[i]->stream = lead->stream;
+    }
+    auto restore = [&]() { for (int i = 0; i < B; i++) E[i]->stream = own[i]; };
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<LoopCursor> L((size_t)B);
+    r = NEMGPU_OK;
+    for (int i = 0; i < B && r == NEMGPU_OK; i++) { E[i]->draws = 0; r = loop_begin(E[i], L[i], E[i]->cfg.it_max, true); }
+    if (r == NEMGPU_OK) r = iterate_many(E, L);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < B && r == NEMGPU_OK; i++) {
+        if (E[i]->iters == 0) {                                    // nem_alg.c:1845-1851
+            if ((r = do_mstep(E[i])) || (r = do_tables(E[i])) || (r = do_density(E[i]))) break;
+        }
+    }
+    if (r == NEMGPU_OK && results != nullptr) {
+        std::vector<Recorder> recs((size_t)B);
+        std::vector<int> all((size_t)B);
+        for (int i = 0; i < B; i++) all[i] = i;
+        r = lockstep(E, all, recs, [&](int m) { return criteria_enqueue(E[m], -1); }, false);
+        for (int i = 0; i < B && r == NEMGPU_OK; i++) {
+            fill_result(E[i], &results[i]);
+            results[i].loop_seconds = secs;
+            if (hipMemcpyAsync(results[i].crit, E[i]->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, lead->stream) != hipSuccess) {
+                set_error("criteria copy failed"); r = NEMGPU_E_DEVICE;
+            }
+        }
+        if (r == NEMGPU_OK && hipStreamSynchronize(lead->stream) != hipSuccess) { set_error("synchronisation failed"); r = NEMGPU_E_DEVICE; }
+    }
+    restore();
+    return r;
 }
 
 void drop_graphs(nemgpu_engine* e)
@@ -873,8 +1159,8 @@ const float* float_partition(nemgpu_engine* e, int buf)
     return e->c_onehot;
 }
 
-// ComputeCrit on the partition in buffer `buf` (default: the current one) with the current densities
-int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
+// ComputeCrit on the partition in buffer `buf` (default: the current one) with the current densities: the launches
+int criteria_enqueue(nemgpu_engine* e, int buf = -1)
 {
     int r;
     if (e->lo != 0 || e->hi != e->n_total) { set_error("criteria need the whole partition on one engine"); return NEMGPU_E_FUNCARG; }
@@ -883,7 +1169,13 @@ int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
     launch_criteria(e->n, e->k, e->npad, e->nei_ptr, e->nei_idx, e->nei_w, e->has_graph ? 1 : 0, e->cfg.beta, c,
                     e->pkfki, e->logpkfki, e->crit_dik, e->crit_gik, e->crit_lfi, e->crit_lzi, e->crit6_dev,
                     e->ncem() ? 1 : 0, e->stream);
-    HIPCHK(hipGetLastError());
+    if (!current_recorder()) HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
+{
+    int r;
+    if ((r = criteria_enqueue(e, buf))) return r;
     HIPCHK(hipMemcpyAsync(crit6, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return NEMGPU_OK;
@@ -1048,9 +1340,11 @@ void nemgpu_destroy(nemgpu_engine* e)
         if (g_parked.size() < kParkMax) g_parked.push_back({e->device, e->stream, keep, e->flags_host});
         else keep = nullptr;
     }
-    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.base != keep) (void)hipFree(c.base);
+    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.base != keep && c.owned) (void)hipFree(c.base);
+    if (e->zip_host) (void)hipHostFree(e->zip_host);
+    if (e->zip_dev) (void)hipFree(e->zip_dev);
     if (!keep) {
-        if (e->flags_host) (void)hipHostFree(e->flags_host);
+        if (e->flags_host && !e->flags_host_borrowed) (void)hipHostFree(e->flags_host);
         if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1281,6 +1575,20 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
         if ((r = criteria(e, res->crit))) return r;                // nem_alg.c:1852
     }
     return NEMGPU_OK;
+}
+
+// Several whole runs in lock step: one launch per step of the EM for ALL of them (see "Lock-step batches" above).
+int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results)
+{
+    if (!engines || count <= 0) return NEMGPU_E_FUNCARG;
+    std::vector<nemgpu_engine*> E((size_t)count);
+    for (int i = 0; i < count; i++) {
+        if (!engines[i]) return NEMGPU_E_FUNCARG;
+        for (int j = 0; j < i; j++) if (engines[j] == engines[i]) { set_error("nemgpu_run_many: the same engine twice"); return NEMGPU_E_ARG; }
+        E[i] = engines[i];
+    }
+    HIPCHK(hipSetDevice(E[0]->device));
+    return run_many(E, results);
 }
 
 // INIT_RANDOM: RandNemAlgo (nem_alg.c:1574-1742).  InitPara's whole-sample dispersion (:1200-1281) is one M-step

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cstring>
+#include <type_traits>
 
 #include "nem_ff.hpp"
 #include "nem_chain.hpp"
@@ -459,7 +461,7 @@ struct DensityArgs {
     const int* perm;
 };
 
-__global__ __launch_bounds__(256) void k_density(DensityArgs a)
+__device__ __forceinline__ void density_body(const DensityArgs& a)
 {
     __shared__ double2 sT[DCH];
     __shared__ double sL[DCH];
@@ -554,7 +556,7 @@ struct FusedDensityArgs {
     const int* perm;
 };
 
-__global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
+__device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
 {
     __shared__ float sVal[FD_MAXD];                      // inertia per organism, later epsilon per organism
     __shared__ double2 sT[FD_CH];
@@ -769,18 +771,6 @@ __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a)
     density_store(a.perm, tile, tid, a.n, npad, k, dk, nul, pkd, logpk, a.pkfki, a.logpkfki);
 }
 
-void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
-                          int* zero_flags, int n_zero_flags, hipStream_t s)
-{
-    FusedDensityArgs a;
-    a.xw = (const uint4*)xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
-    a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
-    a.stats_ranks = t.stats_ranks; a.stats_rank_stride = t.stats_rank_stride;
-    a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
-    a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
-    a.use_ff = t.use_ff; a.perm = t.perm;
-    hipLaunchKernelGGL(k_density_fused, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
-}
 
 // ------------------------------------------------------------------------------------------
 // Device-side loop control (one thread, once per EM iteration).  The host enqueues several
@@ -969,7 +959,7 @@ constexpr int kTabShort = 1 << 30;                       // in a round's FLAG_NT
 constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
 
 template <int KT, bool NCEM, int BS>
-__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
 {
     int fold_hint = 0;
     if (a.stop != nullptr) {
@@ -1209,7 +1199,7 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     // D = 5000: 196 blocks x ~45 ns, 12 of a round's 26 us at 200 000 x 5 000).  Once the loop control has seen
     // such a sweep (ctrl[C_FOLD], set by ctrl_logic, read with the stop word) the tally rides on the last-block
     // counters instead.
-    const bool fold = fold_hint != 0 && a.fold_ticket != nullptr && gridDim.x > 32;
+    const bool fold = fold_hint != 0 && a.fold_ticket != nullptr && nblk > 32;
     if (threadIdx.x == 0 && s_nzero > 0) {
         if (!fold) atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
         if (a.flags[FLAG_FIRSTZERO] < s_first) atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);   // first site = n_total - max
@@ -1234,7 +1224,7 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     const bool post_ctrl = NCEM && a.post_on && a.post_ctrl.ctrl != nullptr;
     if (a.publish_byte != nullptr || post_ctrl || fold) {
         int* ticket = a.publish_byte != nullptr ? a.publish_ticket : (post_ctrl ? a.post_ctrl.ticket : a.fold_ticket);
-        if (last_block_ticket(ticket, gridDim.x, fold ? s_nzero : 0, fold ? &a.flags[FLAG_NZERO] : nullptr)) {
+        if (last_block_ticket(ticket, nblk, fold ? s_nzero : 0, fold ? &a.flags[FLAG_NZERO] : nullptr)) {
             if (a.publish_byte != nullptr)
                 *a.publish_byte = (uint8_t)(__hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
             if (post_ctrl) ctrl_logic(a.post_ctrl);
@@ -1242,33 +1232,7 @@ __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a)
     }
 }
 
-void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
-{
-    // large shards run 1024-site blocks: the per-block flag atomics (one address) are what a round costs when
-    // every site reports something (e.g. all densities underflow at D = 5000)
-    const bool big = a.n_local >= 65536;
-    dim3 grid((a.n_local + (big ? 1023 : 255)) / (big ? 1024 : 256)), block(big ? 1024 : 256);
-#define NEM_SW(KT_)                                                                            \
-    case KT_:                                                                                  \
-        if (big) {                                                                             \
-            if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true, 1024>), grid, block, 0, s, a);   \
-            else hipLaunchKernelGGL((k_sweep<KT_, false, 1024>), grid, block, 0, s, a);       \
-        } else {                                                                               \
-            if (ncem) hipLaunchKernelGGL((k_sweep<KT_, true, 256>), grid, block, 0, s, a);    \
-            else hipLaunchKernelGGL((k_sweep<KT_, false, 256>), grid, block, 0, s, a);        \
-        }                                                                                      \
-        break;
-    switch (a.K) {
-        NEM_SW(1) NEM_SW(2) NEM_SW(3) NEM_SW(4) NEM_SW(5) NEM_SW(6) NEM_SW(7) NEM_SW(8) NEM_SW(9) NEM_SW(10)
-    default:
-        grid = dim3((a.n_local + 255) / 256); block = dim3(256);
-        if (ncem) hipLaunchKernelGGL((k_sweep<0, true, 256>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_sweep<0, false, 256>), grid, block, 0, s, a);
-    }
-#undef NEM_SW
-}
 
-__global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
 
 // sharded runs: CVTEST_CLAS over the WHOLE (all-gathered) label array, so every rank takes the same decision
 // without another collective; slot t of true family f: (f / blk) * stride + f % blk
@@ -1296,22 +1260,21 @@ void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new
                        lab_old, flags, stop, ca);
 }
 
-void launch_ctrl(const CtrlArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a); }
 
 // ------------------------------------------------------------------------------------------
 // NCEM bookkeeping after a sweep: per-class membership bitmasks (for the popcount M-step) and
 // the CVTEST_CLAS flag (HasConverged, nem_alg.c:2075-2089: max|c - cold| is 1 iff a label moved).
 // ------------------------------------------------------------------------------------------
-__global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* __restrict__ lab_new,
+__device__ __forceinline__ void labels_post_body(int n_local, int lo, int K, int nw64, const uint8_t* __restrict__ lab_new,
                               const uint8_t* __restrict__ lab_old, uint64_t* __restrict__ mask,
-                              int* __restrict__ flags, const int* __restrict__ stop, CtrlArgs ca)
+                              int* __restrict__ flags, const int* __restrict__ stop, const CtrlArgs& ca, const int nblk)
 {
     if (stop != nullptr && *stop) return;
     const int lane = threadIdx.x & 63;
     // grid-stride over 64-family groups: the grid is capped (launch_labels_post) so that the last-block ticket
     // and the "moved" flag cost a bounded number of same-address atomics however many families there are
     int any_moved = 0;
-    for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < nw64; wave += (gridDim.x * blockDim.x) >> 6) {
+    for (int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < nw64; wave += (nblk * blockDim.x) >> 6) {
         const int i = wave * 64 + lane;
         int lab = 255, moved = 0;
         if (i < n_local) {
@@ -1325,15 +1288,15 @@ __global__ void k_labels_post(int n_local, int lo, int K, int nw64, const uint8_
         any_moved |= __any(moved);
     }
     if (any_moved && lane == 0 && flags[FLAG_MOVED] == 0) atomicOr(&flags[FLAG_MOVED], 1);
-    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
+    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, nblk)) ctrl_logic(ca);
 }
 
 // M1-M3 for NCEM as integer counts: S1[k][d] = #{i : label_i = k, x_id = 1}, N_k = #{label = k}.
 // grid = d + 1 blocks (the last one counts class sizes); out: stats[0..K) = N_k, stats[K + k*d + j] = S1.
 template <int R>
-__global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, const uint64_t* __restrict__ xt,
-                                                      const uint64_t* __restrict__ mask, int* __restrict__ stats,
-                                                      const int* __restrict__ stop, CtrlArgs prev_ctrl)
+__device__ __forceinline__ void mstep_counts_body(int K, int D, int nw64, const uint64_t* __restrict__ xt,
+                                                  const uint64_t* __restrict__ mask, int* __restrict__ stats,
+                                                  const int* __restrict__ stop, const CtrlArgs& prev_ctrl, const int nblk)
 {
     // R organism rows per block (row D = the all-ones row that counts the class sizes): each class-mask word is
     // loaded once for R rows, so the masks' L2 traffic (K * N/8 bytes per block) shrinks by R
@@ -1342,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_mstep_counts(int K, int D, int nw64, co
     // last sweep round left it to us -- there it costs a last-block ticket, two device-wide atomic round trips at the
     // tail of the launch; here it runs beside the counting blocks.  They have read the stop word before it can be
     // raised, so the counts of an iteration that will not happen are computed once for nothing.
-    if (prev_ctrl.ctrl != nullptr && blockIdx.x == gridDim.x - 1) {
+    if (prev_ctrl.ctrl != nullptr && (int)blockIdx.x == nblk - 1) {
         if (threadIdx.x == 0) ctrl_logic(prev_ctrl);
         return;
     }
@@ -1581,12 +1544,12 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
 // centres + inertia (NCEM, from the counts), dispersion + proportions, then the density tables
 // E1 reads.  K*D is small (1 500 at configs[1], 15 000 at configs[3]); the only long part is the
 // d-ordered float chain of the sk_/s__ models.
-__global__ __launch_bounds__(1024) void k_finish(FinishArgs a)
+__device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
 {
     const int tid = threadIdx.x;
     // grid = K blocks (one class each) for the class-separable dispersion models, else one block for all classes
-    const int kb = (gridDim.x > 1) ? blockIdx.x : 0;
-    const int ke = (gridDim.x > 1) ? kb + 1 : a.K;
+    const int kb = (nblk > 1) ? blockIdx.x : 0;
+    const int ke = (nblk > 1) ? kb + 1 : a.K;
     if (a.reset_prop != nullptr) {
         // restart: initial parameters back in place, loop control cleared (the stop word may still be set from
         // the run before; every later kernel of the batch reads it after this launch)
@@ -1735,7 +1698,7 @@ struct OwnWalk {
 
 // roles along blockIdx.x: [0,DB) in0, [DB,2DB) in1, [2DB,3DB) last zero of weight >= EPSILON,
 // [3DB,4DB) "some one has weight >= EPSILON", 4DB: N_k, 4DB+1: inertia for mu = 0.5
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+__device__ __forceinline__ void mstep_fuzzy_a_body(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
                                                       const uint64_t* __restrict__ xt, int nw64,
                                                       const float* __restrict__ c, float* __restrict__ nbobs_k,
                                                       float* __restrict__ in0_out, float* __restrict__ in1_out,
@@ -1803,7 +1766,7 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(int n, int npad, int K, in
     if (d < D) (role == 0 ? in0_out : in1_out)[k * D + d] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
+__device__ __forceinline__ void mstep_fuzzy_b_body(int n, int npad, int K, int D, const uint32_t* __restrict__ xw,
                                                       const uint64_t* __restrict__ xt, int nw64,
                                                       const float* __restrict__ c, const float* __restrict__ nbobs_k,
                                                       const float* __restrict__ in0, const float* __restrict__ in1,
@@ -1886,8 +1849,8 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(int n, int npad, int K, in
 }
 
 // CVTEST_CLAS for float partitions (nem_alg.c:2077-2088): converged iff no |c - cold| >= thres
-__global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float* __restrict__ cold, float thres,
-                             int* __restrict__ flags, const int* __restrict__ stop, CtrlArgs ca)
+__device__ __forceinline__ void conv_fuzzy_body(size_t m, const float* __restrict__ c, const float* __restrict__ cold, float thres,
+                             int* __restrict__ flags, const int* __restrict__ stop, const CtrlArgs& ca, const int nblk)
 {
     if (stop != nullptr && *stop) return;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1898,11 +1861,11 @@ __global__ void k_conv_fuzzy(size_t m, const float* __restrict__ c, const float*
         bad = (dif >= thres);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
-    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
+    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, nblk)) ctrl_logic(ca);
 }
 
 // labels -> one-hot float rows (LabelToClassVector, nem_alg.c:649-664)
-__global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* __restrict__ c)
+__device__ __forceinline__ void onehot_body(int n, int K, const uint8_t* __restrict__ lab, float* __restrict__ c)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * K) return;
@@ -1914,7 +1877,7 @@ __global__ void k_onehot(int n, int K, const uint8_t* __restrict__ lab, float* _
 // C1: criteria (ComputeCrit, nem_alg.c:2702-2751).  Per-site terms in parallel, then the four
 // i-ordered float accumulators (D, G, L, Z) on four lanes reading LDS-staged terms.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_crit_terms(int n, int K, int npad, const int* __restrict__ nei_ptr,
+__device__ __forceinline__ void crit_terms_body(int n, int K, int npad, const int* __restrict__ nei_ptr,
                                                     const int* __restrict__ nei_idx, const float* __restrict__ nei_w,
                                                     int use_nei, float beta, const float* __restrict__ c,
                                                     const double* __restrict__ pkfki,
@@ -2076,7 +2039,7 @@ __device__ inline void chain_window(ChainShared& s, int wn, int& burst)
 }
 
 // chain 0: D (sum of dik), 1: G (sum of gik), 2: L (sum of lfi), 3: Z (minus the sum of lzi); result to part[chain]
-__global__ __launch_bounds__(CH_T) void k_crit_reduce(int n, int K, const float* __restrict__ dik,
+__device__ __forceinline__ void crit_reduce_body(int n, int K, const float* __restrict__ dik,
                                                       const float* __restrict__ gik, const double* __restrict__ lfi,
                                                       const double* __restrict__ lzi, float* __restrict__ part)
 {
@@ -2098,7 +2061,7 @@ __global__ __launch_bounds__(CH_T) void k_crit_reduce(int n, int K, const float*
     if (threadIdx.x == 0) part[chain] = s.acc;
 }
 
-__global__ void k_crit_final(float beta, const float* __restrict__ part, float* __restrict__ crit6)
+__device__ __forceinline__ void crit_final_body(float beta, const float* __restrict__ part, float* __restrict__ crit6)
 {
     const float D = part[0], G = part[1], L = part[2], Z = part[3];
     crit6[0] = D; crit6[1] = G;
@@ -2152,11 +2115,184 @@ void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, in
     hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernels = the bodies above, twice: once with the argument block as a kernel parameter (one problem), once with an
+// array of argument blocks in device memory and the problem in blockIdx.z (B problems per launch).
+// ------------------------------------------------------------------------------------------
+#define NEM_B_HEAD(Args)                                                   \
+    const int p__ = blockIdx.z;                                            \
+    const int nblk = gx[p__];                                              \
+    if ((int)blockIdx.x >= nblk) return;                                   \
+    const Args a = *reinterpret_cast<const Args*>(reinterpret_cast<const char*>(arr) + (size_t)p__ * stride);
+
+__global__ __launch_bounds__(1024) void k_finish(FinishArgs a) { finish_body(a, gridDim.x); }
+__global__ __launch_bounds__(1024) void k_finish_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FinishArgs) finish_body(a, nblk); }
+__global__ __launch_bounds__(256) void k_density(DensityArgs a) { density_body(a); }
+__global__ __launch_bounds__(256) void k_density_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(DensityArgs) density_body(a); }
+__global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a) { density_fused_body(a); }
+__global__ __launch_bounds__(256) void k_density_fused_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FusedDensityArgs) density_fused_body(a); }
+template <int KT, bool NCEM, int BS>
+__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS>(a, gridDim.x); }
+template <int KT, bool NCEM, int BS>
+__global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS>(a, nblk); }
+__global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
+__global__ void k_ctrl_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CtrlArgs) ctrl_logic(a); }
+__global__ void k_labels_post(LabelsPostArgs a)
+{
+    labels_post_body(a.n_local, a.lo, a.K, a.nw64, a.lab_new, a.lab_old, a.mask, a.flags, a.stop, a.ca, gridDim.x);
+}
+__global__ void k_labels_post_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(LabelsPostArgs)
+    labels_post_body(a.n_local, a.lo, a.K, a.nw64, a.lab_new, a.lab_old, a.mask, a.flags, a.stop, a.ca, nblk);
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_mstep_counts(CountsArgs a)
+{
+    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, gridDim.x);
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_mstep_counts_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(CountsArgs)
+    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, nblk);
+}
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_a(FuzzyArgs a)
+{
+    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop);
+}
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_a_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(FuzzyArgs)
+    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop);
+}
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_b(FuzzyArgs a)
+{
+    mstep_fuzzy_b_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.center,
+                       a.iner, a.stop);
+}
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_b_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(FuzzyArgs)
+    mstep_fuzzy_b_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.center,
+                       a.iner, a.stop);
+}
+__global__ void k_conv_fuzzy(ConvFuzzyArgs a) { conv_fuzzy_body(a.m, a.c, a.cold, a.thres, a.flags, a.stop, a.ca, gridDim.x); }
+__global__ void k_conv_fuzzy_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(ConvFuzzyArgs)
+    conv_fuzzy_body(a.m, a.c, a.cold, a.thres, a.flags, a.stop, a.ca, nblk);
+}
+__global__ void k_onehot(OnehotArgs a) { onehot_body(a.n, a.K, a.lab, a.c); }
+__global__ void k_onehot_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(OnehotArgs) onehot_body(a.n, a.K, a.lab, a.c); }
+__global__ __launch_bounds__(256) void k_crit_terms(CritArgs a)
+{
+    crit_terms_body(a.n, a.K, a.npad, a.nei_ptr, a.nei_idx, a.nei_w, a.use_nei, a.beta, a.c, a.pkfki, a.logpkfki, a.dik, a.gik,
+                    a.lfi, a.lzi, a.hard);
+}
+__global__ __launch_bounds__(256) void k_crit_terms_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(CritArgs)
+    crit_terms_body(a.n, a.K, a.npad, a.nei_ptr, a.nei_idx, a.nei_w, a.use_nei, a.beta, a.c, a.pkfki, a.logpkfki, a.dik, a.gik,
+                    a.lfi, a.lzi, a.hard);
+}
+// (crit6 has room for the four partial results behind the six criteria)
+__global__ __launch_bounds__(CH_T) void k_crit_reduce(CritArgs a)
+{
+    crit_reduce_body(a.n, a.hard ? 1 : a.K, a.dik, a.gik, a.lfi, a.lzi, a.crit6 + 6);
+}
+__global__ __launch_bounds__(CH_T) void k_crit_reduce_b(const void* arr, int stride, const int* gx)
+{
+    NEM_B_HEAD(CritArgs)
+    crit_reduce_body(a.n, a.hard ? 1 : a.K, a.dik, a.gik, a.lfi, a.lzi, a.crit6 + 6);
+}
+__global__ void k_crit_final(CritArgs a) { crit_final_body(a.beta, a.crit6 + 6, a.crit6); }
+__global__ void k_crit_final_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CritArgs) crit_final_body(a.beta, a.crit6 + 6, a.crit6); }
+__device__ __forceinline__ void fill_body(const FillArgs& a)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.words; t += 256) a.ptr[t] = a.value;   // (one block)
+}
+__global__ void k_fill(FillArgs a) { fill_body(a); }
+__global__ void k_fill_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FillArgs) fill_body(a); }
+
+// ---- the recorder ----
+static thread_local Recorder* g_recorder = nullptr;
+void set_recorder(Recorder* r) { g_recorder = r; }
+Recorder* current_recorder() { return g_recorder; }
+
+template <typename Args>
+static bool record_op(int kind, int variant, dim3 grid, unsigned block, const Args& a)
+{
+    static_assert(sizeof(Args) <= kOpArgBytes, "argument block too large for an OpRecord");
+    static_assert(std::is_trivially_copyable<Args>::value, "argument blocks are copied byte for byte");
+    Recorder* r = g_recorder;
+    if (r == nullptr) return false;
+    r->ops.emplace_back();
+    OpRecord& o = r->ops.back();
+    o.kind = kind; o.variant = variant; o.gx = grid.x; o.gy = grid.y; o.block = block; o.nbytes = (int)sizeof(Args);
+    memcpy(o.args, &a, sizeof(Args));
+    return true;
+}
+
+static int sweep_variant(int K, bool ncem, bool big) { return (K >= 1 && K <= 10 ? K : 0) | (ncem ? 16 : 0) | (big ? 32 : 0); }
+
+template <bool BATCHED>
+static void sweep_dispatch(int variant, dim3 grid, hipStream_t s, const SweepArgs* a, const void* arr, int stride, const int* gx)
+{
+    const int kt = variant & 15; const bool ncem = (variant & 16) != 0, big = (variant & 32) != 0;
+    dim3 block(big ? 1024 : 256);
+#define NEM_SW2(KT_, NC_, BS_)                                                                                     \
+    do {                                                                                                           \
+        if (BATCHED) hipLaunchKernelGGL((k_sweep_b<KT_, NC_, BS_>), grid, block, 0, s, arr, stride, gx);          \
+        else hipLaunchKernelGGL((k_sweep<KT_, NC_, BS_>), grid, block, 0, s, *a);                                  \
+    } while (0)
+#define NEM_SW(KT_)                                                                                                \
+    case KT_:                                                                                                      \
+        if (big) { if (ncem) NEM_SW2(KT_, true, 1024); else NEM_SW2(KT_, false, 1024); }                           \
+        else { if (ncem) NEM_SW2(KT_, true, 256); else NEM_SW2(KT_, false, 256); }                                 \
+        break;
+    switch (kt) {
+        NEM_SW(1) NEM_SW(2) NEM_SW(3) NEM_SW(4) NEM_SW(5) NEM_SW(6) NEM_SW(7) NEM_SW(8) NEM_SW(9) NEM_SW(10)
+    default:
+        if (ncem) NEM_SW2(0, true, 256); else NEM_SW2(0, false, 256);
+    }
+#undef NEM_SW
+#undef NEM_SW2
+}
+
+void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
+{
+    // large shards run 1024-site blocks: the per-block flag atomics (one address) are what a round costs when
+    // every site reports something (e.g. all densities underflow at D = 5000)
+    const bool generic = !(a.K >= 1 && a.K <= 10);
+    const bool big = a.n_local >= 65536 && !generic;
+    const int bs = big ? 1024 : 256;
+    dim3 grid((a.n_local + bs - 1) / bs);
+    const int variant = sweep_variant(a.K, ncem, big);
+    if (record_op(OP_SWEEP, variant, grid, (unsigned)bs, a)) return;
+    sweep_dispatch<false>(variant, grid, s, &a, nullptr, 0, nullptr);
+}
+
+void launch_ctrl(const CtrlArgs& a, hipStream_t s)
+{
+    if (record_op(OP_CTRL, 0, dim3(1), 1, a)) return;
+    hipLaunchKernelGGL(k_ctrl, dim3(1), dim3(1), 0, s, a);
+}
+
+void launch_fill(int* ptr, int words, int value, hipStream_t s)
+{
+    FillArgs a{ptr, words, value};
+    if (record_op(OP_FILL, 0, dim3(1), 256, a)) return;
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, s, a);
+}
+
 void launch_finish(const FinishArgs& a, hipStream_t s)
 {
     // tables only (mode 0) and the models whose dispersion is per class (sk_, skd): one block per class
     const bool separable = a.mode == 0 || a.disper == NEMGPU_DISP_K_ || a.disper == NEMGPU_DISP_KD;
-    hipLaunchKernelGGL(k_finish, dim3(separable ? a.K : 1), dim3(1024), 0, s, a);
+    const dim3 grid(separable ? a.K : 1);
+    if (record_op(OP_FINISH, separable ? 1 : 0, grid, 1024, a)) return;
+    hipLaunchKernelGGL(k_finish, grid, dim3(1024), 0, s, a);
 }
 
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
@@ -2168,17 +2304,34 @@ void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, do
     a.uni = t.uni; a.nonuni = t.nonuni; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
     a.stop = t.stop; a.use_ff = t.use_ff; a.perm = t.perm;
-    hipLaunchKernelGGL(k_density, dim3(((npad / 256 + 7) / 8) * 8 * t.K), dim3(256), 0, s, a);
+    const dim3 grid(((npad / 256 + 7) / 8) * 8 * t.K);
+    if (record_op(OP_DENSITY, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_density, grid, dim3(256), 0, s, a);
+}
+
+void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
+                          int* zero_flags, int n_zero_flags, hipStream_t s)
+{
+    FusedDensityArgs a;
+    a.xw = (const uint4*)xw; a.n = n; a.npad = npad; a.dpad = t.dpad; a.D = t.D; a.K = t.K; a.n_total = t.n_total;
+    a.disper = t.disper; a.propor = t.propor; a.stats = t.stats;
+    a.stats_ranks = t.stats_ranks; a.stats_rank_stride = t.stats_rank_stride;
+    a.center = t.center; a.disp = t.disp; a.prop = t.prop; a.nbobs_k = t.nbobs_k; a.iter_flags = t.flags;
+    a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags; a.stop = t.stop;
+    a.use_ff = t.use_ff; a.perm = t.perm;
+    const dim3 grid(((npad / 256 + 7) / 8) * 8 * t.K);
+    if (record_op(OP_DENSITY_FUSED, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_density_fused, grid, dim3(256), 0, s, a);
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
                         uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s)
 {
-    CtrlArgs ca{};
-    if (ctrl != nullptr) ca = *ctrl;
-    const int blocks = std::min((nw64 * 64 + 255) / 256, 128);
-    hipLaunchKernelGGL(k_labels_post, dim3(blocks), dim3(256), 0, s, n_local, lo, K, nw64, lab_new, lab_old, mask,
-                       flags, stop, ca);
+    LabelsPostArgs a{n_local, lo, K, nw64, lab_new, lab_old, mask, flags, stop, CtrlArgs{}};
+    if (ctrl != nullptr) a.ca = *ctrl;
+    const dim3 grid(std::min((nw64 * 64 + 255) / 256, 128));
+    if (record_op(OP_LABELS_POST, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_labels_post, grid, dim3(256), 0, s, a);
 }
 
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
@@ -2186,11 +2339,14 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
 {
     // wide matrices: 4 organism rows per block (fewer re-reads of the class masks); narrow ones keep one row per
     // block so that the launch still spreads over the CUs
-    CtrlArgs ca{};
-    if (prev_ctrl != nullptr) ca = *prev_ctrl;
-    const int extra = ca.ctrl != nullptr ? 1 : 0;
-    if (D + 1 >= 1024) hipLaunchKernelGGL(k_mstep_counts<4>, dim3((D + 1 + 3) / 4 + extra), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop, ca);
-    else hipLaunchKernelGGL(k_mstep_counts<1>, dim3(D + 1 + extra), dim3(256), 0, s, K, D, nw64, xt, mask, stats, stop, ca);
+    CountsArgs a{K, D, nw64, xt, mask, stats, stop, CtrlArgs{}};
+    if (prev_ctrl != nullptr) a.prev_ctrl = *prev_ctrl;
+    const int extra = a.prev_ctrl.ctrl != nullptr ? 1 : 0;
+    const bool wide = D + 1 >= 1024;
+    const dim3 grid(wide ? (D + 1 + 3) / 4 + extra : D + 1 + extra);
+    if (record_op(OP_COUNTS, wide ? 4 : 1, grid, 256, a)) return;
+    if (wide) hipLaunchKernelGGL(k_mstep_counts<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_mstep_counts<1>, grid, dim3(256), 0, s, a);
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
@@ -2198,25 +2354,70 @@ void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const
                         float* iner, const int* stop, hipStream_t s)
 {
     const int DB = (D + 63) / 64;
-    hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1,
-                       inh_k, lastz, any1, stop);
-    hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k,
-                       lastz, any1, center, iner, stop);
+    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop};
+    if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
+    if (!record_op(OP_FUZZY_B, 0, dim3(DB, K), 64, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, a);
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
                        const CtrlArgs* ctrl, hipStream_t s)
 {
-    CtrlArgs ca{};
-    if (ctrl != nullptr) ca = *ctrl;
-    hipLaunchKernelGGL(k_conv_fuzzy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, c, cold, thres, flags,
-                       stop, ca);
+    ConvFuzzyArgs a{m, c, cold, thres, flags, stop, CtrlArgs{}};
+    if (ctrl != nullptr) a.ca = *ctrl;
+    const dim3 grid((unsigned)((m + 255) / 256));
+    if (record_op(OP_CONV_FUZZY, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_conv_fuzzy, grid, dim3(256), 0, s, a);
 }
 
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s)
 {
-    size_t m = (size_t)n * K;
-    hipLaunchKernelGGL(k_onehot, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, n, K, lab, c);
+    const size_t m = (size_t)n * K;
+    OnehotArgs a{n, K, lab, c};
+    const dim3 grid((unsigned)((m + 255) / 256));
+    if (record_op(OP_ONEHOT, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_onehot, grid, dim3(256), 0, s, a);
+}
+
+void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
+                     float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
+                     double* lfi, double* lzi, float* crit6, int hard, hipStream_t s)
+{
+    CritArgs a{n, K, npad, nei_ptr, nei_idx, nei_w, use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi, crit6, hard};
+    if (!record_op(OP_CRIT_TERMS, 0, dim3((n + 255) / 256), 256, a))
+        hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    if (!record_op(OP_CRIT_REDUCE, 0, dim3(4), CH_T, a))
+        hipLaunchKernelGGL(k_crit_reduce, dim3(4), dim3(CH_T), 0, s, a);
+    if (!record_op(OP_CRIT_FINAL, 0, dim3(1), 1, a))
+        hipLaunchKernelGGL(k_crit_final, dim3(1), dim3(1), 0, s, a);
+}
+
+void launch_zipped(int kind, int variant, int B, const void* arr, int stride, const int* gx, unsigned max_gx, unsigned gy,
+                   unsigned block, hipStream_t s)
+{
+    const dim3 grid(max_gx, gy, (unsigned)B), blk(block);
+    switch (kind) {
+    case OP_FINISH: hipLaunchKernelGGL(k_finish_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_DENSITY: hipLaunchKernelGGL(k_density_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_DENSITY_FUSED: hipLaunchKernelGGL(k_density_fused_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_SWEEP: sweep_dispatch<true>(variant, grid, s, nullptr, arr, stride, gx); break;
+    case OP_COUNTS:
+        if (variant == 4) hipLaunchKernelGGL(k_mstep_counts_b<4>, grid, blk, 0, s, arr, stride, gx);
+        else hipLaunchKernelGGL(k_mstep_counts_b<1>, grid, blk, 0, s, arr, stride, gx);
+        break;
+    case OP_LABELS_POST: hipLaunchKernelGGL(k_labels_post_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_CTRL: hipLaunchKernelGGL(k_ctrl_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_A: hipLaunchKernelGGL(k_mstep_fuzzy_a_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_B: hipLaunchKernelGGL(k_mstep_fuzzy_b_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_CONV_FUZZY: hipLaunchKernelGGL(k_conv_fuzzy_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_ONEHOT: hipLaunchKernelGGL(k_onehot_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_CRIT_TERMS: hipLaunchKernelGGL(k_crit_terms_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_CRIT_REDUCE: hipLaunchKernelGGL(k_crit_reduce_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_CRIT_FINAL: hipLaunchKernelGGL(k_crit_final_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FILL: hipLaunchKernelGGL(k_fill_b, grid, blk, 0, s, arr, stride, gx); break;
+    default: break;
+    }
 }
 
 // FETCH_SIZE calibration (MI355X_MICROARCH.md, HBM section): a read of a KNOWN byte count with E1's access
@@ -2235,17 +2436,6 @@ __global__ __launch_bounds__(256) void k_calib_read16(const uint4* __restrict__ 
 void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStream_t s)
 {
     hipLaunchKernelGGL(k_calib_read16, dim3(256 * 16), dim3(256), 0, s, (const uint4*)buf, words / 4, sink);
-}
-
-void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
-                     float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
-                     double* lfi, double* lzi, float* crit6, int hard, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_crit_terms, dim3((n + 255) / 256), dim3(256), 0, s, n, K, npad, nei_ptr, nei_idx, nei_w,
-                       use_nei, beta, c, pkfki, logpkfki, dik, gik, lfi, lzi, hard);
-    // (crit6 has room for the four partial results behind the six criteria)
-    hipLaunchKernelGGL(k_crit_reduce, dim3(4), dim3(CH_T), 0, s, n, hard ? 1 : K, dik, gik, lfi, lzi, crit6 + 6);
-    hipLaunchKernelGGL(k_crit_final, dim3(1), dim3(1), 0, s, beta, crit6 + 6, crit6);
 }
 
 }  // namespace nemk

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/nem_mi355x.h"
 
@@ -78,6 +79,42 @@ struct SweepArgs {
     const int* draw_ctl; const int* draw_extra;
     const int* tie_cnt_guess; int* tie_cnt_out;
 };
+// argument blocks of the kernels whose launch wrappers take scalars (the batched launches need them as structs)
+struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const uint8_t* lab_old; uint64_t* mask; int* flags;
+                        const int* stop; CtrlArgs ca; };
+struct CountsArgs { int K, D, nw64; const uint64_t* xt; const uint64_t* mask; int* stats; const int* stop; CtrlArgs prev_ctrl; };
+struct FuzzyArgs { int n, npad, K, D; const uint32_t* xw; const uint64_t* xt; int nw64; const float* c; float* nbobs_k;
+                   float* in0; float* in1; float* inh_k; int* lastz; int* any1; float* center; float* iner; const int* stop; };
+struct ConvFuzzyArgs { size_t m; const float* c; const float* cold; float thres; int* flags; const int* stop; CtrlArgs ca; };
+struct OnehotArgs { int n, K; const uint8_t* lab; float* c; };
+struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const float* nei_w; int use_nei; float beta;
+                  const float* c; const double* pkfki; const float* logpkfki; float* dik; float* gik; double* lfi; double* lzi;
+                  float* crit6; int hard; };
+struct FillArgs { int* ptr; int words; int value; };
+
+// ---- batched launches: B independent problems per launch ---------------------------------------------------------
+// Every loop kernel has a twin that takes an ARRAY of argument blocks in device memory and runs problem blockIdx.z
+// of it.  A host thread that sets a Recorder gets the launches of the code it then runs RECORDED instead of issued
+// (same argument blocks, same grids); the batch driver (nem_engine.hip) records one sequence per problem, checks that
+// the sequences agree launch for launch, and issues each position once for all problems with launch_zipped.
+enum OpKind { OP_FINISH = 1, OP_DENSITY, OP_DENSITY_FUSED, OP_SWEEP, OP_COUNTS, OP_LABELS_POST, OP_CTRL, OP_FUZZY_A, OP_FUZZY_B,
+              OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL };
+constexpr int kOpArgBytes = 512;
+struct OpRecord {
+    int kind, variant;             // variant: template instance / block size, part of what must agree across problems
+    unsigned gx, gy, block;
+    int nbytes;
+    alignas(16) unsigned char args[kOpArgBytes];
+};
+struct Recorder { std::vector<OpRecord> ops; };
+void set_recorder(Recorder* r);    // thread-local; nullptr: launches are issued
+Recorder* current_recorder();
+// position `kind`/`variant` for B problems: dev_args = B argument blocks `stride` bytes apart, dev_gx[B] = each
+// problem's own grid width (blocks beyond it return at once)
+void launch_zipped(int kind, int variant, int B, const void* dev_args, int stride, const int* dev_gx, unsigned max_gx,
+                   unsigned gy, unsigned block, hipStream_t s);
+void launch_fill(int* ptr, int words, int value, hipStream_t s);   // recordable memset of 32-bit words
+
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
                          const int* stop, const CtrlArgs* ctrl, hipStream_t s);
 

@@ -60,6 +60,7 @@ def load_library():
     lib.nemgpu_set_params.argtypes = [vp, vp, vp, vp]
     lib.nemgpu_configure.argtypes = [vp, C.POINTER(Config)]
     lib.nemgpu_run.argtypes = [vp, C.POINTER(Result)]
+    lib.nemgpu_run_many.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Result)]
     lib.nemgpu_run_random.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(Result), ip]
     lib.nemgpu_glibc_random.argtypes = [C.c_uint32, C.c_int, vp]
     lib.nemgpu_init_partition.argtypes = [vp]
@@ -355,6 +356,23 @@ class NemEngine:
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+
+def run_many(engines):
+    """nemgpu_run of several engines in lock step (one launch per EM step for all of them).  Returns their result
+    dicts, each identical to what engine.run() alone gives."""
+    if not engines:
+        return []
+    lib = engines[0].lib
+    handles = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    res = (Result * len(engines))()
+    engines[0]._chk(lib.nemgpu_run_many(handles, len(engines), res))
+    out = []
+    for e, r in zip(engines, res):
+        d = e._result(r)
+        d.update(e.results())
+        out.append(d)
+    return out
 
 
 def calibrate_fetch(nbytes=1 << 30, reps=3):
