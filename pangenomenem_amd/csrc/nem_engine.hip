@@ -100,6 +100,7 @@ struct nemgpu_engine {
     std::vector<uint32_t> draw_host; nemk::GlibcRandom draw_gen{1}; long draw_gen_pos = 0;
     int* draw_ctl = nullptr;
     int draws = 0; bool tie_heavy = false;
+    bool draw_borrowed = false;          // the table is the parent's (lock-step random starts): never written through this engine
     bool libc() const { return cfg.algo == NEMGPU_ALGO_NCEM && cfg.tie_rule == NEMGPU_TIE_LIBC; }
     float* cbuf[3] = {nullptr, nullptr, nullptr};    // fuzzy partitions, n_total*k each
     int cur = 0;
@@ -157,6 +158,9 @@ struct nemgpu_engine {
     // parent's, everything it allocates is carved from a slab the parent owns
     nemgpu_engine* parent = nullptr;
     bool carve_all = false;
+    bool dry_run = false; size_t dry_bytes = 0;               // dev_alloc only adds up what it would carve
+    std::vector<nemgpu_engine*> clones;                      // random starts in lock step: state-only twins of this engine
+    char* clone_slab = nullptr; int* clone_flags_host = nullptr; float* clone_par0 = nullptr; size_t clone_bytes = 0;
     bool flags_host_borrowed = false;
     char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;   // argument blocks of the zipped launches (lead engine)
 
@@ -221,6 +225,7 @@ int dev_alloc(T** p, size_t count)
     if (e == nullptr) { set_error("dev_alloc outside an engine"); return NEMGPU_E_FUNCARG; }
     if (count == 0) count = 1;
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (e->dry_run) { e->dry_bytes += bytes; *p = reinterpret_cast<T*>((uintptr_t)256); return NEMGPU_OK; }
     int r;
     if (e->carve_all && e->shared_chunk >= 0 && e->chunks[e->shared_chunk].size - e->chunks[e->shared_chunk].used >= bytes) {
         nemgpu_engine::Chunk& c = e->chunks[e->shared_chunk];
@@ -247,6 +252,28 @@ int dev_alloc(T** p, size_t count)
 // blocking copy on the engine's stream
 hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 void drop_graphs(nemgpu_engine* e);
+
+// everything an engine owns besides the matrix layouts and the graph: parameters, tables, densities, masks, flags
+int alloc_model_buffers(nemgpu_engine* e)
+{
+    const int k = e->k;
+    const size_t kd = (size_t)k * e->d, kdp = (size_t)k * e->dpad;
+    int r = NEMGPU_OK;
+    auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
+    A(dev_alloc(&e->prop, (size_t)k)); A(dev_alloc(&e->center, kd)); A(dev_alloc(&e->disp, kd));
+    if (e->parent == nullptr) { A(dev_alloc(&e->prop0, (size_t)k)); A(dev_alloc(&e->center0, kd)); A(dev_alloc(&e->disp0, kd)); }
+    A(dev_alloc(&e->nbobs_k, (size_t)k)); A(dev_alloc(&e->iner, kd));
+    A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
+    A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
+    A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
+    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)32 + kTicketWords));   // [0] sweep number, [32..] last-block ticket counters
+    A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
+    A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
+    A(dev_alloc(&e->mask, (size_t)k * e->nw64));
+    A(dev_alloc(&e->stats, (size_t)k + kd));
+    A(dev_alloc(&e->flags_dev, e->flag_words()));
+    return r;
+}
 
 int ensure_state_buffers(nemgpu_engine* e)
 {
@@ -348,6 +375,9 @@ int clear_sweep_flags(nemgpu_engine* e)
 int ensure_draw_window(nemgpu_engine* e, long lo, long count)
 {
     if (e->draw_valid && e->draw_tab0 <= lo && lo + count <= e->draw_tab0 + e->draw_cap) return NEMGPU_OK;
+    if (e->draw_borrowed) {                                  // a twin that outgrew its parent's window gets a table of its own
+        e->draw_borrowed = false; e->draw_valid = false; e->draw_tab = nullptr; e->draw_cap = 0;
+    }
     long cap = std::max<long>(e->draw_cap, 1024);
     while (cap < 2 * count) cap *= 2;
     if (!e->draw_valid || lo < e->draw_tab0) {               // a new stream (seed / restart below the window)
@@ -1293,25 +1323,13 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
         e->own_stream = true;
     }
     int r = NEMGPU_OK;
-    const size_t kd = (size_t)k * d, kdp = (size_t)k * e->dpad;
     alloc_for(e);
     auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
     A(dev_alloc(&e->xw, (size_t)e->W * e->npad));
     A(dev_alloc(&e->xws, (size_t)((e->W + 3) / 4) * 4 * e->npad));   // uint4[ceil(W/4)][npad]
     A(dev_alloc(&e->perm, (size_t)e->npad));
     A(dev_alloc(&e->xt, (size_t)d * e->nw64));
-    A(dev_alloc(&e->prop, (size_t)k)); A(dev_alloc(&e->center, kd)); A(dev_alloc(&e->disp, kd));
-    A(dev_alloc(&e->prop0, (size_t)k)); A(dev_alloc(&e->center0, kd)); A(dev_alloc(&e->disp0, kd));
-    A(dev_alloc(&e->nbobs_k, (size_t)k)); A(dev_alloc(&e->iner, kd));
-    A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
-    A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
-    A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
-    A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)32 + kTicketWords));   // [0] sweep number, [32..] last-block ticket counters
-    A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
-    A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
-    A(dev_alloc(&e->mask, (size_t)k * e->nw64));
-    A(dev_alloc(&e->stats, (size_t)k + kd));
-    A(dev_alloc(&e->flags_dev, e->flag_words()));
+    A(alloc_model_buffers(e));
     if (r == NEMGPU_OK && !e->flags_host && hipHostMalloc((void**)&e->flags_host, e->flag_words() * sizeof(int)) != hipSuccess) {
         set_error("hipHostMalloc failed"); r = NEMGPU_E_DEVICE;
     }
@@ -1326,6 +1344,11 @@ void rccl_release(nemgpu_engine* e);
 void nemgpu_destroy(nemgpu_engine* e)
 {
     if (!e) return;
+    for (nemgpu_engine* c : e->clones) nemgpu_destroy(c);
+    e->clones.clear();
+    if (e->clone_slab) (void)hipFree(e->clone_slab);
+    if (e->clone_flags_host) (void)hipHostFree(e->clone_flags_host);
+    e->clone_slab = nullptr; e->clone_flags_host = nullptr;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     rccl_release(e);
@@ -1595,12 +1618,20 @@ int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results)
 // with every family in class 0; every start draws its centres from the data (MakeRandomPara, :1381-1473), runs the
 // INIT_PARAM_FILE pipeline on them and is ranked by criterion M (DEFAULT_CRIT, nem_typ.h:80); the best partition is
 // restored and EstimPara run on it (:1703-1713).
+static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
+
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
 {
     if (!e || n_starts <= 0) return NEMGPU_E_FUNCARG;
     if (e->lo != 0 || e->hi != e->n_total) { set_error("random starts need the whole problem on one engine"); return NEMGPU_E_FUNCARG; }
     if (!e->have_matrix || e->host_bits.empty()) { set_error("the matrix must be set first"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
+    {
+        // the starts are independent EM runs on ONE matrix: by default they run in lock step, every launch serving all
+        // of them (NEM_MI355X_BATCH_STARTS=0: one after the other on this engine)
+        const char* g = getenv("NEM_MI355X_BATCH_STARTS");
+        if (n_starts > 1 && !(g && g[0] == '0')) return run_random_lockstep(e, n_starts, seed, res, best_start);
+    }
     int r;
     const int n = e->n, d = e->d, k = e->k, wf = e->wf;
     const size_t kd = (size_t)k * d;
@@ -1695,6 +1726,220 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
     }
     if (best_start) *best_start = best;
     cleanup();
+    return NEMGPU_OK;
+}
+
+// ---- random starts in lock step -------------------------------------------------------------------------------
+// A state-only twin of `p`: matrix layouts, graph and draw table are p's, everything else is carved from `slab`.
+static int make_clone(nemgpu_engine* p, nemgpu_engine** out, char* slab, size_t slab_bytes, int* flags_host, float* par0)
+{
+    nemgpu_engine* c = new nemgpu_engine();
+    c->n_total = p->n_total; c->n_true = p->n_true; c->d = p->d; c->k = p->k; c->lo = p->lo; c->hi = p->hi; c->n = p->n;
+    c->npad = p->npad; c->dpad = p->dpad; c->W = p->W; c->wf = p->wf; c->nw64 = p->nw64; c->device = p->device;
+    c->stream = p->stream; c->own_stream = false;
+    c->cfg = p->cfg; c->have_matrix = true; c->have_params = true; c->has_graph = p->has_graph;
+    c->xw = p->xw; c->xws = p->xws; c->perm = p->perm; c->xt = p->xt; c->use_sort = p->use_sort;
+    c->nei_ptr = p->nei_ptr; c->nei_idx = p->nei_idx; c->nei_w = p->nei_w; c->nnz = p->nnz;
+    c->use_graphs = false; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch;
+    c->parent = p; c->carve_all = true;
+    c->chunks.push_back({slab, slab_bytes, 0, false});
+    c->shared_chunk = 0;
+    c->flags_host = flags_host; c->flags_host_borrowed = true;
+    const size_t kd = (size_t)p->k * p->d;
+    c->prop0 = par0; c->center0 = par0 + p->k; c->disp0 = par0 + p->k + kd;
+    alloc_for(c);
+    int r = alloc_model_buffers(c);
+    if (r == NEMGPU_OK) r = ensure_state_buffers(c);
+    if (r == NEMGPU_OK) r = ensure_crit_buffers(c);
+    alloc_for(p);
+    if (r != NEMGPU_OK) { nemgpu_destroy(c); return r; }
+    c->draw_ctl = c->sweep_next + 8;
+    *out = c;
+    return NEMGPU_OK;
+}
+
+// `count` twins of e (kept for the next call)
+static int ensure_clones(nemgpu_engine* e, int count)
+{
+    if ((int)e->clones.size() >= count) return NEMGPU_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (nemgpu_engine* c : e->clones) nemgpu_destroy(c);
+    e->clones.clear();
+    if (e->clone_slab) { (void)hipFree(e->clone_slab); e->clone_slab = nullptr; }
+    if (e->clone_flags_host) { (void)hipHostFree(e->clone_flags_host); e->clone_flags_host = nullptr; }
+    // what one twin carves: a dry run of its allocations
+    {
+        nemgpu_engine probe;
+        probe.n_total = e->n_total; probe.d = e->d; probe.k = e->k; probe.n = e->n; probe.npad = e->npad; probe.dpad = e->dpad;
+        probe.W = e->W; probe.nw64 = e->nw64; probe.cfg = e->cfg; probe.parent = e; probe.dry_run = true;
+        alloc_for(&probe);
+        int r = alloc_model_buffers(&probe);
+        if (r == NEMGPU_OK) r = ensure_state_buffers(&probe);
+        if (r == NEMGPU_OK) r = ensure_crit_buffers(&probe);
+        alloc_for(e);
+        if (r) return r;
+        e->clone_bytes = probe.dry_bytes + 4096;
+    }
+    const size_t kd = (size_t)e->k * e->d;
+    const size_t par_bytes = (((size_t)count * (e->k + 2 * kd) * sizeof(float)) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc((void**)&e->clone_slab, par_bytes + (size_t)count * e->clone_bytes));
+    HIPCHK(hipMemsetAsync(e->clone_slab, 0, par_bytes + (size_t)count * e->clone_bytes, e->stream));
+    HIPCHK(hipHostMalloc((void**)&e->clone_flags_host, (size_t)count * e->flag_words() * sizeof(int)));
+    e->clone_par0 = reinterpret_cast<float*>(e->clone_slab);
+    for (int i = 0; i < count; i++) {
+        nemgpu_engine* c = nullptr;
+        int r = make_clone(e, &c, e->clone_slab + par_bytes + (size_t)i * e->clone_bytes, e->clone_bytes,
+                           e->clone_flags_host + (size_t)i * e->flag_words(), e->clone_par0 + (size_t)i * (e->k + 2 * kd));
+        if (r) return r;
+        e->clones.push_back(c);
+    }
+    return NEMGPU_OK;
+}
+
+// RandNemAlgo (nem_alg.c:1574-1742) with the starts in lock step.  TIE_LIBC: the starts' centre draws and the sweeps'
+// tie draws are one stream, so where start s begins depends on the ties of the starts before it.  The starts of a round
+// are drawn as if none of them tied; the first that did tie is still right (its own draws came from where they should)
+// and everything behind it is redone from the position it left the stream at.
+static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
+{
+    int r;
+    const int n = e->n, d = e->d, k = e->k, wf = e->wf;
+    const size_t kd = (size_t)k * d, par = (size_t)k + 2 * kd;
+    if ((r = ensure_state_buffers(e))) return r;
+    // ---- InitPara: dispersion of the whole sample
+    e->have_params = true;
+    if ((r = reset_state(e))) return r;
+    if (e->ncem()) {
+        HIPCHK(hipMemsetAsync(e->lab[0], 0, (size_t)e->n_total, e->stream));
+    } else {
+        std::vector<float> c1((size_t)n * k, 0.0f);
+        for (int i = 0; i < n; i++) c1[(size_t)i * k] = 1.0f;
+        HIPCHK(copy_sync(e, e->cbuf[0], c1.data(), c1.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->cur = 0; e->masks_valid = false;
+    if ((r = do_mstep(e))) return r;
+    std::vector<float> dispsam((size_t)d);
+    HIPCHK(copy_sync(e, dispsam.data(), e->disp, sizeof(float) * d, hipMemcpyDeviceToHost));
+
+    GlibcRandom rng(seed);
+    if (e->libc() && e->cfg.tie_seed != seed) { e->cfg.tie_seed = seed; e->draw_valid = false; }
+    auto draw_integer = [&](int mini, int maxi, int* out) -> int {
+        if (mini >= maxi) { *out = maxi; return NEMGPU_OK; }
+        if (!e->libc()) { *out = rng.integer(mini, maxi); return NEMGPU_OK; }
+        uint32_t v = 0;
+        int rr = host_draw(e, &v);
+        *out = (int)(v % (uint32_t)(maxi - mini + 1)) + mini;
+        return rr;
+    };
+    auto bit = [&](int i, int j) { return (float)((e->host_bits[(size_t)i * wf + (j >> 5)] >> (j & 31)) & 1u); };
+    alloc_for(e);
+    if (e->ncem()) { if (!e->best_lab && (r = dev_alloc(&e->best_lab, (size_t)e->n_total))) return r; }
+    else { if (!e->best_c && (r = dev_alloc(&e->best_c, (size_t)e->n_total * k))) return r; }
+    const int group = std::min(n_starts, 64);
+    if ((r = ensure_clones(e, group))) return r;
+    for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
+
+    int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
+    float best_crit[6] = {0, 0, 0, 0, 0, 0};
+    nemgpu_result best_res{};
+    std::vector<float> host_par;
+    std::vector<int> start_pos;
+    std::vector<GlibcRandom> rng_after;                           // (hash / first tie rules: the generator after each start's draws)
+    int next = 0;
+    while (next < n_starts) {
+        const int M = std::min(group, n_starts - next);
+        std::vector<nemgpu_engine*> E(e->clones.begin(), e->clones.begin() + M);
+        host_par.assign((size_t)M * par, 0.0f);
+        start_pos.assign((size_t)M, 0);
+        const int pos_first = e->draws;
+        for (int j = 0; j < M; j++) {
+            float* prop = host_par.data() + (size_t)j * par; float* center = prop + k; float* disp = center + kd;
+            // MakeRandomPara, nem_alg.c:1381-1473
+            for (int h = 0; h < k; h++) for (int t = 0; t < d; t++) disp[(size_t)h * d + t] = dispsam[t] / k;     // :1400
+            for (int h = 0; h < k; h++) prop[h] = (float)(1.0 / k);                                              // :1405
+            for (int h = 0; h < k; h++) {
+                int ipt = 0;
+                bool again = true;
+                for (int ndraw = 0; again && ndraw < 100; ndraw++) {                                             // :1419
+                    if ((r = draw_integer(0, n - 1, &ipt))) return r;
+                    again = false;
+                    for (int g = 0; g < h && !again; g++) {
+                        bool different = false;
+                        for (int t = 0; t < d && !different; t++) different = center[(size_t)g * d + t] != bit(ipt, t);
+                        if (!different) again = true;
+                    }
+                }
+                for (int t = 0; t < d; t++) center[(size_t)h * d + t] = bit(ipt, t);                             // :1457
+            }
+            start_pos[j] = e->draws;                                 // where this start's sweeps begin to draw
+        }
+        HIPCHK(copy_sync(e, e->clone_par0, host_par.data(), host_par.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (e->libc()) {
+            if ((r = ensure_draw_window(e, pos_first, (long)(e->draws - pos_first) + draw_need(e)))) return r;
+            for (int j = 0; j < M; j++) {
+                nemgpu_engine* c = E[j];
+                c->draw_tab = e->draw_tab; c->draw_cap = e->draw_cap; c->draw_tab0 = e->draw_tab0; c->draw_valid = true;
+                c->draw_borrowed = true;                           // (a twin that outgrows the shared window builds its own)
+                c->draws = start_pos[j]; c->tie_heavy = e->tie_heavy;
+            }
+        }
+        std::vector<LoopCursor> L((size_t)M);
+        for (int j = 0; j < M; j++) if ((r = loop_begin(E[j], L[j], e->cfg.it_max, true))) return r;
+        if ((r = iterate_many(E, L))) return r;
+        for (int j = 0; j < M; j++)
+            if (E[j]->iters == 0) { if ((r = do_mstep(E[j])) || (r = do_tables(E[j])) || (r = do_density(E[j]))) return r; }
+        {
+            std::vector<Recorder> recs((size_t)M);
+            std::vector<int> all((size_t)M);
+            for (int j = 0; j < M; j++) all[j] = j;
+            if ((r = lockstep(E, all, recs, [&](int m) { return criteria_enqueue(E[m], -1); }, false))) return r;
+        }
+        std::vector<float> crits((size_t)M * 6);
+        for (int j = 0; j < M; j++)
+            HIPCHK(hipMemcpyAsync(crits.data() + (size_t)j * 6, E[j]->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        // the starts of this round that stand: all of them, or (TIE_LIBC) up to the first one whose sweeps drew
+        int valid = M;
+        if (e->libc())
+            for (int j = 0; j < M; j++) if (E[j]->draws != start_pos[j]) { valid = j + 1; break; }
+        for (int j = 0; j < valid; j++) {
+            nemgpu_engine* c = E[j];
+            const float* crit = crits.data() + (size_t)j * 6;
+            last_status = c->status;
+            if (c->status == NEMGPU_OK) {
+                nbsucc++;
+                if (nbsucc == 1 || crit[3] > best_crit[3]) {                                                     // :1676-1697
+                    if (e->ncem()) HIPCHK(hipMemcpyAsync(e->best_lab, c->lab[c->cur], (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+                    else HIPCHK(hipMemcpyAsync(e->best_c, c->cbuf[c->cur], sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
+                    for (int t = 0; t < 6; t++) best_crit[t] = crit[t];
+                    best = next + j;
+                    fill_result(c, &best_res);
+                }
+            }
+        }
+        if (e->libc()) {
+            if (valid < M || E[M - 1]->draws != start_pos[M - 1]) e->draws = E[valid - 1]->draws;   // the stream as start `valid - 1` left it
+            e->tie_heavy = e->tie_heavy || E[valid - 1]->tie_heavy;
+        } else if (valid < M) {
+            set_error("internal: lock-step starts out of order"); return NEMGPU_E_FUNCARG;
+        }
+        next += valid;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (nbsucc > 0) {
+        if (e->ncem()) HIPCHK(hipMemcpyAsync(e->lab[e->cur], e->best_lab, (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+        else HIPCHK(hipMemcpyAsync(e->cbuf[e->cur], e->best_c, sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
+        e->masks_valid = false; e->tables_fresh = false; e->density_fresh = false;
+        if ((r = do_mstep(e))) return r;                                                                      // :1711
+        e->status = NEMGPU_OK; e->emptyk = 0;
+        e->iters = best_res.iters; e->converged = best_res.converged;
+        if (res) { *res = best_res; res->status = NEMGPU_OK; res->tie_draws = e->draws; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
+    } else if (res) {
+        fill_result(e, res);
+        res->status = last_status;
+    }
+    if (best_start) *best_start = best;
+    HIPCHK(hipStreamSynchronize(e->stream));
     return NEMGPU_OK;
 }
 

@@ -189,3 +189,31 @@ def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
     from pangenomenem_amd.engine import NemEngine, NemGpuError
     with pytest.raises(NemGpuError):
         NemEngine(100, 10, 33)
+
+
+@pytest.mark.parametrize("algo,disper,tie,n,d,k,starts", [
+    ("ncem", "sk_", "hash", 3000, 40, 3, 12), ("nem", "skd", "hash", 1500, 25, 3, 7), ("ncem", "skd", "libc", 2500, 30, 4, 10),
+    ("ncem", "sk_", "libc", 600, 6, 3, 9)])
+def test_lockstep_random_starts_equal_sequential_ones(gpu_lib, monkeypatch, algo, disper, tie, n, d, k, starts):
+    """RandNemAlgo's starts in lock step (one launch per EM step for all starts, state-only twins of the engine) against
+    the same starts one after the other: best start, its labels, parameters, criteria, draws -- identical.  The last
+    case ties heavily under TIE_LIBC: every start's position in the stream depends on the ties before it."""
+    from pangenomenem_amd.engine import NemEngine
+    x, _ = synth.bernoulli_pa_matrix(n, d, 77, p=(0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, 77)
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NEM_MI355X_BATCH_STARTS", mode)
+        eng = NemEngine(n, d, k)
+        eng.set_matrix(x)
+        eng.set_graph(nei)
+        eng.configure(algo=algo, beta=0.5, disper=disper, propor="pk", it_max=25, tie=tie, seed=5)
+        out.append(eng.run_random(n_starts=starts, rng_seed=5))
+        out.append(eng.run_random(n_starts=starts, rng_seed=5))      # the twins are reused
+        eng.close()
+    ref = out[0]
+    for other in out[1:]:
+        assert other["best_start"] == ref["best_start"] and other["status"] == ref["status"]
+        assert other["iters"] == ref["iters"] and other["tie_draws"] == ref["tie_draws"]
+        for key in ("c", "center", "disp", "prop", "crit"):
+            assert np.array_equal(other[key], ref[key], equal_nan=True), key
