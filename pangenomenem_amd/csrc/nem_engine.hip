@@ -1719,7 +1719,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
         if ((r = do_mstep(e))) { cleanup(); return r; }                                                      // :1711
         e->status = NEMGPU_OK; e->emptyk = 0;
         e->iters = best_res.iters; e->converged = best_res.converged;
-        if (res) { *res = best_res; res->status = NEMGPU_OK; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
+        if (res) { *res = best_res; res->status = NEMGPU_OK; res->tie_draws = e->draws; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
     } else if (res) {
         fill_result(e, res);
         res->status = last_status;
@@ -1836,6 +1836,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     if (e->ncem()) { if (!e->best_lab && (r = dev_alloc(&e->best_lab, (size_t)e->n_total))) return r; }
     else { if (!e->best_c && (r = dev_alloc(&e->best_c, (size_t)e->n_total * k))) return r; }
     const int group = std::min(n_starts, 64);
+    int width = group;                                            // starts per round (TIE_LIBC: follows how far the guesses hold)
     if ((r = ensure_clones(e, group))) return r;
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
 
@@ -1847,7 +1848,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     std::vector<GlibcRandom> rng_after;                           // (hash / first tie rules: the generator after each start's draws)
     int next = 0;
     while (next < n_starts) {
-        const int M = std::min(group, n_starts - next);
+        const int M = std::min(width, n_starts - next);
         std::vector<nemgpu_engine*> E(e->clones.begin(), e->clones.begin() + M);
         host_par.assign((size_t)M * par, 0.0f);
         start_pos.assign((size_t)M, 0);
@@ -1924,6 +1925,8 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
             set_error("internal: lock-step starts out of order"); return NEMGPU_E_FUNCARG;
         }
         next += valid;
+        // data whose starts tie are run a few starts at a time (everything behind the first tie is thrown away)
+        width = (valid == M) ? std::min(group, 2 * M) : std::max(1, std::min(group, valid == 1 ? 1 : 2 * valid));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (nbsucc > 0) {
