@@ -83,6 +83,7 @@ struct nemgpu_engine {
     uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
     double2* uni = nullptr;
     int* nonuni = nullptr;
+    uint2* ffq = nullptr;         // [k][256] fast-forward increments of the classes on the uniform chain (k_finish)
     int* sweep_next = nullptr;    // device word: number of the next E-step sweep (tie-break hash key)
     bool tables_fresh = false;    // density tables match prop/center/disp
     bool density_fresh = false;   // pkfki / logpkfki match the tables
@@ -266,6 +267,7 @@ int alloc_model_buffers(nemgpu_engine* e)
     A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
     A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
     A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
+    A(dev_alloc(&e->ffq, (size_t)k * 256));
     A(dev_alloc(&e->uni, (size_t)k)); A(dev_alloc(&e->nonuni, (size_t)k)); A(dev_alloc(&e->sweep_next, (size_t)32 + kTicketWords));   // [0] sweep number, [32..] last-block ticket counters
     A(dev_alloc(&e->pk, (size_t)k)); A(dev_alloc(&e->logpk, (size_t)k));
     A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
@@ -321,6 +323,7 @@ FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
     t.reset_ctrl = nullptr; t.reset_ctrl_words = 0; t.reset_sweep_next = nullptr;
     t.use_ff = e->use_ff() ? 1 : 0;
     t.perm = e->perm;
+    t.ffq = e->ffq;
     return t;
 }
 
@@ -668,7 +671,10 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     int r;
     const int saved = e->cur;
     e->cur = cur;
-    const bool fused = !e->cfg.param_fix && e->ncem() && e->fused_update();
+    // one engine alone: the parameter update rides in the density launch (a launch boundary costs more than the
+    // redundant per-block derivation).  In a lock-step batch the launch is shared by all members and the kernels are
+    // bound by instruction issue: there the update runs once per class (k_finish) and the density blocks only load it
+    const bool fused = !e->cfg.param_fix && e->ncem() && e->fused_update() && current_recorder() == nullptr;
     const bool counts_first = !e->cfg.param_fix && e->ncem();      // the iteration starts with k_mstep_counts
     if (e->ctrl_pending && !counts_first) {                        // (not reached: the mode is fixed within a batch)
         launch_ctrl(e->ctrl_deferred, e->stream);
@@ -2542,6 +2548,7 @@ int nemgpu_set_fast_forward(nemgpu_engine* e, int on)
         drop_graphs(e);                                            // captured launches carry the old setting
         e->ff_mode = mode;
         e->density_fresh = false;
+        e->tables_fresh = false;                                   // (the increment tables are built with the density tables)
     }
     return NEMGPU_OK;
 }

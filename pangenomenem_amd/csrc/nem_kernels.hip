@@ -459,6 +459,7 @@ struct DensityArgs {
     const int* stop;
     int use_ff;
     const int* perm;
+    const uint2* ffq;                                    // per class: the 256 (q0, q1 - q0) of ff_build, made by k_finish
 };
 
 __device__ __forceinline__ void density_body(const DensityArgs& a)
@@ -490,7 +491,8 @@ __device__ __forceinline__ void density_body(const DensityArgs& a)
         // (W <= kDensMaskWords here: table_flag_general sends wider matrices down the general path)
         for (int w = tid; w < W; w += 256) sAm[w] = make_uint2(a.am0[k * W + w], a.am1[k * W + w]);
         if (a.use_ff && l1 >= 0.0 && l0 <= 0.0) {        // block-uniform
-            ff_build(sQ0, sQ1, l1, l0, tid);
+            const uint2 q = a.ffq[k * 256 + tid];          // (k_finish built the class's increment table)
+            sQ0[tid] = q.x; sQ1[tid] = q.y;
             __syncthreads();
             dk = chain_ff(a.xw, npad, i, a.D, sAm, sQ0, sQ1, l1h, l0);
         } else {
@@ -1577,6 +1579,20 @@ __device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
     for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_flag_general(a, t);
     __syncthreads();
     for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_entry(a, t);   // dpad and 1024 are multiples of 64
+    if (a.use_ff && a.ffq != nullptr) {
+        // the uniform chain's fast-forward increments (nem_ff.hpp), one table per class that stays on that chain
+        __syncthreads();                                 // (uni[k] / nonuni[k] of this block's classes are settled)
+        for (int t = kb * 256 + tid; t < ke * 256; t += 1024) {
+            const int k = t >> 8;
+            if (a.nonuni[k] == 0) {
+                const double l1 = a.uni[k].x, l0 = a.uni[k].y;
+                uint32_t q0, q1;
+                ff_entry(l1, -l0, t & 255, q0, q1);
+                if (q0 == kFFInvalid) q1 = kFFInvalid;
+                a.ffq[t] = make_uint2(q0, q1 - q0);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2303,7 +2319,7 @@ void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, do
     a.tabT = t.tabT; a.tabL0 = t.tabL0; a.nz0 = t.nz0; a.nz1 = t.nz1; a.am0 = t.am0; a.am1 = t.am1;
     a.uni = t.uni; a.nonuni = t.nonuni; a.pk = t.pk; a.logpk = t.logpk;
     a.pkfki = pkfki; a.logpkfki = logpkfki; a.zero_flags = zero_flags; a.n_zero_flags = n_zero_flags;
-    a.stop = t.stop; a.use_ff = t.use_ff; a.perm = t.perm;
+    a.stop = t.stop; a.use_ff = t.use_ff; a.perm = t.perm; a.ffq = t.ffq;
     const dim3 grid(((npad / 256 + 7) / 8) * 8 * t.K);
     if (record_op(OP_DENSITY, 0, grid, 256, a)) return;
     hipLaunchKernelGGL(k_density, grid, dim3(256), 0, s, a);

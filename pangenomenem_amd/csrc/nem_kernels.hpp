@@ -138,6 +138,7 @@ struct FinishArgs {
     int* reset_ctrl; int reset_ctrl_words; int* reset_sweep_next;
     const int* perm;               // density kernels: lane i of the (sorted) matrix copy is family perm[i]
     int use_ff;                    // density kernels: fast-forward the uniform chain inside float binades (nem_ff.hpp)
+    uint2* ffq;                    // [K][256] (q0, q1 - q0): the fast-forward increments per class, built next to the tables
 };
 void launch_finish(const FinishArgs& a, hipStream_t s);
 void launch_density(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
