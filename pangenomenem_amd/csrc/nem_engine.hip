@@ -164,6 +164,9 @@ struct nemgpu_engine {
     char* clone_slab = nullptr; int* clone_flags_host = nullptr; float* clone_par0 = nullptr; size_t clone_bytes = 0;
     bool flags_host_borrowed = false;
     char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;   // argument blocks of the zipped launches (lead engine)
+    int* zip_flags_host = nullptr; int* zip_flags_dev = nullptr; size_t zip_flags_cap = 0;   // the members' flag blocks, gathered
+    struct ZipGraph { uint64_t key; int asked; hipGraphExec_t exec; };
+    std::vector<ZipGraph> zip_graphs;                       // captured launch sequences of lock-step batches, by shape
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -1001,6 +1004,8 @@ int zip_reserve(nemgpu_engine* lead, size_t bytes)
 {
     if (lead->zip_cap >= bytes) return NEMGPU_OK;
     HIPCHK(hipStreamSynchronize(lead->stream));
+    for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // (they hold the old slab's addresses)
+    lead->zip_graphs.clear();
     if (lead->zip_host) (void)hipHostFree(lead->zip_host);
     if (lead->zip_dev) (void)hipFree(lead->zip_dev);
     lead->zip_host = nullptr; lead->zip_dev = nullptr; lead->zip_cap = 0;
@@ -1012,8 +1017,9 @@ int zip_reserve(nemgpu_engine* lead, size_t bytes)
     return NEMGPU_OK;
 }
 
-// issue the recorded sequences of `members` (indices into recs / E) on the lead's stream
-int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const std::vector<int>& members)
+// issue the recorded sequences of `members` (indices into recs / E) on the lead's stream; flags_words > 0: behind them,
+// one copy of every member's flag block to the host (gathered on the device first)
+int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const std::vector<int>& members, size_t flags_words)
 {
     if (members.empty()) return NEMGPU_OK;
     // groups of members with the same sequence of (kernel, variant, block, grid height)
@@ -1038,6 +1044,8 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
     struct Launch { int kind, variant, B, stride; size_t args_off, gx_off; unsigned max_gx, gy, block; };
     std::vector<Launch> launches;
     size_t off = 0;
+    uint64_t key = 1469598103934665603ull;                        // FNV-1a over everything a captured sequence depends on
+    auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
     for (const auto& g : groups) {
         const int B = (int)g.size();
         for (size_t t = 0; t < recs[g[0]].ops.size(); t++) {
@@ -1051,13 +1059,54 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
             for (int b = 0; b < B; b++) { gx[b] = (int)recs[g[b]].ops[t].gx; L.max_gx = std::max(L.max_gx, recs[g[b]].ops[t].gx); }
             off += ((size_t)B * sizeof(int) + 15) & ~(size_t)15;
             launches.push_back(L);
+            mix((uint64_t)L.kind); mix((uint64_t)L.variant); mix((uint64_t)B); mix((uint64_t)stride); mix(L.max_gx); mix(L.gy); mix(L.block);
         }
     }
-    if (off == 0) return NEMGPU_OK;
-    HIPCHK(hipMemcpyAsync(lead->zip_dev, lead->zip_host, off, hipMemcpyHostToDevice, lead->stream));
-    for (const Launch& L : launches)
-        launch_zipped(L.kind, L.variant, L.B, lead->zip_dev + L.args_off, L.stride, reinterpret_cast<const int*>(lead->zip_dev + L.gx_off),
-                      L.max_gx, L.gy, L.block, lead->stream);
+    mix(flags_words);
+    if (off == 0 && flags_words == 0) return NEMGPU_OK;
+    if (off) HIPCHK(hipMemcpyAsync(lead->zip_dev, lead->zip_host, off, hipMemcpyHostToDevice, lead->stream));
+    // The launches themselves depend only on the shape (kernels, grids, slab offsets), not on the argument blocks'
+    // content: a shape seen before is replayed from its captured graph
+    nemgpu_engine::ZipGraph* slot = nullptr;
+    for (auto& g : lead->zip_graphs) if (g.key == key) { slot = &g; break; }
+    if (slot == nullptr && lead->use_graphs) {
+        if (lead->zip_graphs.size() >= 64) {
+            for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            lead->zip_graphs.clear();
+        }
+        lead->zip_graphs.push_back({key, 0, nullptr});
+        slot = &lead->zip_graphs.back();
+    }
+    auto issue = [&]() -> int {
+        for (const Launch& L : launches)
+            launch_zipped(L.kind, L.variant, L.B, lead->zip_dev + L.args_off, L.stride, reinterpret_cast<const int*>(lead->zip_dev + L.gx_off),
+                          L.max_gx, L.gy, L.block, lead->stream);
+        if (flags_words)
+            HIPCHK(hipMemcpyAsync(lead->zip_flags_host, lead->zip_flags_dev, flags_words * sizeof(int), hipMemcpyDeviceToHost, lead->stream));
+        return NEMGPU_OK;
+    };
+    if (slot != nullptr && slot->exec != nullptr) {
+        HIPCHK(hipGraphLaunch(slot->exec, lead->stream));
+        return NEMGPU_OK;
+    }
+    const bool capture = slot != nullptr && (slot->asked++ > 0 || lead->capture_first);
+    if (capture) {
+        HIPCHK(hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
+        r = issue();
+        hipGraph_t graph = nullptr;
+        const hipError_t cerr = hipStreamEndCapture(lead->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            slot->exec = exec;
+            if (graph) (void)hipGraphDestroy(graph);
+            HIPCHK(hipGraphLaunch(exec, lead->stream));
+            return NEMGPU_OK;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        lead->use_graphs = false;                                  // plain launches from now on
+    }
+    if ((r = issue())) return r;
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -1069,6 +1118,8 @@ int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, st
     if (members.empty()) return NEMGPU_OK;
     nemgpu_engine* lead = E[0];
     HIPCHK(hipStreamSynchronize(lead->stream));                // (the argument slab of the previous step is free again)
+    static const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     int r = NEMGPU_OK;
     for (int m : members) {
         recs[m].ops.clear();
@@ -1077,11 +1128,43 @@ int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, st
         set_recorder(nullptr);
         if (r) return r;
     }
-    if ((r = zip_and_launch(lead, recs, members))) return r;
-    if (fetch_flags)
-        for (int m : members)
-            HIPCHK(hipMemcpyAsync(E[m]->flags_host, E[m]->flags_dev, E[m]->flag_words() * sizeof(int), hipMemcpyDeviceToHost, lead->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    const size_t fw = lead->flag_words();
+    if (fetch_flags) {
+        // every member's flag block goes to one staging area on the device (a last zipped launch) and from there
+        // to the host in ONE copy
+        const size_t need = fw * E.size();
+        if (lead->zip_flags_cap < need) {
+            if (lead->zip_flags_host) (void)hipHostFree(lead->zip_flags_host);
+            if (lead->zip_flags_dev) (void)hipFree(lead->zip_flags_dev);
+            lead->zip_flags_host = nullptr; lead->zip_flags_dev = nullptr; lead->zip_flags_cap = 0;
+            for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            lead->zip_graphs.clear();
+            HIPCHK(hipHostMalloc((void**)&lead->zip_flags_host, need * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&lead->zip_flags_dev, need * sizeof(int)));
+            lead->zip_flags_cap = need;
+        }
+        size_t slot = 0;
+        for (int m : members) {
+            set_recorder(&recs[m]);
+            launch_copy_words(E[m]->flags_dev, lead->zip_flags_dev + slot * fw, (int)fw, lead->stream);
+            set_recorder(nullptr);
+            slot++;
+        }
+    }
+    if ((r = zip_and_launch(lead, recs, members, fetch_flags ? fw * members.size() : 0))) return r;
+    const auto t2 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(lead->stream));
+    if (fetch_flags) {
+        size_t slot = 0;
+        for (int m : members) { memcpy(E[m]->flags_host, lead->zip_flags_host + slot * fw, fw * sizeof(int)); slot++; }
+    }
+    if (prof) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[lockstep] members %zu ops %zu: record %.0f us, zip+launch+copies %.0f us, wait %.0f us\n", members.size(),
+                recs[members[0]].ops.size(), us(t0, t1), us(t1, t2), us(t2, t3));
+    }
     return NEMGPU_OK;
 }
 
@@ -1372,6 +1455,10 @@ void nemgpu_destroy(nemgpu_engine* e)
     for (const nemgpu_engine::Chunk& c : e->chunks) if (c.base != keep && c.owned) (void)hipFree(c.base);
     if (e->zip_host) (void)hipHostFree(e->zip_host);
     if (e->zip_dev) (void)hipFree(e->zip_dev);
+    if (e->zip_flags_host) (void)hipHostFree(e->zip_flags_host);
+    if (e->zip_flags_dev) (void)hipFree(e->zip_flags_dev);
+    for (auto& g : e->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->zip_graphs.clear();
     if (!keep) {
         if (e->flags_host && !e->flags_host_borrowed) (void)hipHostFree(e->flags_host);
         if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1746,7 +1833,7 @@ static int make_clone(nemgpu_engine* p, nemgpu_engine** out, char* slab, size_t 
     c->cfg = p->cfg; c->have_matrix = true; c->have_params = true; c->has_graph = p->has_graph;
     c->xw = p->xw; c->xws = p->xws; c->perm = p->perm; c->xt = p->xt; c->use_sort = p->use_sort;
     c->nei_ptr = p->nei_ptr; c->nei_idx = p->nei_idx; c->nei_w = p->nei_w; c->nnz = p->nnz;
-    c->use_graphs = false; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch;
+    c->use_graphs = p->use_graphs; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch;   // (graphs: the zipped sequences')
     c->parent = p; c->carve_all = true;
     c->chunks.push_back({slab, slab_bytes, 0, false});
     c->shared_chunk = 0;

@@ -2231,6 +2231,13 @@ __device__ __forceinline__ void fill_body(const FillArgs& a)
 __global__ void k_fill(FillArgs a) { fill_body(a); }
 __global__ void k_fill_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FillArgs) fill_body(a); }
 
+__device__ __forceinline__ void copy_body(const CopyArgs& a)
+{
+    for (int t = threadIdx.x; t < a.words; t += 256) a.dst[t] = a.src[t];                           // (one block)
+}
+__global__ void k_copy_words(CopyArgs a) { copy_body(a); }
+__global__ void k_copy_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CopyArgs) copy_body(a); }
+
 // ---- the recorder ----
 static thread_local Recorder* g_recorder = nullptr;
 void set_recorder(Recorder* r) { g_recorder = r; }
@@ -2300,6 +2307,13 @@ void launch_fill(int* ptr, int words, int value, hipStream_t s)
     FillArgs a{ptr, words, value};
     if (record_op(OP_FILL, 0, dim3(1), 256, a)) return;
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, s, a);
+}
+
+void launch_copy_words(const int* src, int* dst, int words, hipStream_t s)
+{
+    CopyArgs a{src, dst, words};
+    if (record_op(OP_COPY, 0, dim3(1), 256, a)) return;
+    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, s, a);
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t s)
@@ -2432,6 +2446,7 @@ void launch_zipped(int kind, int variant, int B, const void* arr, int stride, co
     case OP_CRIT_REDUCE: hipLaunchKernelGGL(k_crit_reduce_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_CRIT_FINAL: hipLaunchKernelGGL(k_crit_final_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FILL: hipLaunchKernelGGL(k_fill_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_COPY: hipLaunchKernelGGL(k_copy_words_b, grid, blk, 0, s, arr, stride, gx); break;
     default: break;
     }
 }

@@ -91,6 +91,7 @@ struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const 
                   const float* c; const double* pkfki; const float* logpkfki; float* dik; float* gik; double* lfi; double* lzi;
                   float* crit6; int hard; };
 struct FillArgs { int* ptr; int words; int value; };
+struct CopyArgs { const int* src; int* dst; int words; };
 
 // ---- batched launches: B independent problems per launch ---------------------------------------------------------
 // Every loop kernel has a twin that takes an ARRAY of argument blocks in device memory and runs problem blockIdx.z
@@ -98,7 +99,7 @@ struct FillArgs { int* ptr; int words; int value; };
 // (same argument blocks, same grids); the batch driver (nem_engine.hip) records one sequence per problem, checks that
 // the sequences agree launch for launch, and issues each position once for all problems with launch_zipped.
 enum OpKind { OP_FINISH = 1, OP_DENSITY, OP_DENSITY_FUSED, OP_SWEEP, OP_COUNTS, OP_LABELS_POST, OP_CTRL, OP_FUZZY_A, OP_FUZZY_B,
-              OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL };
+              OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL, OP_COPY };
 constexpr int kOpArgBytes = 512;
 struct OpRecord {
     int kind, variant;             // variant: template instance / block size, part of what must agree across problems
@@ -114,6 +115,7 @@ Recorder* current_recorder();
 void launch_zipped(int kind, int variant, int B, const void* dev_args, int stride, const int* dev_gx, unsigned max_gx,
                    unsigned gy, unsigned block, hipStream_t s);
 void launch_fill(int* ptr, int words, int value, hipStream_t s);   // recordable memset of 32-bit words
+void launch_copy_words(const int* src, int* dst, int words, hipStream_t s);   // recordable device-to-device copy
 
 void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
                          const int* stop, const CtrlArgs* ctrl, hipStream_t s);
