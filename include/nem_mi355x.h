@@ -34,8 +34,8 @@ extern "C" {
  *   nk             number of classes K (> 0)
  *   algo           "nem" | "ncem"            ("gem" is not reachable from PPanGGOLiN; rejected)
  *   beta           MRF weight of the neighbourhood term
- *   convergence    "none" | "clas"           ("crit" rejected: needs per-iteration criteria)
- *   convergence_th threshold of the "clas" test (max |c - c_old| < th)
+ *   convergence    "none" | "clas" | "crit"
+ *   convergence_th threshold: "clas" max |c - c_old| < th; "crit" |(M - M_old) / M| < th (nem_alg.c:2075-2105)
  *   format         "hard" (.cf) | "fuzzy" (.uf)
  *   it_max         maximum number of EM iterations (>= 0)
  *   dolog          non-zero: messages to <Fname>.stderr and the reference's iteration log <Fname>.log (criteria
@@ -73,7 +73,10 @@ typedef struct nemgpu_engine nemgpu_engine;
 enum { NEMGPU_ALGO_NEM = 0, NEMGPU_ALGO_NCEM = 1 };
 enum { NEMGPU_DISP___ = 0, NEMGPU_DISP_K_ = 1, NEMGPU_DISP__D = 2, NEMGPU_DISP_KD = 3 };
 enum { NEMGPU_PROP__ = 0, NEMGPU_PROP_K = 1 };
-enum { NEMGPU_CV_NONE = 0, NEMGPU_CV_CLAS = 1 };
+/* CRIT: HasConverged's CVTEST_CRIT (nem_alg.c:2090-2105) on criterion M, starting from 0 like a reference run
+   without a log (Criteria = {0}, nem_exe.c:264); CRIT_LOGGED: starting from the criterion of the initial partition,
+   like a reference run with dolog (WriteLogCrit, nem_alg.c:1980, 2398) */
+enum { NEMGPU_CV_NONE = 0, NEMGPU_CV_CLAS = 1, NEMGPU_CV_CRIT = 2, NEMGPU_CV_CRIT_LOGGED = 3 };
 /* NCEM tie rule (ComputeMAP, nem_alg.c:590-645; numeric values of TIE_RANDOM / TIE_FIRST follow TieET).
    LIBC = the reference's TIE_RANDOM: kmaxes[random() % (nequal+1)] on glibc's random() after srandom(tie_seed)
    (nem_exe.c:621; the reference seeds with time(NULL), :353), drawn in site order exactly as the sequential

@@ -453,8 +453,15 @@ static int run_from_params(const orc_problem* p, orc_state* s, int reseed)
                                    p->tie_rule, p->tie_seed, sweep++, s->c_nk);
 
     /* NemAlgo (nem_alg.c:1789-1840) */
+    {
+        int t;
+        for (t = 0; t < 6; t++) s->crit[t] = 0.0f;                 /* Criteria = {0}, nem_exe.c:264 */
+    }
+    if (p->cvtest == ORC_CV_CRIT_LOGGED)                           /* a logging run: WriteLogCrit after the initial sweep */
+        orc_crit(n, k, p->nei_ptr, p->nei_idx, p->nei_w, p->beta, s->c_nk, s->pkfki_nk, s->logpkfki_nk, s->crit);
     t0 = now_s();
     for (iter = 1; iter <= p->it_max && !converged && err == ORC_STS_OK; iter++) {
+        const float oldcrit = s->crit[3];                          /* ChosenCrit(CRIT_M), :1802 */
         memcpy(cold, s->c_nk, sizeof(float) * nk);                 /* :1801 */
         if (!p->param_fix)                                         /* :1806 */
             err = orc_mstep(n, d, k, p->x, s->c_nk, p->disper, p->propor, s->prop_k, s->center_kd,
@@ -464,6 +471,14 @@ static int run_from_params(const orc_problem* p, orc_state* s, int reseed)
             s->n_zero_density += orc_sweep(n, k, p->nei_ptr, p->nei_idx, p->nei_w, p->beta, s->pkfki_nk,
                                            ncem, p->tie_rule, p->tie_seed, sweep++, s->c_nk);
             if (p->cvtest == ORC_CV_CLAS) converged = orc_converged(n, k, s->c_nk, cold, p->cvthres);
+            else if (p->cvtest == ORC_CV_CRIT || p->cvtest == ORC_CV_CRIT_LOGGED) {     /* nem_alg.c:2090-2105 */
+                float curcrit, critdif;
+                orc_crit(n, k, p->nei_ptr, p->nei_idx, p->nei_w, p->beta, s->c_nk, s->pkfki_nk, s->logpkfki_nk, s->crit);
+                curcrit = s->crit[3];
+                if (curcrit != 0) critdif = (float)fabs((curcrit - oldcrit) / curcrit);
+                else critdif = FLT_MAX;                            /* MAXFLOAT */
+                converged = (critdif < p->cvthres);
+            }
         }
     }
     iter = iter - 1;                                               /* :1842 */

@@ -24,7 +24,11 @@ extern "C" {
 enum { ORC_ALGO_NEM = 0, ORC_ALGO_NCEM = 1 };
 enum { ORC_DISP___ = 0, ORC_DISP_K_ = 1, ORC_DISP__D = 2, ORC_DISP_KD = 3 };
 enum { ORC_PROP__ = 0, ORC_PROP_K = 1 };
-enum { ORC_CV_NONE = 0, ORC_CV_CLAS = 1 };
+/* CvemET (nem_typ.h) + one: CVTEST_CRIT compares the chosen criterion (M, DEFAULT_CRIT) of consecutive iterations
+   (HasConverged, nem_alg.c:2090-2105); the value it starts from is 0 in a run without a log (Criteria = {0},
+   nem_exe.c:264) and the criterion of the initial partition in a logging run (WriteLogCrit, nem_alg.c:1980, 2398):
+   CRIT = the former, CRIT_LOGGED = the latter */
+enum { ORC_CV_NONE = 0, ORC_CV_CLAS = 1, ORC_CV_CRIT = 2, ORC_CV_CRIT_LOGGED = 3 };
 /* tie rule of the NCEM C-step (ComputeMAP, nem_alg.c:590-645):
    LIBC  = reference behaviour: kmaxes[random() % (nequal+1)] in site order (srandom(seed) first)
    FIRST = TIE_FIRST (keep the first maximum)

@@ -252,14 +252,14 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     cfg.cvtest = NEMGPU_CV_NONE;
     cfg.cvthres = 1.0f;
     if (cv == -1) lg.pr(" Unknown convergence test %s\n", convergence ? convergence : "(null)");
-    else if (cv == 2) {
-        lg.pr(" Convergence test crit is not supported by this engine (use clas or none)\n");
-        lg.pr("*** NEM error status : bad arguments\n");
-        lg.close();
-        return EXIT_E_ARGS_;
-    } else if (cv == 1) {
+    else if (cv != 0) {
         if (convergence_th <= 0) lg.pr(" Conv threshold must be > 0 (here %f)\n", convergence_th);   // never satisfied
-        else { cfg.cvtest = NEMGPU_CV_CLAS; cfg.cvthres = convergence_th; }
+        else {
+            // crit (nem_alg.c:2090-2105): a run that logs starts from the initial partition's criterion, one that
+            // does not from Criteria = {0} (nem_exe.c:264)
+            cfg.cvtest = cv == 1 ? NEMGPU_CV_CLAS : (dolog ? NEMGPU_CV_CRIT_LOGGED : NEMGPU_CV_CRIT);
+            cfg.cvthres = convergence_th;
+        }
     }
     int fm = get_enum(format, FormatStr, 2);
     if (fm == -1) lg.pr(" Unknown format %s\n", format ? format : "(null)");

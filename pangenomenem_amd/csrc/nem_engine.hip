@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cfloat>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -100,6 +102,7 @@ struct nemgpu_engine {
     uint32_t* draw_tab = nullptr; int draw_cap = 0; long draw_tab0 = 0; bool draw_valid = false;
     std::vector<uint32_t> draw_host; nemk::GlibcRandom draw_gen{1}; long draw_gen_pos = 0;
     int* draw_ctl = nullptr;
+    float crit_ref = 0.0f;               // CVTEST_CRIT: the criterion the next iteration's is compared with
     int draws = 0; bool tie_heavy = false;
     bool draw_borrowed = false;          // the table is the parent's (lock-step random starts): never written through this engine
     bool libc() const { return cfg.algo == NEMGPU_ALGO_NCEM && cfg.tie_rule == NEMGPU_TIE_LIBC; }
@@ -936,7 +939,7 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
     return NEMGPU_OK;
 }
 
-int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
+int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
 {
     int r;
     LoopCursor lc;
@@ -989,6 +992,48 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
         if ((r = batch_finish(e, lc))) return r;
     }
     return NEMGPU_OK;
+}
+
+int criteria(nemgpu_engine* e, float crit6[6], int buf);
+
+// CVTEST_CRIT (HasConverged, nem_alg.c:2090-2105): iterate until the chosen criterion (M, DEFAULT_CRIT nem_typ.h:80)
+// moves by less than the threshold, relatively.  The criterion is an i-ordered float sum over all families that the
+// loop does not otherwise need, so this test runs one iteration per host round trip: iteration, criteria, decision.
+// The value the first iteration is compared with: 0 (Criteria = {0}, nem_exe.c:264) or, for a run that logs, the
+// criterion of the initial partition (WriteLogCrit at the end of the initial sweep, nem_alg.c:1980, 2398).
+int iterate_crit(nemgpu_engine* e, int n_iters, bool with_init)
+{
+    int r;
+    if (with_init) {
+        if ((r = iterate_pipelined(e, 0, true))) return r;
+        e->crit_ref = 0.0f;
+        if (e->cfg.cvtest == NEMGPU_CV_CRIT_LOGGED) {
+            float c6[6];
+            if ((r = criteria(e, c6, -1))) return r;
+            e->crit_ref = c6[3];
+        }
+    }
+    for (int it = 0; it < n_iters && !e->converged && e->status == NEMGPU_OK; it++) {
+        const float oldcrit = e->crit_ref;
+        if ((r = iterate_pipelined(e, 1, false))) return r;
+        if (e->status != NEMGPU_OK) break;
+        float c6[6];
+        if ((r = criteria(e, c6, -1))) return r;
+        const float curcrit = c6[3];
+        e->crit_ref = curcrit;
+        float critdif;
+        if (curcrit != 0) critdif = (float)fabs((curcrit - oldcrit) / curcrit);
+        else critdif = FLT_MAX;                                    // MAXFLOAT
+        if (critdif < e->cfg.cvthres) e->converged = 1;
+    }
+    return NEMGPU_OK;
+}
+
+bool crit_test(const nemgpu_engine* e) { return e->cfg.cvtest == NEMGPU_CV_CRIT || e->cfg.cvtest == NEMGPU_CV_CRIT_LOGGED; }
+
+int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
+{
+    return crit_test(e) ? iterate_crit(e, n_iters, with_init) : iterate_pipelined(e, n_iters, with_init);
 }
 
 // ============================================================================================
@@ -1218,6 +1263,13 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
         E[i]->stream = lead->stream;
     }
     auto restore = [&]() { for (int i = 0; i < B; i++) E[i]->stream = own[i]; };
+    for (int i = 0; i < B; i++) {
+        if (crit_test(E[i])) {                                     // (a host round trip per iteration: nothing to share)
+            restore();
+            for (int j = 0; j < B; j++) { int rr = nemgpu_run(E[j], results ? &results[j] : nullptr); if (rr) return rr; }
+            return NEMGPU_OK;
+        }
+    }
     auto t0 = std::chrono::steady_clock::now();
     std::vector<LoopCursor> L((size_t)B);
     r = NEMGPU_OK;
@@ -1616,8 +1668,8 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     if (!e || !cfg) return NEMGPU_E_FUNCARG;
     if (cfg->algo != NEMGPU_ALGO_NEM && cfg->algo != NEMGPU_ALGO_NCEM) { set_error("algo must be nem or ncem"); return NEMGPU_E_ARG; }
     if (cfg->disper < 0 || cfg->disper > 3 || cfg->propor < 0 || cfg->propor > 1) { set_error("bad dispersion/proportion model"); return NEMGPU_E_ARG; }
-    if (cfg->cvtest != NEMGPU_CV_NONE && cfg->cvtest != NEMGPU_CV_CLAS) { set_error("convergence must be none or clas"); return NEMGPU_E_ARG; }
-    if (cfg->cvtest == NEMGPU_CV_CLAS && !(cfg->cvthres > 0)) { set_error("convergence threshold must be > 0"); return NEMGPU_E_ARG; }
+    if (cfg->cvtest < NEMGPU_CV_NONE || cfg->cvtest > NEMGPU_CV_CRIT_LOGGED) { set_error("convergence must be none, clas or crit"); return NEMGPU_E_ARG; }
+    if (cfg->cvtest != NEMGPU_CV_NONE && !(cfg->cvthres > 0)) { set_error("convergence threshold must be > 0"); return NEMGPU_E_ARG; }
     if (cfg->it_max < 0) { set_error("it_max must be >= 0"); return NEMGPU_E_ARG; }
     if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH && cfg->tie_rule != NEMGPU_TIE_LIBC) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
     if (cfg->tie_rule == NEMGPU_TIE_LIBC && e->sh_stride != 0) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_ARG; }
@@ -1639,7 +1691,15 @@ int nemgpu_init_partition(nemgpu_engine* e)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
-    return init_partition(e);
+    int r = init_partition(e);
+    if (r) return r;
+    e->crit_ref = 0.0f;
+    if (e->cfg.cvtest == NEMGPU_CV_CRIT_LOGGED) {                  // (what the first iteration's criterion is compared with)
+        float c6[6];
+        if ((r = criteria(e, c6))) return r;
+        e->crit_ref = c6[3];
+    }
+    return NEMGPU_OK;
 }
 
 int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
@@ -1723,7 +1783,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
         // the starts are independent EM runs on ONE matrix: by default they run in lock step, every launch serving all
         // of them (NEM_MI355X_BATCH_STARTS=0: one after the other on this engine)
         const char* g = getenv("NEM_MI355X_BATCH_STARTS");
-        if (n_starts > 1 && !(g && g[0] == '0')) return run_random_lockstep(e, n_starts, seed, res, best_start);
+        if (n_starts > 1 && !(g && g[0] == '0') && !crit_test(e)) return run_random_lockstep(e, n_starts, seed, res, best_start);
     }
     int r;
     const int n = e->n, d = e->d, k = e->k, wf = e->wf;

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnem_mi355x.so")
 ALGO = {"nem": 0, "ncem": 1}
 DISP = {"s__": 0, "sk_": 1, "s_d": 2, "skd": 3}
 PROP = {"p_": 0, "pk": 1}
-CVT = {"none": 0, "clas": 1}
+CVT = {"none": 0, "clas": 1, "crit": 2, "crit_logged": 3}
 TIE = {"libc": 0, "first": 1, "hash": 2}
 STATUS_OK, STATUS_W_EMPTYCLASS, STATUS_E_DEVICE = 0, 2, 9
 

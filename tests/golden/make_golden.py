@@ -88,6 +88,13 @@ def case_list():
     ct = np.tile(np.full(12, 1.0, np.float32), (2, 1))
     dt = np.full((2, 12), 0.3, np.float32)
     add("ties_two_equal_classes", xt, synth.contiguity_graph(400, 4), 2, pt, ct, dt, it_max=3)
+
+    # convergence = "crit" (HasConverged's CVTEST_CRIT, nem_alg.c:2090-2105), as a run without a log tests it
+    xc, _ = synth.ushaped_pa_matrix(2048, 15, 4)
+    neic = synth.contiguity_graph(2048, 4)
+    pc, cc, dc = synth.default_init(15)
+    add("c1_ushape_ncem_cvcrit", xc, neic, 3, pc, cc, dc, cvtest="crit", cvthres=1e-4, it_max=60)
+    add("c1_ushape_nem_skd_cvcrit", xc, neic, 3, pc, cc, dc, algo="nem", disper="skd", cvtest="crit", cvthres=1e-4, it_max=60)
     return cases
 
 
@@ -95,7 +102,14 @@ def main():
     pyoracle.build(ref=True)
     ref = pyoracle.Reference()
     manifest = []
+    only = None                                           # --only name,name: (re)generate these cases, keep the others
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        only = set(sys.argv[2].split(","))
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = [m for m in json.load(f) if m["name"] not in only]
     for case in case_list():
+        if only is not None and case["name"] not in only:
+            continue
         name, x, nei, k, cfg = case["name"], case["x"], case["nei"], case["k"], case["cfg"]
         n, d = x.shape
         out = os.path.join(HERE, name)

@@ -159,3 +159,35 @@ def test_dropin_log_file_equals_the_reference(gpu_lib, tmp_path, algo, disper, n
     assert pyoracle.Reference().nem(ref_base, *args) == 0
     from tests.util import assert_same_nem_log
     assert_same_nem_log(open(base + ".log").read(), open(ref_base + ".log").read())
+
+
+@pytest.mark.parametrize("algo,disper,thres,dolog", [("ncem", "sk_", 1e-4, True), ("nem", "skd", 1e-4, True),
+                                                     ("ncem", "sk_", 0.05, True), ("nem", "sk_", 1e-3, True)])
+def test_dropin_crit_convergence_equals_the_reference(gpu_lib, tmp_path, algo, disper, thres, dolog):
+    """nem(..., convergence="crit", ...) as a logging run (dolog, what PPanGGOLiN passes): the reference compares the
+    first iteration's criterion with the initial partition's (WriteLogCrit, nem_alg.c:1980, 2398).  Same iteration
+    count, same .uf byte for byte, same parameter lines of .mf as the reference's own nem() on the same files."""
+    import shutil
+    from oracle import pyoracle
+    if not pyoracle.have_reference():
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    from pangenomenem_amd import nemfiles, synth
+    import nem as nem_module
+    n, d = 2048, 15
+    x, _ = synth.ushaped_pa_matrix(n, d, 4)
+    nei = synth.contiguity_graph(n, 4)
+    prop, center, disp = synth.default_init(d)
+    ours, ref = str(tmp_path / "ours"), str(tmp_path / "ref")
+    base = nemfiles.write_nem_inputs(ours, x, nei, prop, center, disp)
+    shutil.copytree(ours, ref)
+    ref_base = os.path.join(ref, "nem_file")
+    args = (3, algo.encode(), 0.5, b"crit", thres, b"fuzzy", 60, dolog, b"bern", b"pk", disper.encode(), 2)
+    assert nem_module.nem(base.encode(), *args) == 0
+    assert pyoracle.Reference().nem(ref_base, *args) == 0
+    import re
+    it_ours = re.search(r"NEM (converged|did not converge) after (\d+) iterations", open(base + ".stderr").read())
+    it_ref = re.search(r"NEM (converged|did not converge) after (\d+) iterations", open(ref_base + ".stderr", errors="replace").read())
+    assert it_ours and it_ref and it_ours.groups() == it_ref.groups()
+    assert open(base + ".uf", "rb").read() == open(ref_base + ".uf", "rb").read()
+    ours_mf, ref_mf = open(base + ".mf", "rb").read().split(b"\n"), open(ref_base + ".mf", "rb").read().split(b"\n")
+    assert ours_mf[-4:] == ref_mf[-4:]

@@ -80,3 +80,22 @@ def test_random_starts_bit_exact(oracle, reference, n, d, k, algo, disper, start
         assert a["best_start"] == b["best_start"]
         for key in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
             assert bits_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("n,d,algo,disper,thres", [(2048, 15, "ncem", "sk_", 1e-4), (2048, 15, "nem", "sk_", 1e-3),
+                                                   (1500, 40, "nem", "skd", 1e-4), (1500, 40, "ncem", "skd", 0.02),
+                                                   (900, 25, "ncem", "s__", 1e-6)])
+def test_crit_convergence_bit_exact(oracle, reference, n, d, algo, disper, thres):
+    """convergence = "crit" (HasConverged's CVTEST_CRIT, nem_alg.c:2090-2105): the relative move of criterion M
+    between iterations, from Criteria = {0} in a run without a log (nem_exe.c:264) -- iteration count and everything
+    else bit for bit."""
+    x, _ = synth.ushaped_pa_matrix(n, d, 4)
+    nei = synth.contiguity_graph(n, 4)
+    prop, center, disp = synth.default_init(d)
+    a = oracle.run(x, nei, 3, prop, center, disp, algo=algo, beta=0.5, disper=disper, cvtest="crit", cvthres=thres,
+                   it_max=60, tie="libc", seed=12345)
+    b = reference.classify(x, nei, 3, prop, center, disp, algo=algo, beta=0.5, disper=disper, cvtest="crit",
+                           cvthres=thres, it_max=60, seed=12345)
+    assert a["iters"] == b["iters"] and a["converged"] == b["converged"] and 1 < a["iters"] < 60
+    for key in ("c", "prop", "center", "disp", "crit"):
+        assert bits_equal(a[key], b[key]), key
