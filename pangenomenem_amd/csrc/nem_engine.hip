@@ -80,6 +80,8 @@ struct nemgpu_engine {
     float *nbobs_k = nullptr, *iner = nullptr;
     int *fz_lastz = nullptr, *fz_any1 = nullptr;
     float *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
+    float* fz_ct = nullptr;       // class-major copy of the memberships, [k][npad] (the wave-per-chain M-step)
+    bool fuzzy_chains = true;     // NEM_MI355X_FUZZY_CHAINS=0: the one-lane-per-chain kernels
     double2* tabT = nullptr;
     double* tabL0 = nullptr;
     uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
@@ -302,6 +304,7 @@ int ensure_state_buffers(nemgpu_engine* e)
             if ((r = dev_alloc(&e->fz_inh, (size_t)e->k))) return r;
             if ((r = dev_alloc(&e->fz_lastz, kd))) return r;
             if ((r = dev_alloc(&e->fz_any1, kd))) return r;
+            if ((r = dev_alloc(&e->fz_ct, (size_t)e->k * e->npad))) return r;
         }
     }
     return NEMGPU_OK;
@@ -580,7 +583,8 @@ int do_mstep(nemgpu_engine* e, const CtrlArgs* prev_ctrl = nullptr)
         launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, e->stop_ptr, prev_ctrl, e->stream);
         launch_finish(finish_args(e, 1, e->stats), e->stream);
     } else {
-        launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, e->cbuf[e->cur] + (size_t)e->lo * e->k, e->nbobs_k,
+        launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, e->cbuf[e->cur] + (size_t)e->lo * e->k,
+                           e->fuzzy_chains ? e->fz_ct : nullptr, e->nbobs_k,
                            e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream);
         launch_finish(finish_args(e, 2, nullptr), e->stream);
     }
@@ -1444,6 +1448,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
     if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
     if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
+    if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = (g[0] != '0');
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     ParkedSet parked{-1, nullptr, nullptr, nullptr};

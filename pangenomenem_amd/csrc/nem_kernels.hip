@@ -1719,11 +1719,13 @@ __device__ __forceinline__ void mstep_fuzzy_a_body(int n, int npad, int K, int D
                                                       const float* __restrict__ c, float* __restrict__ nbobs_k,
                                                       float* __restrict__ in0_out, float* __restrict__ in1_out,
                                                       float* __restrict__ inh_k, int* __restrict__ lastz_out,
-                                                      int* __restrict__ any1_out, const int* __restrict__ stop)
+                                                      int* __restrict__ any1_out, const int* __restrict__ stop,
+                                                      const int flags_only)
 {
     if (stop != nullptr && *stop) return;
     const int DB = (D + 63) >> 6;
     const int role = blockIdx.x < 4 * DB ? blockIdx.x / DB : 4 + (int)blockIdx.x - 4 * DB;
+    if (flags_only && role != 2 && role != 3) return;                    // (the sums are k_mstep_fuzzy_sums' then)
     const int bx = role < 4 ? blockIdx.x - role * DB : 0;
     const int k = blockIdx.y;
     const int d = bx * 64 + threadIdx.x;
@@ -1862,6 +1864,257 @@ __device__ __forceinline__ void mstep_fuzzy_b_body(int n, int npad, int K, int D
         center[t] = mu;
         iner[t] = (mu == 0.0f) ? in0[t] : (mu == 1.0f ? in1[t] : inh_k[k]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fuzzy M-step's sums, split along the families.  Each of the K*(2D+2) sums of pass A and the K*D prefix scans
+// of pass B is an i-ordered float accumulator over all N families (nem_mod.c:1303-1313, 1677-1686, 1448-1458) --
+// N dependent adds, whoever runs them.  But between two powers of two a float accumulator moves on a fixed grid
+// and the chain is a prefix sum of integers (nem_chain.hpp); the sum is then a matter of a scan.  Here ONE WAVE
+// owns a chain and takes it 256 families at a time: every lane turns its four memberships into grid increments,
+// a DPP scan places them, the first element the integer form cannot take (the next binade, an exact tie, a sum
+// that is not ready) is found with a ballot and stepped -- with a short burst behind it -- by the reference's own
+// float add.  Float inputs make this simpler than the criteria's chains: c * 2^s is exact, so "near a tie" is
+// "exactly a tie".  (float)((double)a + (double)b) is the float sum, so all four kinds of sums are float adds.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8: prefix inside each row of 16
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+struct WaveChain {
+    float* sx;                                           // LDS: the window's 256 addends, family order
+    float acc;                                           // the accumulator (the same value in every lane)
+    int burst;
+    // sequential float adds of sx[p .. p + count): the reference's own arithmetic, sixteen addends fetched ahead
+    __device__ __forceinline__ void steps(int p, int count)
+    {
+        int i = 0;
+        for (; i + 16 <= count; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) v[t] = sx[p + i + t];
+#pragma unroll
+            for (int t = 0; t < 16; t++) acc = acc + v[t];
+        }
+        for (; i < count; i++) acc = acc + sx[p + i];
+    }
+    // the window: wn (<= 256) addends, lane l holds x[0..3] = addends 4l .. 4l+3 (the same values are in sx)
+    __device__ __forceinline__ void window(const float (&x)[4], int wn)
+    {
+        const int lane = threadIdx.x & 63;
+        int pos = 0;
+        while (pos < wn) {
+            const uint32_t ab = __float_as_uint(acc);
+            const int E = (int)((ab >> 23) & 255u);
+            if ((ab >> 31) != 0u || E < 24 || E > 253) {      // negative, tiny, zero or not finite: step
+                const int cnt = min(burst, wn - pos);
+                steps(pos, cnt);
+                pos += cnt;
+                burst = nemchain::next_burst(burst, -1);
+                continue;
+            }
+            const float sc = __uint_as_float((uint32_t)(127 + 150 - E) << 23);    // 1 / ulp(acc): 2^(150 - E), a normal float
+            const uint32_t M0 = (ab & 0x7fffffu) | 0x800000u;
+            uint32_t inc[4];
+            int stop = 4;                                // first of my four the integer form cannot take
+            uint32_t lsum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * lane + j;
+                inc[j] = 0;
+                if (e >= pos && e < wn && j < stop) {
+                    const float q = x[j] * sc;           // exact (a power-of-two scaling; an overflow gives inf)
+                    if (q == 0.0f) continue;             // +0 / -0: the identity
+                    if (!(q > 0.0f) || !(q < 33554432.0f)) { stop = j; continue; }   // shrinking, NaN, or 2^25 and more
+                    const float fl = floorf(q);
+                    const float fr = q - fl;             // exact
+                    if (fr == 0.5f) { stop = j; continue; }                          // a tie: the parity of M decides
+                    inc[j] = (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
+                    lsum += inc[j];
+                }
+            }
+            const uint32_t incl = wave_scan_incl(lsum);
+            uint32_t M = M0 + incl - lsum;
+            int cand = INT_MAX; uint32_t candM = 0;
+            constexpr uint32_t top = 1u << 24;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * lane + j;
+                if (e >= pos && e < wn && cand == INT_MAX) {
+                    if (j == stop || M >= top || M + inc[j] > top) { cand = e; candM = M; }
+                    else M += inc[j];
+                }
+            }
+            const uint64_t who = __ballot(cand != INT_MAX);
+            if (who == 0ull) {                           // the rest of the window went through in integer form
+                const uint32_t Mt = (uint32_t)__builtin_amdgcn_readlane((int)(M0 + incl), 63);
+                acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
+                burst = nemchain::next_burst(burst, wn - pos);
+                pos = wn;
+                break;
+            }
+            const int first = (int)__ffsll((long long)who) - 1;      // (a lane behind the first stop holds a wrong M: ignored)
+            const int p = __builtin_amdgcn_readlane(cand, first);
+            const uint32_t Mb = (uint32_t)__builtin_amdgcn_readlane((int)candM, first);
+            acc = __uint_as_float(Mb >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mb & 0x7fffffu)));
+            const int cnt = min(burst, wn - p);
+            steps(p, cnt);
+            burst = nemchain::next_burst(burst, p - pos);
+            pos = p + cnt;
+        }
+    }
+};
+
+// lane's four memberships of class k for families i0 + 4 lane .. + 3 (class-major copy ct[K][npad]) and the four bits
+// of organism row `row` (organism-major bit rows) for the same families
+__device__ __forceinline__ void fuzzy_fetch(const float* __restrict__ ctk, const uint64_t* __restrict__ row, int i0, int lane,
+                                            int nw64, float4& c4, uint32_t& bits4)
+{
+    c4 = *reinterpret_cast<const float4*>(ctk + i0 + 4 * lane);
+    const int w = min((i0 >> 6) + (lane >> 4), nw64 - 1);
+    bits4 = row != nullptr ? (uint32_t)((row[w] >> ((4 * lane) & 63)) & 0xFull) : 0xFu;
+}
+
+// c [n][K] -> ct [K][npad] (zeros behind n)
+__device__ __forceinline__ void transpose_c_body(int n, int npad, int K, const float* __restrict__ c, float* __restrict__ ct,
+                                                 const int* __restrict__ stop)
+{
+    if (stop != nullptr && *stop) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    for (int k = 0; k < K; k++) ct[(size_t)k * npad + i] = i < n ? c[(size_t)i * K + k] : 0.0f;
+}
+
+// pass A: chains [0, D) inertia for mu = 0 (the ones), [D, 2D) for mu = 1 (the zeros), 2D: N_k, 2D + 1: mu = 1/2
+__device__ __forceinline__ void mstep_fuzzy_sums_body(const FuzzyArgs& a)
+{
+    if (a.stop != nullptr && *a.stop) return;
+    __shared__ float sx[256];
+    const int k = blockIdx.y, D = a.D, lane = threadIdx.x;
+    const int chain = blockIdx.x;
+    const int role = chain < D ? 0 : chain < 2 * D ? 1 : chain - 2 * D + 2;      // 0 ones, 1 zeros, 2 all, 3 halves
+    const int d = role == 0 ? chain : role == 1 ? chain - D : 0;
+    const uint64_t* row = role < 2 ? a.xt + (size_t)d * a.nw64 : nullptr;
+    const float* ctk = a.ct + (size_t)k * a.npad;
+    WaveChain wc{sx, 0.0f, nemchain::kBurst};
+    float4 cn; uint32_t bn;
+    fuzzy_fetch(ctk, row, 0, lane, a.nw64, cn, bn);
+    for (int i0 = 0; i0 < a.n; i0 += 256) {
+        const float4 c4 = cn; uint32_t b4 = bn;
+        if (i0 + 256 < a.n) fuzzy_fetch(ctk, row, i0 + 256, lane, a.nw64, cn, bn);
+        if (role == 1) b4 = ~b4;
+        float x[4] = {c4.x, c4.y, c4.z, c4.w};
+        const int wn = min(256, a.n - i0);
+        bool halves = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (role == 3) {                             // nem_mod.c:1683 with |x - 1/2| = 1/2: (float)((double)s + (double)c * 0.5)
+                const float h = x[j] * 0.5f;             //  = the float sum s + c/2 whenever c/2 is a float
+                halves = halves && (h * 2.0f == x[j]);
+                x[j] = h;
+            } else if (!((b4 >> j) & 1u) || 4 * lane + j >= wn) x[j] = -0.0f;     // not in this sum: the additive identity
+        }
+        if (role == 3 && __ballot(!halves) != 0ull) {    // an odd subnormal membership: this window in the double form
+            __syncthreads();
+            sx[4 * lane] = c4.x; sx[4 * lane + 1] = c4.y; sx[4 * lane + 2] = c4.z; sx[4 * lane + 3] = c4.w;
+            __syncthreads();
+            for (int j = 0; j < wn; j++) wc.acc = (float)((double)wc.acc + (double)sx[j] * 0.5);
+            continue;
+        }
+        __syncthreads();                                 // (one wave per block: the previous window's reads are done)
+        sx[4 * lane] = x[0]; sx[4 * lane + 1] = x[1]; sx[4 * lane + 2] = x[2]; sx[4 * lane + 3] = x[3];
+        __syncthreads();
+        wc.window(x, wn);
+    }
+    if (lane == 0) {
+        if (role == 0) a.in0[k * D + d] = wc.acc;
+        else if (role == 1) a.in1[k * D + d] = wc.acc;
+        else if (role == 2) a.nbobs_k[k] = wc.acc;
+        else a.inh_k[k] = wc.acc;
+    }
+}
+
+// pass B: ComputeMedian's prefix scan over the zeros of organism d against N_k / 2 (nem_mod.c:1439-1497), then the
+// centre and its inertia; a class without weight keeps its centres and gets its inertia against them (:1404-1408, 1669-1686)
+__device__ __forceinline__ void mstep_fuzzy_median_body(const FuzzyArgs& a)
+{
+    if (a.stop != nullptr && *a.stop) return;
+    __shared__ float sx[256];
+    const int k = blockIdx.y, D = a.D, lane = threadIdx.x, d = blockIdx.x;
+    const int t = k * D + d;
+    const uint64_t* row = a.xt + (size_t)d * a.nw64;
+    const float* ctk = a.ct + (size_t)k * a.npad;
+    const float nk = a.nbobs_k[k];
+    const bool empty = !((double)nk > kEpsilonD);
+    const float mu_old = a.center[t];
+    const float half = nk / 2;                           // nem_mod.c:1439
+    const double half_eps = (double)half + kEpsilonD;    // nem_mod.c:1464
+    WaveChain wc{sx, 0.0f, nemchain::kBurst};
+    int istar = a.n; float cum = 0.0f; bool crossed = false;
+    float4 cn; uint32_t bn;
+    fuzzy_fetch(ctk, row, 0, lane, a.nw64, cn, bn);
+    for (int i0 = 0; i0 < a.n && !crossed; i0 += 256) {
+        const float4 c4 = cn; const uint32_t b4 = bn;
+        if (i0 + 256 < a.n) fuzzy_fetch(ctk, row, i0 + 256, lane, a.nw64, cn, bn);
+        float x[4] = {c4.x, c4.y, c4.z, c4.w};
+        const int wn = min(256, a.n - i0);
+        bool exact = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool one = ((b4 >> j) & 1u) != 0;
+            if (4 * lane + j >= wn) x[j] = -0.0f;
+            else if (empty) {                            // c * |x - mu_old|, |.| in {0, 1/2, 1} for the centres the M-step makes
+                const float ad = fabsf((one ? 1.0f : 0.0f) - mu_old);
+                const float v = x[j] * ad;
+                exact = exact && (ad == 0.0f || ad == 1.0f || (ad == 0.5f && v * 2.0f == x[j]));
+                x[j] = ad == 0.0f ? -0.0f : v;
+            } else if (one) x[j] = -0.0f;                // the scan runs over the zeros
+        }
+        if (empty && __ballot(!exact) != 0ull) {         // a centre outside {0, 1/2, 1} (hand-made .m): the double form
+            __syncthreads();
+            sx[4 * lane] = c4.x; sx[4 * lane + 1] = c4.y; sx[4 * lane + 2] = c4.z; sx[4 * lane + 3] = c4.w;
+            __syncthreads();
+            for (int j = 0; j < wn; j++) {
+                const int i = i0 + j;
+                const bool one = ((row[i >> 6] >> (i & 63)) & 1ull) != 0;
+                wc.acc = (float)((double)wc.acc + (double)sx[j] * fabs((double)((one ? 1.0f : 0.0f) - mu_old)));   // :1683
+            }
+            continue;
+        }
+        __syncthreads();
+        sx[4 * lane] = x[0]; sx[4 * lane + 1] = x[1]; sx[4 * lane + 2] = x[2]; sx[4 * lane + 3] = x[3];
+        __syncthreads();
+        const float before = wc.acc;
+        wc.window(x, wn);
+        if (!empty && !(wc.acc < half)) {
+            // the weights are >= 0: the scan reached N_k / 2 inside this window -- walk it again for the family
+            float run = before;
+            for (int j = 0; j < wn; j++) {
+                run = run + sx[j];
+                if (!(run < half)) { istar = i0 + j; cum = run; break; }
+            }
+            crossed = true;
+        }
+    }
+    if (lane != 0) return;
+    if (empty) { a.iner[t] = wc.acc; return; }
+    float mu;
+    if (crossed) {                                       // median position among the zeros
+        const bool gt0 = (double)cum > half_eps;         // cum is the value at the crossing
+        const bool next0 = a.lastz[t] > istar;           // a zero of weight >= EPSILON follows the crossing
+        if (gt0 || next0) mu = 0.0f;                     // x_med = 0 (or midway to another 0)
+        else if (a.any1[t]) mu = 0.5f;                   // midway to the first one with weight
+        else mu = 0.0f;                                  // reference runs off the array here (UB)
+    } else mu = 1.0f;                                    // x_med = 1 (or midway to another 1)
+    a.center[t] = mu;
+    a.iner[t] = (mu == 0.0f) ? a.in0[t] : (mu == 1.0f ? a.in1[t] : a.inh_k[k]);
 }
 
 // CVTEST_CLAS for float partitions (nem_alg.c:2077-2088): converged iff no |c - cold| >= thres
@@ -2175,12 +2428,14 @@ __global__ __launch_bounds__(256) void k_mstep_counts_b(const void* arr, int str
 }
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(FuzzyArgs a)
 {
-    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop);
+    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop,
+                       a.ct != nullptr);
 }
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a_b(const void* arr, int stride, const int* gx)
 {
     NEM_B_HEAD(FuzzyArgs)
-    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop);
+    mstep_fuzzy_a_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.stop,
+                       a.ct != nullptr);
 }
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_b(FuzzyArgs a)
 {
@@ -2193,6 +2448,12 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b_b(const void* arr, int str
     mstep_fuzzy_b_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.center,
                        a.iner, a.stop);
 }
+__global__ void k_transpose_c(FuzzyArgs a) { transpose_c_body(a.n, a.npad, a.K, a.c, a.ct, a.stop); }
+__global__ void k_transpose_c_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) transpose_c_body(a.n, a.npad, a.K, a.c, a.ct, a.stop); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_sums(FuzzyArgs a) { mstep_fuzzy_sums_body(a); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_sums_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_sums_body(a); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_median(FuzzyArgs a) { mstep_fuzzy_median_body(a); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_median_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_median_body(a); }
 __global__ void k_conv_fuzzy(ConvFuzzyArgs a) { conv_fuzzy_body(a.m, a.c, a.cold, a.thres, a.flags, a.stop, a.ca, gridDim.x); }
 __global__ void k_conv_fuzzy_b(const void* arr, int stride, const int* gx)
 {
@@ -2380,15 +2641,28 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
 }
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
-                        float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
+                        float* ct, float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
                         float* iner, const int* stop, hipStream_t s)
 {
     const int DB = (D + 63) / 64;
-    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop};
+    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct};
+    if (ct == nullptr) {                                 // one lane per chain (kept for comparison: NEM_MI355X_FUZZY_CHAINS=0)
+        if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
+            hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
+        if (!record_op(OP_FUZZY_B, 0, dim3(DB, K), 64, a))
+            hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, a);
+        return;
+    }
+    // one wave per chain, 256 families per step: class-major copy of the memberships, the two order-free facts of
+    // ComputeMedian's tie rule, the sums, the medians
+    if (!record_op(OP_FUZZY_T, 0, dim3(npad / 256), 256, a))
+        hipLaunchKernelGGL(k_transpose_c, dim3(npad / 256), dim3(256), 0, s, a);
     if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
         hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
-    if (!record_op(OP_FUZZY_B, 0, dim3(DB, K), 64, a))
-        hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, a);
+    if (!record_op(OP_FUZZY_SUMS, 0, dim3(2 * D + 2, K), 64, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_sums, dim3(2 * D + 2, K), dim3(64), 0, s, a);
+    if (!record_op(OP_FUZZY_MED, 0, dim3(D, K), 64, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_median, dim3(D, K), dim3(64), 0, s, a);
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
@@ -2440,6 +2714,9 @@ void launch_zipped(int kind, int variant, int B, const void* arr, int stride, co
     case OP_CTRL: hipLaunchKernelGGL(k_ctrl_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FUZZY_A: hipLaunchKernelGGL(k_mstep_fuzzy_a_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FUZZY_B: hipLaunchKernelGGL(k_mstep_fuzzy_b_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_T: hipLaunchKernelGGL(k_transpose_c_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_SUMS: hipLaunchKernelGGL(k_mstep_fuzzy_sums_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_MED: hipLaunchKernelGGL(k_mstep_fuzzy_median_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_CONV_FUZZY: hipLaunchKernelGGL(k_conv_fuzzy_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_ONEHOT: hipLaunchKernelGGL(k_onehot_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_CRIT_TERMS: hipLaunchKernelGGL(k_crit_terms_b, grid, blk, 0, s, arr, stride, gx); break;

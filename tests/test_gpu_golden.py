@@ -43,7 +43,7 @@ def test_engine_matches_reference_golden(gpu_lib, name):
     assert maxdiff(got["prop"], exp["prop"]) <= TOL                      # pi
     assert maxdiff(got["nbobs_k"], exp["nbobs_k"]) <= 1e-6 * max(1.0, float(np.max(exp["nbobs_k"])))
     rel = np.abs(got["crit"].astype(np.float64) - exp["crit"]) / np.maximum(1.0, np.abs(exp["crit"]))
-    assert np.all((rel <= 1e-5) | ~np.isfinite(exp["crit"])), (got["crit"], exp["crit"])
+    assert np.all((rel <= 1e-6) | ~np.isfinite(exp["crit"])), (got["crit"], exp["crit"])
     assert (got["n_zero_density"] > 0) == bool(exp["zero_density"])
 
 
