@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SRC
+    cmd = [hipcc] + FLAGS + os.environ.get("NEM_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

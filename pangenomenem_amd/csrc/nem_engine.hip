@@ -304,7 +304,7 @@ int ensure_state_buffers(nemgpu_engine* e)
             if ((r = dev_alloc(&e->fz_inh, (size_t)e->k))) return r;
             if ((r = dev_alloc(&e->fz_lastz, kd))) return r;
             if ((r = dev_alloc(&e->fz_any1, kd))) return r;
-            if ((r = dev_alloc(&e->fz_ct, (size_t)e->k * e->npad))) return r;
+            if ((r = dev_alloc(&e->fz_ct, (size_t)e->k * ((size_t)(e->n + 1023) / 1024 * 1024)))) return r;   // [k][n up to whole 1024-family windows]
         }
     }
     return NEMGPU_OK;

@@ -958,6 +958,7 @@ __device__ __forceinline__ bool local_proba(const SweepArgs& a, int K, const dou
 // that a guess of the new partition carries the guess of who draws with it.
 constexpr int kLabMask = 0x7F, kLabDrew = 0x80;
 constexpr int kTabShort = 1 << 30;                       // in a round's FLAG_NTIES word: the draw table was too short
+constexpr int kFuzzyWaves = 4;                          // chains (waves) per block of the fuzzy M-step's chain kernels
 constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
 
 template <int KT, bool NCEM, int BS>
@@ -1888,8 +1889,21 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     return v;
 }
 
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware keeps a wave's LDS
+// operations in order; this only stops the compiler from moving them across (no block barrier: the chains of a
+// block's waves advance independently)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kEPL = 4;                                  // families per lane and window of the chain kernels
+constexpr int kWin = 64 * kEPL;                          // families per window
+
 struct WaveChain {
-    float* sx;                                           // LDS: the window's 256 addends, family order
+    float* sx;                                           // LDS: the window's kWin addends, family order
     float acc;                                           // the accumulator (the same value in every lane)
     int burst;
     // sequential float adds of sx[p .. p + count): the reference's own arithmetic, sixteen addends fetched ahead
@@ -1905,10 +1919,11 @@ struct WaveChain {
         }
         for (; i < count; i++) acc = acc + sx[p + i];
     }
-    // the window: wn (<= 256) addends, lane l holds x[0..3] = addends 4l .. 4l+3 (the same values are in sx)
-    __device__ __forceinline__ void window(const float (&x)[4], int wn)
+    // the window: wn (<= kWin) addends, lane l holds x[0 .. kEPL) = addends kEPL l .. (the same values are in sx).
+    // Branch-free per element: what an element adds and whether the integer form can take it are selects.
+    __device__ __forceinline__ void window(const float (&x)[kEPL], int wn)
     {
-        const int lane = threadIdx.x & 63;
+        const int e0 = kEPL * (int)(threadIdx.x & 63);
         int pos = 0;
         while (pos < wn) {
             const uint32_t ab = __float_as_uint(acc);
@@ -1922,35 +1937,59 @@ struct WaveChain {
             }
             const float sc = __uint_as_float((uint32_t)(127 + 150 - E) << 23);    // 1 / ulp(acc): 2^(150 - E), a normal float
             const uint32_t M0 = (ab & 0x7fffffu) | 0x800000u;
-            uint32_t inc[4];
-            int stop = 4;                                // first of my four the integer form cannot take
+            constexpr uint32_t top = 1u << 24;
+            if (pos == 0) {
+                // most windows hold nothing the integer form cannot take and end inside the binade they began in:
+                // then all that is needed is the sum of the increments (no scan, no search for the first stop)
+                uint32_t tot = 0; bool clean = true;
+#pragma unroll
+                for (int j = 0; j < kEPL; j++) {
+                    const float q = x[j] * sc;           // (addends behind wn are -0: increment 0)
+                    const float fl = floorf(q);
+                    const float fr = q - fl;
+                    clean = clean & (q >= 0.0f) & (q < 33554432.0f) & (fr != 0.5f);
+                    tot += (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
+                }
+                const bool small = tot < (1u << 17);     // (64 lanes of less than 2^17 cannot wrap 32 bits)
+                if (__ballot(!(clean & small)) == 0ull) {
+                    const uint32_t Mt = M0 + (uint32_t)wave_reduce_add((int)tot);
+                    if (Mt <= top) {
+                        acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
+                        burst = nemchain::next_burst(burst, wn);
+                        return;
+                    }
+                }
+            }
+            uint32_t inc[kEPL];
+            int stop = kEPL;                             // first of mine the integer form cannot take
             uint32_t lsum = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int e = 4 * lane + j;
-                inc[j] = 0;
-                if (e >= pos && e < wn && j < stop) {
-                    const float q = x[j] * sc;           // exact (a power-of-two scaling; an overflow gives inf)
-                    if (q == 0.0f) continue;             // +0 / -0: the identity
-                    if (!(q > 0.0f) || !(q < 33554432.0f)) { stop = j; continue; }   // shrinking, NaN, or 2^25 and more
-                    const float fl = floorf(q);
-                    const float fr = q - fl;             // exact
-                    if (fr == 0.5f) { stop = j; continue; }                          // a tie: the parity of M decides
-                    inc[j] = (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
-                    lsum += inc[j];
-                }
+            for (int j = 0; j < kEPL; j++) {
+                const int e = e0 + j;
+                const bool act = (e >= pos) & (e < wn);
+                const float q = x[j] * sc;               // exact (a power-of-two scaling; an overflow gives inf)
+                const float fl = floorf(q);
+                const float fr = q - fl;                 // exact
+                // takeable: 0 <= q < 2^25 (a shrinking sum, NaN or inf fail the compares) and not a tie (its rounding
+                // depends on the parity of M)
+                const bool ok = (q >= 0.0f) & (q < 33554432.0f) & (fr != 0.5f);
+                const uint32_t v = (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
+                const bool first_bad = act & !ok & (stop == kEPL);
+                stop = first_bad ? j : stop;
+                inc[j] = (act & ok & (stop == kEPL)) ? v : 0u;
+                lsum += inc[j];
             }
             const uint32_t incl = wave_scan_incl(lsum);
             uint32_t M = M0 + incl - lsum;
             int cand = INT_MAX; uint32_t candM = 0;
-            constexpr uint32_t top = 1u << 24;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int e = 4 * lane + j;
-                if (e >= pos && e < wn && cand == INT_MAX) {
-                    if (j == stop || M >= top || M + inc[j] > top) { cand = e; candM = M; }
-                    else M += inc[j];
-                }
+            for (int j = 0; j < kEPL; j++) {
+                const int e = e0 + j;
+                const bool act = (e >= pos) & (e < wn);
+                const bool hit = act & (cand == INT_MAX) & ((j == stop) | (M >= top) | (M + inc[j] > top));
+                candM = hit ? M : candM;
+                cand = hit ? e : cand;
+                M += inc[j];
             }
             const uint64_t who = __ballot(cand != INT_MAX);
             if (who == 0ull) {                           // the rest of the window went through in integer form
@@ -1972,70 +2011,117 @@ struct WaveChain {
     }
 };
 
-// lane's four memberships of class k for families i0 + 4 lane .. + 3 (class-major copy ct[K][npad]) and the four bits
-// of organism row `row` (organism-major bit rows) for the same families
+// One window's inputs of a lane: its kEPL memberships of class k (class-major copy ct[K][npad]) for families
+// i0 + kEPL lane .. and the word of organism row `row` that holds their bits.  (The word is handed on as loaded:
+// shifting it here would make the fetch wait for its own load, and the fetch runs ahead of its use.)
+struct FuzzyIn { float4 c[kEPL / 4]; uint64_t word; };
 __device__ __forceinline__ void fuzzy_fetch(const float* __restrict__ ctk, const uint64_t* __restrict__ row, int i0, int lane,
-                                            int nw64, float4& c4, uint32_t& bits4)
+                                            int nw64, FuzzyIn& in)
 {
-    c4 = *reinterpret_cast<const float4*>(ctk + i0 + 4 * lane);
-    const int w = min((i0 >> 6) + (lane >> 4), nw64 - 1);
-    bits4 = row != nullptr ? (uint32_t)((row[w] >> ((4 * lane) & 63)) & 0xFull) : 0xFu;
+    const float4* p = reinterpret_cast<const float4*>(ctk + i0 + kEPL * lane);
+#pragma unroll
+    for (int t = 0; t < kEPL / 4; t++) in.c[t] = p[t];
+    const int w = min((i0 >> 6) + ((kEPL * lane) >> 6), nw64 - 1);
+    in.word = row != nullptr ? row[w] : ~0ull;
+}
+__device__ __forceinline__ uint32_t fuzzy_bits(uint64_t word, int lane) { return (uint32_t)(word >> ((kEPL * lane) & 63)) & ((1u << kEPL) - 1u); }
+__device__ __forceinline__ void fuzzy_unpack(const FuzzyIn& in, float (&x)[kEPL])
+{
+#pragma unroll
+    for (int t = 0; t < kEPL / 4; t++) { x[4 * t] = in.c[t].x; x[4 * t + 1] = in.c[t].y; x[4 * t + 2] = in.c[t].z; x[4 * t + 3] = in.c[t].w; }
+}
+__device__ __forceinline__ void fuzzy_stage(float* sx, int lane, const float (&x)[kEPL])
+{
+    float4* d = reinterpret_cast<float4*>(sx + kEPL * lane);
+#pragma unroll
+    for (int t = 0; t < kEPL / 4; t++) d[t] = make_float4(x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]);
 }
 
-// c [n][K] -> ct [K][npad] (zeros behind n)
-__device__ __forceinline__ void transpose_c_body(int n, int npad, int K, const float* __restrict__ c, float* __restrict__ ct,
+// c [n][K] -> ct [K][ctpad] (zeros behind n; ctpad: n rounded up to whole windows)
+__device__ __forceinline__ void transpose_c_body(int n, int ctpad, int K, const float* __restrict__ c, float* __restrict__ ct,
                                                  const int* __restrict__ stop)
 {
     if (stop != nullptr && *stop) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= npad) return;
-    for (int k = 0; k < K; k++) ct[(size_t)k * npad + i] = i < n ? c[(size_t)i * K + k] : 0.0f;
+    if (i >= ctpad) return;
+    for (int k = 0; k < K; k++) ct[(size_t)k * ctpad + i] = i < n ? c[(size_t)i * K + k] : 0.0f;
 }
 
 // pass A: chains [0, D) inertia for mu = 0 (the ones), [D, 2D) for mu = 1 (the zeros), 2D: N_k, 2D + 1: mu = 1/2
 __device__ __forceinline__ void mstep_fuzzy_sums_body(const FuzzyArgs& a)
 {
     if (a.stop != nullptr && *a.stop) return;
-    __shared__ float sx[256];
-    const int k = blockIdx.y, D = a.D, lane = threadIdx.x;
-    const int chain = blockIdx.x;
+    __shared__ float sx_all[kFuzzyWaves][kWin];
+    const int k = blockIdx.y, D = a.D, lane = threadIdx.x & 63;
+    const int chain = blockIdx.x * kFuzzyWaves + (threadIdx.x >> 6);             // one chain per wave
+    if (chain >= 2 * D + 2) return;
+    float* sx = sx_all[threadIdx.x >> 6];
     const int role = chain < D ? 0 : chain < 2 * D ? 1 : chain - 2 * D + 2;      // 0 ones, 1 zeros, 2 all, 3 halves
     const int d = role == 0 ? chain : role == 1 ? chain - D : 0;
     const uint64_t* row = role < 2 ? a.xt + (size_t)d * a.nw64 : nullptr;
-    const float* ctk = a.ct + (size_t)k * a.npad;
+    const float* ctk = a.ct + (size_t)k * a.ctpad;
     WaveChain wc{sx, 0.0f, nemchain::kBurst};
-    float4 cn; uint32_t bn;
-    fuzzy_fetch(ctk, row, 0, lane, a.nw64, cn, bn);
-    for (int i0 = 0; i0 < a.n; i0 += 256) {
-        const float4 c4 = cn; uint32_t b4 = bn;
-        if (i0 + 256 < a.n) fuzzy_fetch(ctk, row, i0 + 256, lane, a.nw64, cn, bn);
-        if (role == 1) b4 = ~b4;
-        float x[4] = {c4.x, c4.y, c4.z, c4.w};
-        const int wn = min(256, a.n - i0);
+    int fact = -1;                                       // this lane's last family of the sum with a weight >= EPSILON
+    // Four windows are in flight ahead of the one being summed (a window's arithmetic is shorter than a trip to
+    // memory): four register sets, each refilled right after use.  Every fetch is issued unconditionally (behind the
+    // last window it repeats the last one), so that the compiler counts outstanding loads exactly and waits for the
+    // oldest only.
+    const int nwin = (a.n + kWin - 1) / kWin;
+    int gi = 0;
+    auto fetch = [&](FuzzyIn& dst) { fuzzy_fetch(ctk, row, min(gi, nwin - 1) * kWin, lane, a.nw64, dst); gi++; };
+    auto take = [&](const FuzzyIn& cur, const int i0) {
+        uint32_t b = fuzzy_bits(cur.word, lane);
+        if (role == 1) b = ~b;
+        float x[kEPL];
+        fuzzy_unpack(cur, x);
+        const int wn = min(kWin, a.n - i0);
         bool halves = true;
+        if (role < 2) {
+            // the two order-free facts ComputeMedian's tie rule needs (nem_mod.c:1470-1483), beside the sums: whether
+            // some ONE has a weight >= EPSILON (with the ones' sum), the last ZERO that has (with the zeros' sum)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < kEPL; j++) {
+                const bool in = ((b >> j) & 1u) != 0 && kEPL * lane + j < wn;
+                if (in && !((double)x[j] < kEpsilonD)) fact = i0 + kEPL * lane + j;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kEPL; j++) {
             if (role == 3) {                             // nem_mod.c:1683 with |x - 1/2| = 1/2: (float)((double)s + (double)c * 0.5)
                 const float h = x[j] * 0.5f;             //  = the float sum s + c/2 whenever c/2 is a float
                 halves = halves && (h * 2.0f == x[j]);
                 x[j] = h;
-            } else if (!((b4 >> j) & 1u) || 4 * lane + j >= wn) x[j] = -0.0f;     // not in this sum: the additive identity
+            } else if (!((b >> j) & 1u) || kEPL * lane + j >= wn) x[j] = -0.0f;   // not in this sum: the additive identity
         }
         if (role == 3 && __ballot(!halves) != 0ull) {    // an odd subnormal membership: this window in the double form
-            __syncthreads();
-            sx[4 * lane] = c4.x; sx[4 * lane + 1] = c4.y; sx[4 * lane + 2] = c4.z; sx[4 * lane + 3] = c4.w;
-            __syncthreads();
+            float raw[kEPL];
+            fuzzy_unpack(cur, raw);
+            wave_lds_sync();
+            fuzzy_stage(sx, lane, raw);
+            wave_lds_sync();
             for (int j = 0; j < wn; j++) wc.acc = (float)((double)wc.acc + (double)sx[j] * 0.5);
-            continue;
+            return;
         }
-        __syncthreads();                                 // (one wave per block: the previous window's reads are done)
-        sx[4 * lane] = x[0]; sx[4 * lane + 1] = x[1]; sx[4 * lane + 2] = x[2]; sx[4 * lane + 3] = x[3];
-        __syncthreads();
+        wave_lds_sync();                                 // (the previous window's reads are done)
+        fuzzy_stage(sx, lane, x);
+        wave_lds_sync();
         wc.window(x, wn);
+    };
+    FuzzyIn r0, r1, r2, r3;
+    fetch(r0); fetch(r1); fetch(r2); fetch(r3);
+    for (int w = 0; w < nwin; w += 4) {
+        take(r0, w * kWin); fetch(r0);
+        if (w + 1 < nwin) { take(r1, (w + 1) * kWin); fetch(r1); }
+        if (w + 2 < nwin) { take(r2, (w + 2) * kWin); fetch(r2); }
+        if (w + 3 < nwin) { take(r3, (w + 3) * kWin); fetch(r3); }
+    }
+    if (role < 2) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) fact = max(fact, __shfl_xor(fact, o));
     }
     if (lane == 0) {
-        if (role == 0) a.in0[k * D + d] = wc.acc;
-        else if (role == 1) a.in1[k * D + d] = wc.acc;
+        if (role == 0) { a.in0[k * D + d] = wc.acc; a.any1[k * D + d] = fact >= 0 ? 1 : 0; }
+        else if (role == 1) { a.in1[k * D + d] = wc.acc; a.lastz[k * D + d] = fact; }
         else if (role == 2) a.nbobs_k[k] = wc.acc;
         else a.inh_k[k] = wc.acc;
     }
@@ -2046,11 +2132,13 @@ __device__ __forceinline__ void mstep_fuzzy_sums_body(const FuzzyArgs& a)
 __device__ __forceinline__ void mstep_fuzzy_median_body(const FuzzyArgs& a)
 {
     if (a.stop != nullptr && *a.stop) return;
-    __shared__ float sx[256];
-    const int k = blockIdx.y, D = a.D, lane = threadIdx.x, d = blockIdx.x;
+    __shared__ float sx_all[kFuzzyWaves][kWin];
+    const int k = blockIdx.y, D = a.D, lane = threadIdx.x & 63, d = blockIdx.x * kFuzzyWaves + (threadIdx.x >> 6);
+    if (d >= D) return;
+    float* sx = sx_all[threadIdx.x >> 6];
     const int t = k * D + d;
     const uint64_t* row = a.xt + (size_t)d * a.nw64;
-    const float* ctk = a.ct + (size_t)k * a.npad;
+    const float* ctk = a.ct + (size_t)k * a.ctpad;
     const float nk = a.nbobs_k[k];
     const bool empty = !((double)nk > kEpsilonD);
     const float mu_old = a.center[t];
@@ -2058,18 +2146,19 @@ __device__ __forceinline__ void mstep_fuzzy_median_body(const FuzzyArgs& a)
     const double half_eps = (double)half + kEpsilonD;    // nem_mod.c:1464
     WaveChain wc{sx, 0.0f, nemchain::kBurst};
     int istar = a.n; float cum = 0.0f; bool crossed = false;
-    float4 cn; uint32_t bn;
-    fuzzy_fetch(ctk, row, 0, lane, a.nw64, cn, bn);
-    for (int i0 = 0; i0 < a.n && !crossed; i0 += 256) {
-        const float4 c4 = cn; const uint32_t b4 = bn;
-        if (i0 + 256 < a.n) fuzzy_fetch(ctk, row, i0 + 256, lane, a.nw64, cn, bn);
-        float x[4] = {c4.x, c4.y, c4.z, c4.w};
-        const int wn = min(256, a.n - i0);
+    const int nwin = (a.n + kWin - 1) / kWin;            // (four windows in flight: see mstep_fuzzy_sums_body)
+    int gi = 0;
+    auto fetch = [&](FuzzyIn& dst) { fuzzy_fetch(ctk, row, min(gi, nwin - 1) * kWin, lane, a.nw64, dst); gi++; };
+    auto take = [&](const FuzzyIn& cur, const int i0) {
+        const uint32_t b = fuzzy_bits(cur.word, lane);
+        float x[kEPL];
+        fuzzy_unpack(cur, x);
+        const int wn = min(kWin, a.n - i0);
         bool exact = true;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool one = ((b4 >> j) & 1u) != 0;
-            if (4 * lane + j >= wn) x[j] = -0.0f;
+        for (int j = 0; j < kEPL; j++) {
+            const bool one = ((b >> j) & 1u) != 0;
+            if (kEPL * lane + j >= wn) x[j] = -0.0f;
             else if (empty) {                            // c * |x - mu_old|, |.| in {0, 1/2, 1} for the centres the M-step makes
                 const float ad = fabsf((one ? 1.0f : 0.0f) - mu_old);
                 const float v = x[j] * ad;
@@ -2078,19 +2167,21 @@ __device__ __forceinline__ void mstep_fuzzy_median_body(const FuzzyArgs& a)
             } else if (one) x[j] = -0.0f;                // the scan runs over the zeros
         }
         if (empty && __ballot(!exact) != 0ull) {         // a centre outside {0, 1/2, 1} (hand-made .m): the double form
-            __syncthreads();
-            sx[4 * lane] = c4.x; sx[4 * lane + 1] = c4.y; sx[4 * lane + 2] = c4.z; sx[4 * lane + 3] = c4.w;
-            __syncthreads();
+            float raw[kEPL];
+            fuzzy_unpack(cur, raw);
+            wave_lds_sync();
+            fuzzy_stage(sx, lane, raw);
+            wave_lds_sync();
             for (int j = 0; j < wn; j++) {
                 const int i = i0 + j;
                 const bool one = ((row[i >> 6] >> (i & 63)) & 1ull) != 0;
                 wc.acc = (float)((double)wc.acc + (double)sx[j] * fabs((double)((one ? 1.0f : 0.0f) - mu_old)));   // :1683
             }
-            continue;
+            return;
         }
-        __syncthreads();
-        sx[4 * lane] = x[0]; sx[4 * lane + 1] = x[1]; sx[4 * lane + 2] = x[2]; sx[4 * lane + 3] = x[3];
-        __syncthreads();
+        wave_lds_sync();
+        fuzzy_stage(sx, lane, x);
+        wave_lds_sync();
         const float before = wc.acc;
         wc.window(x, wn);
         if (!empty && !(wc.acc < half)) {
@@ -2102,6 +2193,14 @@ __device__ __forceinline__ void mstep_fuzzy_median_body(const FuzzyArgs& a)
             }
             crossed = true;
         }
+    };
+    FuzzyIn r0, r1, r2, r3;
+    fetch(r0); fetch(r1); fetch(r2); fetch(r3);
+    for (int w = 0; w < nwin && !crossed; w += 4) {
+        take(r0, w * kWin); fetch(r0);
+        if (w + 1 < nwin && !crossed) { take(r1, (w + 1) * kWin); fetch(r1); }
+        if (w + 2 < nwin && !crossed) { take(r2, (w + 2) * kWin); fetch(r2); }
+        if (w + 3 < nwin && !crossed) { take(r3, (w + 3) * kWin); fetch(r3); }
     }
     if (lane != 0) return;
     if (empty) { a.iner[t] = wc.acc; return; }
@@ -2448,12 +2547,12 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b_b(const void* arr, int str
     mstep_fuzzy_b_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.center,
                        a.iner, a.stop);
 }
-__global__ void k_transpose_c(FuzzyArgs a) { transpose_c_body(a.n, a.npad, a.K, a.c, a.ct, a.stop); }
-__global__ void k_transpose_c_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) transpose_c_body(a.n, a.npad, a.K, a.c, a.ct, a.stop); }
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_sums(FuzzyArgs a) { mstep_fuzzy_sums_body(a); }
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_sums_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_sums_body(a); }
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_median(FuzzyArgs a) { mstep_fuzzy_median_body(a); }
-__global__ __launch_bounds__(64) void k_mstep_fuzzy_median_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_median_body(a); }
+__global__ void k_transpose_c(FuzzyArgs a) { transpose_c_body(a.n, a.ctpad, a.K, a.c, a.ct, a.stop); }
+__global__ void k_transpose_c_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) transpose_c_body(a.n, a.ctpad, a.K, a.c, a.ct, a.stop); }
+__global__ __launch_bounds__(64 * kFuzzyWaves) void k_mstep_fuzzy_sums(FuzzyArgs a) { mstep_fuzzy_sums_body(a); }
+__global__ __launch_bounds__(64 * kFuzzyWaves) void k_mstep_fuzzy_sums_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_sums_body(a); }
+__global__ __launch_bounds__(64 * kFuzzyWaves) void k_mstep_fuzzy_median(FuzzyArgs a) { mstep_fuzzy_median_body(a); }
+__global__ __launch_bounds__(64 * kFuzzyWaves) void k_mstep_fuzzy_median_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_median_body(a); }
 __global__ void k_conv_fuzzy(ConvFuzzyArgs a) { conv_fuzzy_body(a.m, a.c, a.cold, a.thres, a.flags, a.stop, a.ca, gridDim.x); }
 __global__ void k_conv_fuzzy_b(const void* arr, int stride, const int* gx)
 {
@@ -2645,7 +2744,8 @@ void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const
                         float* iner, const int* stop, hipStream_t s)
 {
     const int DB = (D + 63) / 64;
-    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct};
+    const int ctpad = (n + kWin - 1) / kWin * kWin;
+    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct, ctpad};
     if (ct == nullptr) {                                 // one lane per chain (kept for comparison: NEM_MI355X_FUZZY_CHAINS=0)
         if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
             hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
@@ -2653,16 +2753,15 @@ void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const
             hipLaunchKernelGGL(k_mstep_fuzzy_b, dim3(DB, K), dim3(64), 0, s, a);
         return;
     }
-    // one wave per chain, 256 families per step: class-major copy of the memberships, the two order-free facts of
-    // ComputeMedian's tie rule, the sums, the medians
-    if (!record_op(OP_FUZZY_T, 0, dim3(npad / 256), 256, a))
-        hipLaunchKernelGGL(k_transpose_c, dim3(npad / 256), dim3(256), 0, s, a);
-    if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
-        hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
-    if (!record_op(OP_FUZZY_SUMS, 0, dim3(2 * D + 2, K), 64, a))
-        hipLaunchKernelGGL(k_mstep_fuzzy_sums, dim3(2 * D + 2, K), dim3(64), 0, s, a);
-    if (!record_op(OP_FUZZY_MED, 0, dim3(D, K), 64, a))
-        hipLaunchKernelGGL(k_mstep_fuzzy_median, dim3(D, K), dim3(64), 0, s, a);
+    // one wave per chain, 256 families per step: class-major copy of the memberships, the sums (and with them the two
+    // order-free facts of ComputeMedian's tie rule), the medians
+    if (!record_op(OP_FUZZY_T, 0, dim3(ctpad / 256), 256, a))
+        hipLaunchKernelGGL(k_transpose_c, dim3(ctpad / 256), dim3(256), 0, s, a);
+    const dim3 gs((2 * D + 2 + kFuzzyWaves - 1) / kFuzzyWaves, K), gm((D + kFuzzyWaves - 1) / kFuzzyWaves, K);
+    if (!record_op(OP_FUZZY_SUMS, 0, gs, 64 * kFuzzyWaves, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_sums, gs, dim3(64 * kFuzzyWaves), 0, s, a);
+    if (!record_op(OP_FUZZY_MED, 0, gm, 64 * kFuzzyWaves, a))
+        hipLaunchKernelGGL(k_mstep_fuzzy_median, gm, dim3(64 * kFuzzyWaves), 0, s, a);
 }
 
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,

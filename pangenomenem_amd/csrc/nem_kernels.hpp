@@ -85,7 +85,7 @@ struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const 
 struct CountsArgs { int K, D, nw64; const uint64_t* xt; const uint64_t* mask; int* stats; const int* stop; CtrlArgs prev_ctrl; };
 struct FuzzyArgs { int n, npad, K, D; const uint32_t* xw; const uint64_t* xt; int nw64; const float* c; float* nbobs_k;
                    float* in0; float* in1; float* inh_k; int* lastz; int* any1; float* center; float* iner; const int* stop;
-                   float* ct; };   // ct: class-major copy of c, [K][npad] (nullptr: the one-lane-per-chain kernels)
+                   float* ct; int ctpad; };   // ct: class-major copy of c, [K][ctpad] (nullptr: the one-lane-per-chain kernels)
 struct ConvFuzzyArgs { size_t m; const float* c; const float* cold; float thres; int* flags; const int* stop; CtrlArgs ca; };
 struct OnehotArgs { int n, K; const uint8_t* lab; float* c; };
 struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const float* nei_w; int use_nei; float beta;
