@@ -138,7 +138,9 @@ class EngineRun:
         eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="clas", cvthres=1e-8, it_max=100)
         first = eng.run()
         self.first = first
-        self.cycle = max(1, int(first["iters"]))
+        # (a run that ends with an empty class -- K = 9 of the K sweep -- stops in the M-step of its last iteration:
+        #  the iterations before it are the ones that can be timed)
+        self.cycle = max(1, int(first["iters"]) - (1 if first["status"] != 0 else 0))
         eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="none", it_max=100)
         eng.set_graph_policy(True)
 
@@ -166,7 +168,7 @@ class EngineRun:
             graphs_primed=(c1["captured"] == c0["captured"] and c1["plain"] == c0["plain"]),
             graph_replays_timed=c1["replayed"] - c0["replayed"],
             host_finished_sweeps_timed=c1["host_finished_sweeps"] - c0["host_finished_sweeps"],
-            iters_to_converge=int(self.first["iters"]), cycle_iterations=self.cycle,
+            iters_to_converge=int(self.first["iters"]), cycle_iterations=self.cycle, run_status=int(self.first["status"]),
             # two initial sweeps per restart ride in the total; the rest are the iterations' own
             sweep_rounds_per_iteration=(rounds - 2 * restarts) / max(steps, 1) if rounds else None,
         )

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Chunk throughput of the drop-in nem() on one GPU: P independent configs[1]-sized problems (files on /tmp),
-one after the other vs. several worker threads (pangenomenem_amd.batch.nem_many).  Prints one JSON object."""
+"""Chunk throughput on one GPU, whole problems (upload included): P independent configs[1]-sized problems through the
+drop-in nem() (files on /tmp) on 1..16 worker threads (pangenomenem_amd.batch.nem_many), and in memory through
+solve_many -- engines built on `w` host threads, then ONE lock-step batch (nemgpu_run_many).  Prints one JSON object."""
 import json
 import os
 import shutil

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-2 profile collection.  Runs on the GPU box from the repo root:
+#     gpurun --timeout 1100 -- 'bash profiles/collect_r02.sh'
+# then, back in the container:   python profiles/summarize.py r02
+# Kernel timing (--kernel-trace --stats) and each PMC counter are separate runs, as MI355X_MICROARCH.md's
+# HBM / rocprofv3 section prescribes; the program itself follows `--` (no env/bash hop).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+R=r02
+mkdir -p $O
+Q="--no-cpu-baseline --no-north-star"
+# the default bench line (configs[1], CPU baseline and north-star block) and the line as the driver asks for it
+python3 bench.py > $O/${R}_bench_c2.json 2> $O/${R}_bench_c2.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${R}_bench_c2_driver.json 2> /dev/null
+echo "[collect] bench lines done"
+# per-kernel durations: C2 (default command), C2 on the three-latent-class generator, C3, C4, the fuzzy path
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_c2 -- python3 bench.py $Q > $O/${R}_c2_prof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_c3 -- python3 bench.py --families 50000 --organisms 1000 --steps 220 --warmup 22 $Q > $O/${R}_c3_prof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_c4 -- python3 bench.py --families 200000 --organisms 5000 --steps 20 --warmup 4 $Q > $O/${R}_c4_prof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_c2_fuzzy -- python3 bench.py --algo nem --steps 50 --warmup 5 $Q > $O/${R}_c2_fuzzy_prof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_b16 -- python3 profiles/batch_lockstep.py 20000 500 16 > $O/${R}_b16_prof.json 2> /dev/null
+echo "[collect] kernel traces done"
+# HBM traffic counters, one counter per run: C2, C4, the lock-step batch of 16
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_c2_fetch -- python3 bench.py --steps 56 --warmup 7 $Q > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_c2_write -- python3 bench.py --steps 56 --warmup 7 $Q > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_c4_fetch -- python3 bench.py --families 200000 --organisms 5000 --steps 10 --warmup 2 $Q > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_c4_write -- python3 bench.py --families 200000 --organisms 5000 --steps 10 --warmup 2 $Q > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_b16_fetch -- python3 profiles/batch_lockstep.py 20000 500 16 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${R}_b16_write -- python3 profiles/batch_lockstep.py 20000 500 16 > /dev/null 2>&1
+# FETCH_SIZE calibration: a known 1 GiB read, 16 bytes per lane
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${R}_calib -- python3 -c "from pangenomenem_amd.engine import calibrate_fetch; calibrate_fetch(1 << 30, 3)" > /dev/null 2>&1
+echo "[collect] counters done"
+# unprofiled bench lines of the same build (C3, C4), the fuzzy path, the sharded driver on one GPU and on two ranks (gloo)
+python3 bench.py --families 50000 --organisms 1000 --steps 1100 --warmup 110 $Q > $O/${R}_bench_50000x1000.json 2> /dev/null
+python3 bench.py --families 200000 --organisms 5000 --steps 300 --warmup 30 $Q > $O/${R}_bench_200000x5000.json 2> /dev/null
+python3 bench.py --spectrum latent3 $Q > $O/${R}_bench_20000x500_latent3.json 2> /dev/null
+python3 bench.py --algo nem --steps 300 --warmup 30 $Q > $O/${R}_bench_20000x500_fuzzy.json 2> /dev/null
+python3 bench.py --disper skd $Q > $O/${R}_bench_20000x500_skd.json 2> /dev/null
+python3 bench.py --dist --no-cpu-baseline > $O/${R}_bench_dist_world1.json 2> /dev/null
+python3 bench.py --gpus 2 --backend gloo --steps 220 --warmup 22 > $O/${R}_bench_2ranks_gloo_one_gpu.json 2> /dev/null
+echo "[collect] bench variants done"
+# BASELINE configs[4]: the K sweep (20 000 x 500, skd), one line per K
+rm -f $O/${R}_ksweep.jsonl
+for k in 2 3 4 5 6 7 8 9 10; do python3 bench.py --k $k --steps 200 --warmup 20 $Q >> $O/${R}_ksweep.jsonl 2> /dev/null; done
+echo "[collect] K sweep done"
+# lock-step batches, random starts, whole chunks, host-buffer-inclusive solve, the fuzzy M-step alone
+python3 profiles/batch_lockstep.py > $O/${R}_batch_lockstep.json 2> /dev/null
+python3 profiles/random_starts.py > $O/${R}_random_starts.json 2> /dev/null
+python3 profiles/batch_chunks.py > $O/${R}_batch_chunks.json 2> /dev/null
+python3 profiles/pcie_inclusive.py > $O/${R}_pcie_inclusive.json 2> /dev/null
+python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep.txt 2> /dev/null
+NEM_MI355X_FUZZY_CHAINS=0 python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep_lane_per_chain.txt 2> /dev/null
+echo "[collect] done"
+cat $O/${R}_bench_c2_driver.json
