@@ -56,8 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--families", type=int, default=None,
                     help="families: of the problem (1 GPU, strong scaling) or per GPU (weak scaling)")
     ap.add_argument("--organisms", type=int, default=None)
-    ap.add_argument("--k", type=int, default=3,
-                    help="classes; K != 3 runs BASELINE configs[4]: 10-latent-group data, K-class .m, skd")
+    ap.add_argument("--k", type=int, default=None,
+                    help="classes (default 3); given: BASELINE configs[4], the K sweep -- 10-latent-group data, K-class .m, skd")
     ap.add_argument("--algo", default="ncem")
     ap.add_argument("--disper", default=None, help="dispersion model (default sk_, BASELINE's; skd for --k != 3)")
     ap.add_argument("--spectrum", default="ushape", choices=["ushape", "latent3"])
@@ -100,11 +100,11 @@ def self_launch(args):
 # ----------------------------------------------------------------------------------------------------------------
 # workloads
 # ----------------------------------------------------------------------------------------------------------------
-def make_workload(n, d, k, spectrum, seed):
+def make_workload(n, d, k, spectrum, seed, ksweep=False):
     """(x, nei, prop, center, disp, disper, description)"""
     from pangenomenem_amd import synth
     nei = synth.contiguity_graph(n, seed)
-    if k != 3:
+    if ksweep:
         x, _ = synth.grouped_pa_matrix(n, d, 5, groups=10)
         prop, center, disp = synth.kclass_init(x, k)
         return x, nei, prop, center, disp, "skd", "10-latent-group matrix (SURVEY.md 8d, C5), deterministic K-class .m"
@@ -279,17 +279,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     from pangenomenem_amd import build as nem_build
-    k, beta = args.k, 0.5
+    ksweep = args.k is not None
+    k, beta = (args.k if ksweep else 3), 0.5
     sharded = world > 1 or args.dist
     if args.disper is None:
-        args.disper = "sk_" if k == 3 else "skd"
-    if sharded and k != 3:
+        args.disper = "skd" if ksweep else "sk_"
+    if sharded and ksweep:
         raise SystemExit("the sharded path benchmarks K = 3 (BASELINE configs[2])")
 
     if not sharded:
         nem_build.build()                          # no-op when the in-tree library is up to date
         n_tot, d = args.families or 20000, args.organisms or 500
-        x, nei, prop, center, disp, _, what = make_workload(n_tot, d, k, args.spectrum, 2)
+        x, nei, prop, center, disp, _, what = make_workload(n_tot, d, k, args.spectrum, 2, ksweep)
         run = EngineRun(x, nei, k, prop, center, disp, args.algo, beta, args.disper)
         dt_max, extra = run.timed(args.steps, args.warmup)
         # E1 kernel duration: HIP events on the engine's stream around individual launches, on the state the
@@ -352,8 +353,8 @@ def main():
     if rank == 0:
         ms_per_step = dt_max * 1e3 / args.steps
         cells_per_s = n_tot * d * args.steps / dt_max
-        shape = SHAPES.get((n_tot, d), "custom shape") if (k == 3 and args.disper == "sk_") else \
-            ("BASELINE configs[4] (K-sweep)" if (n_tot, d) == (20000, 500) and args.disper == "skd" else "custom model")
+        shape = ("BASELINE configs[4] (K sweep)" if (n_tot, d) == (20000, 500) and args.disper == "skd" else "custom model") \
+            if ksweep else (SHAPES.get((n_tot, d), "custom shape") if args.disper == "sk_" else "custom model")
         out = {
             "metric": "em_family_x_organism_cells_per_sec",
             "value": cells_per_s,
@@ -388,7 +389,7 @@ def main():
             except Exception as exc:   # the checker is optional on the box; the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 1, "kind": "unavailable",
                                        "sample": "failed: %r" % (exc,)}
-        if not sharded and not args.no_north_star and k == 3:
+        if not sharded and not args.no_north_star and not ksweep:
             try:
                 run.eng.close()
                 out["north_star_target"] = north_star_target(args)

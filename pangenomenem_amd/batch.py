@@ -40,16 +40,30 @@ def _build(problem, device, cfg):
 
 def solve_many(problems, workers=8, group=64, device=0, **cfg):
     """problems = [(x, nei, k, prop, center, disp), ...]; returns their solve() results, each bit-identical to the
-    problem solved alone.  workers: host threads building the engines (bit-packing and uploads); group: problems
-    per lock-step batch."""
+    problem solved alone.  workers: host threads that build the engines (bit-packing, uploads) and fetch the results;
+    group: problems per lock-step batch.  While one group runs on the GPU the next one is being built."""
     out = []
     group = max(1, int(group))
+
+    def finish(engines, metas):
+        def fetch(pair):
+            eng, meta = pair
+            meta.update(eng.results())
+            eng.close()
+            return meta
+        return list(pool.map(fetch, zip(engines, metas)))
+
     with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
-        for g0 in range(0, len(problems), group):
-            engines = list(pool.map(lambda p: _build(p, device, cfg), problems[g0:g0 + group]))
+        chunks = [problems[g0:g0 + group] for g0 in range(0, len(problems), group)]
+        building = [pool.submit(_build, p, device, cfg) for p in chunks[0]] if chunks else []
+        for ci in range(len(chunks)):
+            engines = [f.result() for f in building]
+            building = [pool.submit(_build, p, device, cfg) for p in chunks[ci + 1]] if ci + 1 < len(chunks) else []
             try:
-                out.extend(run_many(engines))
-            finally:
+                metas = run_many(engines, fetch=False)
+            except Exception:
                 for e in engines:
                     e.close()
+                raise
+            out.extend(finish(engines, metas))
     return out

@@ -358,9 +358,10 @@ class NemEngine:
         self._chk(self.lib.nemgpu_set_stream(self._h, C.c_void_p(stream_ptr)))
 
 
-def run_many(engines):
+def run_many(engines, fetch=True):
     """nemgpu_run of several engines in lock step (one launch per EM step for all of them).  Returns their result
-    dicts, each identical to what engine.run() alone gives."""
+    dicts, each identical to what engine.run() alone gives (fetch=False: without the arrays -- engine.results()
+    fetches them, e.g. from worker threads)."""
     if not engines:
         return []
     lib = engines[0].lib
@@ -370,7 +371,8 @@ def run_many(engines):
     out = []
     for e, r in zip(engines, res):
         d = e._result(r)
-        d.update(e.results())
+        if fetch:
+            d.update(e.results())
         out.append(d)
     return out
 
