@@ -346,6 +346,22 @@ def main():
         extra = dict(iters_to_converge=cycle, cycle_iterations=cycle, native_rccl=bool(job.native),
                      rccl_ranks=job.eng.rccl_ranks(), backend=args.backend,
                      batch_graphs=bool(job.use_graphs))
+        if world > 1 and args.scaling == "strong" and rank == 0:
+            # the same problem on ONE GPU, same run: what the strong-scaling values are to be compared with (the
+            # N = 1 default of this script is configs[1], another problem)
+            try:
+                x1, nei1, p1, c1, d1, _, _ = make_workload(n_tot, d, k, args.spectrum, seed)
+                solo = EngineRun(x1, nei1, k, p1, c1, d1, args.algo, beta, "sk_", device=device)
+                st = max(solo.cycle, (min(args.steps, 220) // solo.cycle) * solo.cycle)
+                t1, _ = solo.timed(st, solo.cycle)
+                extra["single_gpu_same_workload"] = dict(ms_per_step=t1 * 1e3 / st, value=n_tot * d * st / t1,
+                                                         em_iterations_per_sec=st / t1, steps=st)
+                extra["speedup_vs_single_gpu_same_workload"] = (t1 / st) / (dt_max / args.steps)
+                solo.eng.close()
+            except Exception as exc:
+                extra["single_gpu_same_workload"] = {"error": repr(exc)}
+        if world > 1:
+            dist.barrier()
         parallelism = ("families sharded over %d GPUs in contiguous blocks (%s scaling); per EM iteration two RCCL "
                        "all-gathers of the label blocks, the second also carrying the ranks' int32 M-step statistics"
                        % (world, scaling)) if world > 1 else "1 GPU through the sharded driver"
