@@ -134,6 +134,10 @@ struct nemgpu_engine {
     // relaxation rounds enqueued per sweep before anybody looks (round 0, its verification, and one more that costs
     // an early-exit launch when it is not needed and a host round trip when it is missing); NEM_MI355X_ROUNDS=2..4
     int round_batch = 3;
+    // ... per sweep of an ITERATION: two (the round and its verification) until a sweep of this engine needed more --
+    // then every later one gets round_batch.  (Labels are sticky: on the bench's pre-convergence data only the sweep
+    // that starts from the blind partition needs a third round; an early-exit launch per iteration costs 2.5 us.)
+    int rounds_iter = 2;
     bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
     int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
@@ -481,7 +485,7 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
 }
 
 int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false, const CtrlArgs* post_ctrl = nullptr,
-                  bool post_moved = false, int slot_base = 0)
+                  bool post_moved = false, int slot_base = 0, int rounds = 0)
 {
     c = SweepCtx();
     c.slot_base = slot_base;
@@ -502,7 +506,7 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
     }
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
-    return sweep_launch_rounds(e, c, c.multi ? e->round_batch : 1);
+    return sweep_launch_rounds(e, c, c.multi ? (rounds > 0 ? rounds : e->round_batch) : 1);
 }
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
@@ -650,11 +654,11 @@ int post_sweep(nemgpu_engine* e, int newbuf, int oldbuf, const CtrlArgs* ctrl = 
     return NEMGPU_OK;
 }
 
-constexpr int kPipeDepth = 6;
+constexpr int kPipeDepth = 7;       // (the graph table holds batches of up to 7 iterations)
 
 // A sweep of the pipelined loop whose two enqueued rounds did not reach the fixed point (or, TIE_LIBC, ran out of
 // the draw table): the context from which the host goes on with rounds 2, 3, ... (current partition = e->cur)
-int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id)
+int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id, int launched)
 {
     sc = SweepCtx();
     sc.use_nei = e->has_graph && e->cfg.beta != 0.0f;
@@ -663,9 +667,9 @@ int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id)
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = sc.use_nei ? 1 : 0;
     a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id; a.sweep_id_ptr = nullptr;
-    sc.r = e->round_batch; sc.checked = e->round_batch;   // (the enqueued rounds all changed something)
+    sc.r = launched; sc.checked = launched;               // (the enqueued rounds all changed something)
     if (e->libc()) {
-        for (int q = 0; q < e->round_batch; q++) if (e->h_round(q)[FLAG_NTIES] & (1 << 30)) e->tie_heavy = true;
+        for (int q = 0; q < launched; q++) if (e->h_round(q)[FLAG_NTIES] & (1 << 30)) e->tie_heavy = true;
         int r = ensure_draw_window(e, e->draws, draw_need(e));
         if (r) return r;
         sweep_draw_args(e, a, true);
@@ -714,7 +718,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     SweepCtx c;
     e->sweep_counter = sweep_id;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->round_batch;
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->rounds_iter;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -722,7 +726,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     // tests in the next iteration's counts launch when there is one
     const bool defer = defer_ctrl && counts_first;
     CtrlArgs none{};
-    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? (defer ? &none : &ca) : nullptr, true))) { e->cur = saved; return r; }
+    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? (defer ? &none : &ca) : nullptr, true, 0, e->rounds_iter))) { e->cur = saved; return r; }
     if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (!e->ncem()) { if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; } }
     else e->masks_valid = true;
@@ -898,7 +902,7 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         e->cur = 1;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, 1u))) return r;
+        if ((r = host_rounds_ctx(e, sc, 1u, e->round_batch))) return r;
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
         e->sweep_rounds += 1;                                  // + the blind sweep
@@ -926,7 +930,8 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1)))) return r;
+        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), e->rounds_iter))) return r;
+        if (e->rounds_iter < e->round_batch) { e->rounds_iter = e->round_batch; drop_graphs(e); }   // from now on: one round more
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         int rounds = 0;
         if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
@@ -1448,6 +1453,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     e->cfg.tie_rule = NEMGPU_TIE_HASH; e->cfg.tie_seed = 0;
     if (const char* g = getenv("NEM_MI355X_GRAPHS")) e->use_graphs = (g[0] != '0');   // 0: plain launches only
     if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
+    if (const char* g = getenv("NEM_MI355X_ROUNDS_ITER")) e->rounds_iter = std::max(2, std::min(e->round_batch, atoi(g)));
+    e->rounds_iter = std::min(e->rounds_iter, e->round_batch);
     if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = (g[0] != '0');
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
@@ -1898,7 +1905,7 @@ static int make_clone(nemgpu_engine* p, nemgpu_engine** out, char* slab, size_t 
     c->cfg = p->cfg; c->have_matrix = true; c->have_params = true; c->has_graph = p->has_graph;
     c->xw = p->xw; c->xws = p->xws; c->perm = p->perm; c->xt = p->xt; c->use_sort = p->use_sort;
     c->nei_ptr = p->nei_ptr; c->nei_idx = p->nei_idx; c->nei_w = p->nei_w; c->nnz = p->nnz;
-    c->use_graphs = p->use_graphs; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch;   // (graphs: the zipped sequences')
+    c->use_graphs = p->use_graphs; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch; c->rounds_iter = p->rounds_iter;   // (graphs: the zipped sequences')
     c->parent = p; c->carve_all = true;
     c->chunks.push_back({slab, slab_bytes, 0, false});
     c->shared_chunk = 0;
