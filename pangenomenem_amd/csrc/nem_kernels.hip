@@ -68,180 +68,6 @@ __device__ inline long long wave_reduce_add_ll(long long v)
 }
 
 // ------------------------------------------------------------------------------------------
-// The fuzzy M-step's sums, split along the families.  Each of the K*(2D+2) sums of pass A and the K*D prefix scans
-// of pass B is an i-ordered float accumulator over all N families (nem_mod.c:1303-1313, 1677-1686, 1448-1458) --
-// N dependent adds, whoever runs them.  But between two powers of two a float accumulator moves on a fixed grid
-// and the chain is a prefix sum of integers (nem_chain.hpp); the sum is then a matter of a scan.  Here ONE WAVE
-// owns a chain and takes it 256 families at a time: every lane turns its four memberships into grid increments,
-// a DPP scan places them, the first element the integer form cannot take (the next binade, an exact tie, a sum
-// that is not ready) is found with a ballot and stepped -- with a short burst behind it -- by the reference's own
-// float add.  Float inputs make this simpler than the criteria's chains: c * 2^s is exact, so "near a tie" is
-// "exactly a tie".  (float)((double)a + (double)b) is the float sum, so all four kinds of sums are float adds.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8: prefix inside each row of 16
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware keeps a wave's LDS
-// operations in order; this only stops the compiler from moving them across (no block barrier: the chains of a
-// block's waves advance independently)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr int kEPL = 4;                                  // families per lane and window of the chain kernels
-constexpr int kWin = 64 * kEPL;                          // families per window
-
-struct WaveChain {
-    const float* sx;                                     // LDS: the window's kWin addends, in order (nullptr: every addend is cval)
-    float acc;                                           // the accumulator (the same value in every lane)
-    int burst;
-    float cval = 0.0f;
-    // sequential float adds of sx[p .. p + count): the reference's own arithmetic, sixteen addends fetched ahead
-    __device__ __forceinline__ void steps(int p, int count)
-    {
-        int i = 0;
-        if (sx == nullptr) {                             // (wave-uniform)
-            for (; i < count; i++) acc = acc + cval;
-            return;
-        }
-        for (; i + 16 <= count; i += 16) {
-            float v[16];
-#pragma unroll
-            for (int t = 0; t < 16; t++) v[t] = sx[p + i + t];
-#pragma unroll
-            for (int t = 0; t < 16; t++) acc = acc + v[t];
-        }
-        for (; i < count; i++) acc = acc + sx[p + i];
-    }
-    // the window: wn (<= kWin) addends, lane l holds x[0 .. kEPL) = addends kEPL l .. (the same values are in sx).
-    // Branch-free per element: what an element adds and whether the integer form can take it are selects.
-    __device__ __forceinline__ void window(const float (&x)[kEPL], int wn)
-    {
-        const int e0 = kEPL * (int)(threadIdx.x & 63);
-        int pos = 0;
-        while (pos < wn) {
-            const uint32_t ab = __float_as_uint(acc);
-            const int E = (int)((ab >> 23) & 255u);
-            if ((ab >> 31) != 0u || E < 24 || E > 253) {      // negative, tiny, zero or not finite: step
-                const int cnt = min(burst, wn - pos);
-                steps(pos, cnt);
-                pos += cnt;
-                burst = nemchain::next_burst(burst, -1);
-                continue;
-            }
-            const float sc = __uint_as_float((uint32_t)(127 + 150 - E) << 23);    // 1 / ulp(acc): 2^(150 - E), a normal float
-            const uint32_t M0 = (ab & 0x7fffffu) | 0x800000u;
-            constexpr uint32_t top = 1u << 24;
-            if (pos == 0) {
-                // most windows hold nothing the integer form cannot take and end inside the binade they began in:
-                // then all that is needed is the sum of the increments (no scan, no search for the first stop)
-                uint32_t tot = 0; bool clean = true;
-#pragma unroll
-                for (int j = 0; j < kEPL; j++) {
-                    const float q = x[j] * sc;           // (addends behind wn are -0: increment 0)
-                    const float fl = floorf(q);
-                    const float fr = q - fl;
-                    clean = clean & (q >= 0.0f) & (q < 33554432.0f) & (fr != 0.5f);
-                    tot += (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
-                }
-                const bool small = tot < (1u << 17);     // (64 lanes of less than 2^17 cannot wrap 32 bits)
-                if (__ballot(!(clean & small)) == 0ull) {
-                    const uint32_t Mt = M0 + (uint32_t)wave_reduce_add((int)tot);
-                    if (Mt <= top) {
-                        acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
-                        burst = nemchain::next_burst(burst, wn);
-                        return;
-                    }
-                }
-            }
-            // An exact tie is no obstacle either: float addition rounds it to even, so what it adds depends on the
-            // PARITY of the mantissa it meets -- a + (a odd) on an even one, a + (a even) on an odd one -- and on
-            // nothing else.  Every addend is therefore a map M -> M + d[M & 1], such maps compose into maps of the
-            // same form, and the window is a scan with that composition (two increments per element instead of one).
-            uint32_t de[kEPL], dod[kEPL];                // what element j adds to an even / an odd mantissa
-            int stop = kEPL;                             // first of mine the integer form cannot take
-            uint32_t L0 = 0, L1 = 0;                     // my elements composed: added to an even / odd mantissa at my first one
-#pragma unroll
-            for (int j = 0; j < kEPL; j++) {
-                const int e = e0 + j;
-                const bool act = (e >= pos) & (e < wn);
-                const float q = x[j] * sc;               // exact (a power-of-two scaling; an overflow gives inf)
-                const float fl = floorf(q);
-                const float fr = q - fl;                 // exact
-                const bool ok = (q >= 0.0f) & (q < 33554432.0f);        // (a shrinking sum, NaN or inf fail the compares)
-                const uint32_t a = (uint32_t)fl;
-                const bool tie = fr == 0.5f;
-                const uint32_t up = fr > 0.5f ? 1u : 0u;
-                const bool first_bad = act & !ok & (stop == kEPL);
-                stop = first_bad ? j : stop;
-                const bool take = act & ok & (stop == kEPL);
-                de[j] = take ? (tie ? a + (a & 1u) : a + up) : 0u;
-                dod[j] = take ? (tie ? a + ((a & 1u) ^ 1u) : a + up) : 0u;
-                const uint32_t n0 = L0 + ((L0 & 1u) ? dod[j] : de[j]);
-                const uint32_t n1 = L1 + ((L1 & 1u) ? de[j] : dod[j]);   // (an odd mantissa plus L1)
-                L0 = n0; L1 = n1;
-            }
-            // inclusive scan over the lanes with "first the lanes to my left, then me"
-            uint32_t I0 = L0, I1 = L1;
-            // (a lane without a left partner gets the identity (0, 0))
-#define NEM_FOLD(ctrl, row_mask)                                                                                      \
-            {                                                                                                         \
-                const uint32_t l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I0, ctrl, row_mask, 0xF, false);    \
-                const uint32_t l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I1, ctrl, row_mask, 0xF, false);    \
-                const uint32_t h0 = l0 + ((l0 & 1u) ? I1 : I0);                                                       \
-                const uint32_t h1 = l1 + ((l1 & 1u) ? I0 : I1);                                                       \
-                I0 = h0; I1 = h1;                                                                                     \
-            }
-            NEM_FOLD(0x111, 0xF) NEM_FOLD(0x112, 0xF) NEM_FOLD(0x114, 0xF) NEM_FOLD(0x118, 0xF)   // row_shr 1, 2, 4, 8
-            NEM_FOLD(0x142, 0xA) NEM_FOLD(0x143, 0xC)                                             // row_bcast 15, 31
-#undef NEM_FOLD
-            const uint32_t Mend = M0 + ((M0 & 1u) ? I1 : I0);
-            const uint32_t Mprev = (uint32_t)__shfl_up((int)Mend, 1);
-            uint32_t M = (threadIdx.x & 63) == 0 ? M0 : Mprev;
-            const uint32_t incl = Mend - M0;             // (lane 63: the window's total)
-            int cand = INT_MAX; uint32_t candM = 0;
-#pragma unroll
-            for (int j = 0; j < kEPL; j++) {
-                const int e = e0 + j;
-                const bool act = (e >= pos) & (e < wn);
-                const uint32_t inc = (M & 1u) ? dod[j] : de[j];
-                const bool hit = act & (cand == INT_MAX) & ((j == stop) | (M >= top) | (M + inc > top));
-                candM = hit ? M : candM;
-                cand = hit ? e : cand;
-                M += inc;
-            }
-            const uint64_t who = __ballot(cand != INT_MAX);
-            if (who == 0ull) {                           // the rest of the window went through in integer form
-                const uint32_t Mt = (uint32_t)__builtin_amdgcn_readlane((int)(M0 + incl), 63);
-                acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
-                burst = nemchain::next_burst(burst, wn - pos);
-                pos = wn;
-                break;
-            }
-            const int first = (int)__ffsll((long long)who) - 1;      // (a lane behind the first stop holds a wrong M: ignored)
-            const int p = __builtin_amdgcn_readlane(cand, first);
-            const uint32_t Mb = (uint32_t)__builtin_amdgcn_readlane((int)candM, first);
-            acc = __uint_as_float(Mb >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mb & 0x7fffffu)));
-            const int cnt = min(burst, wn - p);
-            steps(p, cnt);
-            burst = nemchain::next_burst(burst, p - pos);
-            pos = p + cnt;
-        }
-    }
-};
-
-// ------------------------------------------------------------------------------------------
 // layout kernels (one-off, at upload time)
 //   xf  [n][W]      family-major bit rows (host layout)
 //   xw  [W][npad]   word-major: lane i reads word w of family i  -> coalesced E1 reads
@@ -811,21 +637,23 @@ __device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
             } else {
                 // the two d-ordered chains of InerToDispK_ (nem_mod.c:1054-1058), each on a wave of its own: the
                 // inertia values sixteen at a time from LDS ahead of the dependent adds, the N_KD chain from a register
-                if (tid < 128) {                         // waves 0 and 1: one chain each, 256 organisms per step (WaveChain)
-                    const int which = tid >> 6;
-                    WaveChain wc{nullptr, 0.0f, nemchain::kBurst, nkf};
-                    for (int i0 = 0; i0 < D; i0 += kWin) {
-                        const int wn = min(kWin, D - i0);
-                        float x[kEPL];
+                if (tid == 0) {
+                    float si = 0.0f;
+                    int d = 0;
+                    for (; d + 16 <= D; d += 16) {
+                        float v[16];
 #pragma unroll
-                        for (int j = 0; j < kEPL; j++) {
-                            const int t = kEPL * lane + j;
-                            x[j] = t < wn ? (which ? nkf : sVal[i0 + t]) : -0.0f;
-                        }
-                        wc.sx = which ? nullptr : sVal + i0;
-                        wc.window(x, wn);
+                        for (int t = 0; t < 16; t++) v[t] = sVal[d + t];
+#pragma unroll
+                        for (int t = 0; t < 16; t++) si += v[t];
                     }
-                    if (lane == 0) sChain[which] = wc.acc;
+                    for (; d < D; d++) si += sVal[d];
+                    sChain[0] = si;
+                } else if (tid == 64) {
+                    float sn = 0.0f;
+#pragma unroll 8
+                    for (int d = 0; d < D; d++) sn += nkf;
+                    sChain[1] = sn;
                 }
                 __syncthreads();
                 if (tid == 0) sEps = sChain[0] / sChain[1];
@@ -1625,30 +1453,30 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
                 for (int kk = 0; kk < kn; kk++)
                     for (int d = tid; d < D; d += 1024) s_in[kk * Dp + d] = iner[(k0 + kk) * D + d];
                 __syncthreads();
-                {
-                    // a wave per chain, 256 organisms per step: the d-ordered float sums as exact integer-grid prefix
-                    // sums (WaveChain: ties -- every odd addend once the total passes 2^24 -- are parity-dependent
-                    // increments, part of the scan) -- 20 steps instead of 5 000 dependent adds at D = 5 000
-                    const int lane = tid & 63;
-                    for (int c = tid >> 6; c < 2 * kn; c += 16) {            // (wave-uniform)
+                if ((tid & 63) == 0) {
+                    for (int c = tid >> 6; c < 2 * kn; c += 16) {
                         const int kk = c >> 1, k = k0 + kk;
                         if (!s_seq[k]) continue;
                         const float nk = nbobs_k[k];
                         if (!(nk > 0)) continue;
-                        WaveChain wc{nullptr, 0.0f, nemchain::kBurst, nk};
-                        for (int i0 = 0; i0 < D; i0 += kWin) {
-                            const int wn = min(kWin, D - i0);
-                            const float* base = s_in + kk * Dp + i0;
-                            float x[kEPL];
-#pragma unroll
-                            for (int j = 0; j < kEPL; j++) {
-                                const int t = kEPL * lane + j;
-                                x[j] = t < wn ? ((c & 1) ? nk : base[t]) : -0.0f;
+                        if (c & 1) {
+                            float sn = 0.0f;
+#pragma unroll 8
+                            for (int d = 0; d < D; d++) sn += nk;
+                            s_sn[k] = sn;
+                        } else {
+                            float si = 0.0f;
+                            const float* base = s_in + kk * Dp;
+                            const float4* b4 = reinterpret_cast<const float4*>(base);
+                            const int dq = D & ~3;
+#pragma unroll 8
+                            for (int t = 0; t < (dq >> 2); t++) {
+                                const float4 v = b4[t];
+                                si = (((si + v.x) + v.y) + v.z) + v.w;
                             }
-                            wc.sx = (c & 1) ? nullptr : base;
-                            wc.window(x, wn);
+                            for (int d = dq; d < D; d++) si += base[d];
+                            s_si[k] = si;
                         }
-                        if (lane == 0) { if (c & 1) s_sn[k] = wc.acc; else s_si[k] = wc.acc; }
                     }
                 }
                 __syncthreads();
@@ -2038,6 +1866,175 @@ __device__ __forceinline__ void mstep_fuzzy_b_body(int n, int npad, int K, int D
         iner[t] = (mu == 0.0f) ? in0[t] : (mu == 1.0f ? in1[t] : inh_k[k]);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The fuzzy M-step's sums, split along the families.  Each of the K*(2D+2) sums of pass A and the K*D prefix scans
+// of pass B is an i-ordered float accumulator over all N families (nem_mod.c:1303-1313, 1677-1686, 1448-1458) --
+// N dependent adds, whoever runs them.  But between two powers of two a float accumulator moves on a fixed grid
+// and the chain is a prefix sum of integers (nem_chain.hpp); the sum is then a matter of a scan.  Here ONE WAVE
+// owns a chain and takes it 256 families at a time: every lane turns its four memberships into grid increments,
+// a DPP scan places them, the first element the integer form cannot take (the next binade, an exact tie, a sum
+// that is not ready) is found with a ballot and stepped -- with a short burst behind it -- by the reference's own
+// float add.  Float inputs make this simpler than the criteria's chains: c * 2^s is exact, so "near a tie" is
+// "exactly a tie".  (float)((double)a + (double)b) is the float sum, so all four kinds of sums are float adds.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8: prefix inside each row of 16
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware keeps a wave's LDS
+// operations in order; this only stops the compiler from moving them across (no block barrier: the chains of a
+// block's waves advance independently)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kEPL = 4;                                  // families per lane and window of the chain kernels
+constexpr int kWin = 64 * kEPL;                          // families per window
+
+struct WaveChain {
+    float* sx;                                           // LDS: the window's kWin addends, family order
+    float acc;                                           // the accumulator (the same value in every lane)
+    int burst;
+    // sequential float adds of sx[p .. p + count): the reference's own arithmetic, sixteen addends fetched ahead
+    __device__ __forceinline__ void steps(int p, int count)
+    {
+        int i = 0;
+        for (; i + 16 <= count; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) v[t] = sx[p + i + t];
+#pragma unroll
+            for (int t = 0; t < 16; t++) acc = acc + v[t];
+        }
+        for (; i < count; i++) acc = acc + sx[p + i];
+    }
+    // the window: wn (<= kWin) addends, lane l holds x[0 .. kEPL) = addends kEPL l .. (the same values are in sx).
+    // Branch-free per element: what an element adds and whether the integer form can take it are selects.
+    __device__ __forceinline__ void window(const float (&x)[kEPL], int wn)
+    {
+        const int e0 = kEPL * (int)(threadIdx.x & 63);
+        int pos = 0;
+        while (pos < wn) {
+            const uint32_t ab = __float_as_uint(acc);
+            const int E = (int)((ab >> 23) & 255u);
+            if ((ab >> 31) != 0u || E < 24 || E > 253) {      // negative, tiny, zero or not finite: step
+                const int cnt = min(burst, wn - pos);
+                steps(pos, cnt);
+                pos += cnt;
+                burst = nemchain::next_burst(burst, -1);
+                continue;
+            }
+            const float sc = __uint_as_float((uint32_t)(127 + 150 - E) << 23);    // 1 / ulp(acc): 2^(150 - E), a normal float
+            const uint32_t M0 = (ab & 0x7fffffu) | 0x800000u;
+            constexpr uint32_t top = 1u << 24;
+            if (pos == 0) {
+                // most windows hold nothing the integer form cannot take and end inside the binade they began in:
+                // then all that is needed is the sum of the increments (no scan, no search for the first stop)
+                uint32_t tot = 0; bool clean = true;
+#pragma unroll
+                for (int j = 0; j < kEPL; j++) {
+                    const float q = x[j] * sc;           // (addends behind wn are -0: increment 0)
+                    const float fl = floorf(q);
+                    const float fr = q - fl;
+                    clean = clean & (q >= 0.0f) & (q < 33554432.0f) & (fr != 0.5f);
+                    tot += (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
+                }
+                const bool small = tot < (1u << 17);     // (64 lanes of less than 2^17 cannot wrap 32 bits)
+                if (__ballot(!(clean & small)) == 0ull) {
+                    const uint32_t Mt = M0 + (uint32_t)wave_reduce_add((int)tot);
+                    if (Mt <= top) {
+                        acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
+                        burst = nemchain::next_burst(burst, wn);
+                        return;
+                    }
+                }
+            }
+            // An exact tie is no obstacle either: float addition rounds it to even, so what it adds depends on the
+            // PARITY of the mantissa it meets -- a + (a odd) on an even one, a + (a even) on an odd one -- and on
+            // nothing else.  Every addend is therefore a map M -> M + d[M & 1], such maps compose into maps of the
+            // same form, and the window is a scan with that composition (two increments per element instead of one).
+            uint32_t de[kEPL], dod[kEPL];                // what element j adds to an even / an odd mantissa
+            int stop = kEPL;                             // first of mine the integer form cannot take
+            uint32_t L0 = 0, L1 = 0;                     // my elements composed: added to an even / odd mantissa at my first one
+#pragma unroll
+            for (int j = 0; j < kEPL; j++) {
+                const int e = e0 + j;
+                const bool act = (e >= pos) & (e < wn);
+                const float q = x[j] * sc;               // exact (a power-of-two scaling; an overflow gives inf)
+                const float fl = floorf(q);
+                const float fr = q - fl;                 // exact
+                const bool ok = (q >= 0.0f) & (q < 33554432.0f);        // (a shrinking sum, NaN or inf fail the compares)
+                const uint32_t a = (uint32_t)fl;
+                const bool tie = fr == 0.5f;
+                const uint32_t up = fr > 0.5f ? 1u : 0u;
+                const bool first_bad = act & !ok & (stop == kEPL);
+                stop = first_bad ? j : stop;
+                const bool take = act & ok & (stop == kEPL);
+                de[j] = take ? (tie ? a + (a & 1u) : a + up) : 0u;
+                dod[j] = take ? (tie ? a + ((a & 1u) ^ 1u) : a + up) : 0u;
+                const uint32_t n0 = L0 + ((L0 & 1u) ? dod[j] : de[j]);
+                const uint32_t n1 = L1 + ((L1 & 1u) ? de[j] : dod[j]);   // (an odd mantissa plus L1)
+                L0 = n0; L1 = n1;
+            }
+            // inclusive scan over the lanes with "first the lanes to my left, then me"
+            uint32_t I0 = L0, I1 = L1;
+            // (a lane without a left partner gets the identity (0, 0))
+#define NEM_FOLD(ctrl, row_mask)                                                                                      \
+            {                                                                                                         \
+                const uint32_t l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I0, ctrl, row_mask, 0xF, false);    \
+                const uint32_t l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I1, ctrl, row_mask, 0xF, false);    \
+                const uint32_t h0 = l0 + ((l0 & 1u) ? I1 : I0);                                                       \
+                const uint32_t h1 = l1 + ((l1 & 1u) ? I0 : I1);                                                       \
+                I0 = h0; I1 = h1;                                                                                     \
+            }
+            NEM_FOLD(0x111, 0xF) NEM_FOLD(0x112, 0xF) NEM_FOLD(0x114, 0xF) NEM_FOLD(0x118, 0xF)   // row_shr 1, 2, 4, 8
+            NEM_FOLD(0x142, 0xA) NEM_FOLD(0x143, 0xC)                                             // row_bcast 15, 31
+#undef NEM_FOLD
+            const uint32_t Mend = M0 + ((M0 & 1u) ? I1 : I0);
+            const uint32_t Mprev = (uint32_t)__shfl_up((int)Mend, 1);
+            uint32_t M = (threadIdx.x & 63) == 0 ? M0 : Mprev;
+            const uint32_t incl = Mend - M0;             // (lane 63: the window's total)
+            int cand = INT_MAX; uint32_t candM = 0;
+#pragma unroll
+            for (int j = 0; j < kEPL; j++) {
+                const int e = e0 + j;
+                const bool act = (e >= pos) & (e < wn);
+                const uint32_t inc = (M & 1u) ? dod[j] : de[j];
+                const bool hit = act & (cand == INT_MAX) & ((j == stop) | (M >= top) | (M + inc > top));
+                candM = hit ? M : candM;
+                cand = hit ? e : cand;
+                M += inc;
+            }
+            const uint64_t who = __ballot(cand != INT_MAX);
+            if (who == 0ull) {                           // the rest of the window went through in integer form
+                const uint32_t Mt = (uint32_t)__builtin_amdgcn_readlane((int)(M0 + incl), 63);
+                acc = __uint_as_float(Mt >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mt & 0x7fffffu)));
+                burst = nemchain::next_burst(burst, wn - pos);
+                pos = wn;
+                break;
+            }
+            const int first = (int)__ffsll((long long)who) - 1;      // (a lane behind the first stop holds a wrong M: ignored)
+            const int p = __builtin_amdgcn_readlane(cand, first);
+            const uint32_t Mb = (uint32_t)__builtin_amdgcn_readlane((int)candM, first);
+            acc = __uint_as_float(Mb >= top ? ((uint32_t)(E + 1) << 23) : (((uint32_t)E << 23) | (Mb & 0x7fffffu)));
+            const int cnt = min(burst, wn - p);
+            steps(p, cnt);
+            burst = nemchain::next_burst(burst, p - pos);
+            pos = p + cnt;
+        }
+    }
+};
 
 // One window's inputs of a lane: its kEPL memberships of class k (class-major copy ct[K][npad]) for families
 // i0 + kEPL lane .. and the word of organism row `row` that holds their bits.  (The word is handed on as loaded:
