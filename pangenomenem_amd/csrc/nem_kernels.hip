@@ -1960,13 +1960,9 @@ struct WaveChain {
                     }
                 }
             }
-            // An exact tie is no obstacle either: float addition rounds it to even, so what it adds depends on the
-            // PARITY of the mantissa it meets -- a + (a odd) on an even one, a + (a even) on an odd one -- and on
-            // nothing else.  Every addend is therefore a map M -> M + d[M & 1], such maps compose into maps of the
-            // same form, and the window is a scan with that composition (two increments per element instead of one).
-            uint32_t de[kEPL], dod[kEPL];                // what element j adds to an even / an odd mantissa
+            uint32_t inc[kEPL];
             int stop = kEPL;                             // first of mine the integer form cannot take
-            uint32_t L0 = 0, L1 = 0;                     // my elements composed: added to an even / odd mantissa at my first one
+            uint32_t lsum = 0;
 #pragma unroll
             for (int j = 0; j < kEPL; j++) {
                 const int e = e0 + j;
@@ -1974,47 +1970,26 @@ struct WaveChain {
                 const float q = x[j] * sc;               // exact (a power-of-two scaling; an overflow gives inf)
                 const float fl = floorf(q);
                 const float fr = q - fl;                 // exact
-                const bool ok = (q >= 0.0f) & (q < 33554432.0f);        // (a shrinking sum, NaN or inf fail the compares)
-                const uint32_t a = (uint32_t)fl;
-                const bool tie = fr == 0.5f;
-                const uint32_t up = fr > 0.5f ? 1u : 0u;
+                // takeable: 0 <= q < 2^25 (a shrinking sum, NaN or inf fail the compares) and not a tie (its rounding
+                // depends on the parity of M)
+                const bool ok = (q >= 0.0f) & (q < 33554432.0f) & (fr != 0.5f);
+                const uint32_t v = (uint32_t)fl + (fr > 0.5f ? 1u : 0u);
                 const bool first_bad = act & !ok & (stop == kEPL);
                 stop = first_bad ? j : stop;
-                const bool take = act & ok & (stop == kEPL);
-                de[j] = take ? (tie ? a + (a & 1u) : a + up) : 0u;
-                dod[j] = take ? (tie ? a + ((a & 1u) ^ 1u) : a + up) : 0u;
-                const uint32_t n0 = L0 + ((L0 & 1u) ? dod[j] : de[j]);
-                const uint32_t n1 = L1 + ((L1 & 1u) ? de[j] : dod[j]);   // (an odd mantissa plus L1)
-                L0 = n0; L1 = n1;
+                inc[j] = (act & ok & (stop == kEPL)) ? v : 0u;
+                lsum += inc[j];
             }
-            // inclusive scan over the lanes with "first the lanes to my left, then me"
-            uint32_t I0 = L0, I1 = L1;
-            // (a lane without a left partner gets the identity (0, 0))
-#define NEM_FOLD(ctrl, row_mask)                                                                                      \
-            {                                                                                                         \
-                const uint32_t l0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I0, ctrl, row_mask, 0xF, false);    \
-                const uint32_t l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)I1, ctrl, row_mask, 0xF, false);    \
-                const uint32_t h0 = l0 + ((l0 & 1u) ? I1 : I0);                                                       \
-                const uint32_t h1 = l1 + ((l1 & 1u) ? I0 : I1);                                                       \
-                I0 = h0; I1 = h1;                                                                                     \
-            }
-            NEM_FOLD(0x111, 0xF) NEM_FOLD(0x112, 0xF) NEM_FOLD(0x114, 0xF) NEM_FOLD(0x118, 0xF)   // row_shr 1, 2, 4, 8
-            NEM_FOLD(0x142, 0xA) NEM_FOLD(0x143, 0xC)                                             // row_bcast 15, 31
-#undef NEM_FOLD
-            const uint32_t Mend = M0 + ((M0 & 1u) ? I1 : I0);
-            const uint32_t Mprev = (uint32_t)__shfl_up((int)Mend, 1);
-            uint32_t M = (threadIdx.x & 63) == 0 ? M0 : Mprev;
-            const uint32_t incl = Mend - M0;             // (lane 63: the window's total)
+            const uint32_t incl = wave_scan_incl(lsum);
+            uint32_t M = M0 + incl - lsum;
             int cand = INT_MAX; uint32_t candM = 0;
 #pragma unroll
             for (int j = 0; j < kEPL; j++) {
                 const int e = e0 + j;
                 const bool act = (e >= pos) & (e < wn);
-                const uint32_t inc = (M & 1u) ? dod[j] : de[j];
-                const bool hit = act & (cand == INT_MAX) & ((j == stop) | (M >= top) | (M + inc > top));
+                const bool hit = act & (cand == INT_MAX) & ((j == stop) | (M >= top) | (M + inc[j] > top));
                 candM = hit ? M : candM;
                 cand = hit ? e : cand;
-                M += inc;
+                M += inc[j];
             }
             const uint64_t who = __ballot(cand != INT_MAX);
             if (who == 0ull) {                           // the rest of the window went through in integer form
