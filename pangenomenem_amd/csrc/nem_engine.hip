@@ -138,6 +138,7 @@ struct nemgpu_engine {
     // then every later one gets round_batch.  (Labels are sticky: on the bench's pre-convergence data only the sweep
     // that starts from the blind partition needs a third round; an early-exit launch per iteration costs 2.5 us.)
     int rounds_iter = 2;
+    int rounds_enqueued = 2;             // ... what the iterations of the batch in flight were given
     bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
     int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
@@ -718,7 +719,11 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     SweepCtx c;
     e->sweep_counter = sweep_id;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->rounds_iter;
+    // (members of a lock-step batch all take the same number of rounds: a member with a sequence of its own would
+    //  need launches of its own)
+    const int it_rounds = current_recorder() != nullptr ? e->round_batch : e->rounds_iter;
+    e->rounds_enqueued = it_rounds;
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = it_rounds;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -726,7 +731,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     // tests in the next iteration's counts launch when there is one
     const bool defer = defer_ctrl && counts_first;
     CtrlArgs none{};
-    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? (defer ? &none : &ca) : nullptr, true, 0, e->rounds_iter))) { e->cur = saved; return r; }
+    if ((r = sweep_enqueue(e, e->cfg.beta, c, false, e->ncem() ? (defer ? &none : &ca) : nullptr, true, 0, it_rounds))) { e->cur = saved; return r; }
     if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (!e->ncem()) { if ((r = post_sweep(e, (cur + 1) % 3, cur, &ca))) { e->cur = saved; return r; } }
     else e->masks_valid = true;
@@ -930,7 +935,7 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), e->rounds_iter))) return r;
+        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), e->rounds_enqueued))) return r;
         if (e->rounds_iter < e->round_batch) { e->rounds_iter = e->round_batch; drop_graphs(e); }   // from now on: one round more
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         int rounds = 0;

@@ -47,13 +47,14 @@ def per_kernel(counter_csv, stat="mean"):
 
 
 def full_launch_us(trace_csv, kernel):
-    """duration of the kernel's FULL launches: the median of the upper half of its launches (launches that return at
-    the stop word of a converged batch are a few microseconds and pull a plain average down)"""
+    """duration of the kernel's FULL launches in a lock-step batch: the median of the top decile of its launches
+    (members converge at different iterations, so most launches of a batch serve fewer than all members; launches
+    that return at the stop word are a few microseconds)"""
     d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace_csv))
                if short(r["Kernel_Name"]) == kernel)
     if not d:
         return None, 0
-    top = d[len(d) // 2:]
+    top = d[-max(1, len(d) // 10):]
     return top[len(top) // 2], len(d)
 
 
