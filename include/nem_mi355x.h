@@ -152,6 +152,25 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res);
    result is bit-identical to its nemgpu_run.  results: `count` entries. */
 int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results);
 
+/* Many whole problems from host arrays to host arrays in ONE call -- PPanGGOLiN's chunk loop
+   (ppanggolin.py:1045-1086) when the chunks are arrays: `workers` threads of the library build the engines (bit
+   packing, asynchronous uploads), the calling thread runs each `group` of them in lock step (nemgpu_run_many) as soon
+   as it is complete, the workers fetch results and recycle engines while later groups are being built.  Every
+   problem's result equals its own nemgpu_run.  Returns the first failure (each problem's own status is in rc). */
+typedef struct {
+    int n, d, k;
+    const uint8_t*  x_bytes;     /* [n][d] values 0/1 ...                                   */
+    const uint32_t* x_bits;      /* ... or [n][ceil(d/32)] bit rows: exactly one of the two */
+    const int32_t*  nei_ptr;     /* CSR neighbourhood graph [n+1] (NULL: none) */
+    const int32_t*  nei_idx;
+    const float*    nei_w;
+    const float *prop, *center, *disp;                                  /* initial parameters [k], [k][d], [k][d] */
+    float *out_prop, *out_center, *out_disp, *out_nbobs_k, *out_c;      /* results, any may be NULL; out_c [n][k] */
+    nemgpu_result result;
+    int rc;
+} nemgpu_problem;
+int nemgpu_solve_many(nemgpu_problem* problems, int count, const nemgpu_config* cfg, int device, int workers, int group);
+
 /* Whole run from random starts (the reference's init_mode = INIT_RANDOM, RandNemAlgo nem_alg.c:1574-1742): n_starts
    starts (the reference uses 50), centres drawn from the data with the reference's generator -- glibc random()
    after srandom(seed), restated in csrc/nem_rng.hpp -- best start by criterion M, EstimPara on the best partition.
@@ -234,7 +253,9 @@ int nemgpu_rccl_ranks(const nemgpu_engine* e);
    (argmax labels for ncem engines). */
 int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk);
 
-/* Results (HOST buffers; any pointer may be NULL).  c_nk is row-major [(site_hi-site_lo) x k]. */
+/* Results (HOST buffers; any pointer may be NULL).  c_nk is row-major [(site_hi-site_lo) x k].
+   nemgpu_get_results: parameters and partition in one device round trip. */
+int nemgpu_get_results(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k, float* c_nk);
 int nemgpu_get_partition(nemgpu_engine* e, float* c_nk);
 int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels);
 int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k);

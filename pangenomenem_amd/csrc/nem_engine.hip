@@ -16,6 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <map>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -58,6 +61,8 @@ struct nemgpu_engine {
     bool own_stream = false;
     nemgpu_config cfg{};
     bool have_matrix = false, have_params = false, has_graph = false;
+    bool reset_pending = false;          // set_params / configure: the device half of the reset is still to do
+                                         // (a run that starts with the restart launch does it there)
 
     uint32_t* xw = nullptr;
     // E1's own copy of the matrix: uint4[ceil(W/4)][npad], lane i holds family perm[i].  Inside every 256-family
@@ -68,7 +73,14 @@ struct nemgpu_engine {
     // nothing outside the density kernels sees the order.
     uint32_t* xws = nullptr;
     int* perm = nullptr;
-    std::vector<uint32_t> host_bits;     // the family-major bit rows as uploaded (random starts pick centres from them)
+    // the family-major bit rows as uploaded (random starts pick centres from them): pinned when they fit the pool's
+    // staging limit -- then the upload is a true asynchronous copy out of them -- else host_bits_own's
+    uint32_t* host_bits = nullptr; size_t host_bits_words = 0, host_bits_pin = 0;
+    std::vector<uint32_t> host_bits_own;
+    // pinned sources of uploads that may still be in flight on the stream (matrix order, graph, parameters): they go
+    // back to the pool when the engine is destroyed or an input is replaced (after a wait)
+    struct Staged { char* p; size_t size; };
+    std::vector<Staged> staging;
     bool use_sort = true;
     uint64_t* xt = nullptr;
     int *nei_ptr = nullptr, *nei_idx = nullptr;
@@ -77,6 +89,9 @@ struct nemgpu_engine {
 
     float *prop = nullptr, *center = nullptr, *disp = nullptr;
     float *prop0 = nullptr, *center0 = nullptr, *disp0 = nullptr;
+    // prop | center | disp | nbobs_k live in ONE block (sections 256-byte aligned), and so do the initial values
+    // (with a zero tail where nbobs_k is): a reset, an upload and a download are one copy each
+    size_t par_o_center = 0, par_o_disp = 0, par_o_nb = 0, par_words = 0;
     float *nbobs_k = nullptr, *iner = nullptr;
     int *fz_lastz = nullptr, *fz_any1 = nullptr;
     float *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
@@ -173,10 +188,19 @@ struct nemgpu_engine {
     std::vector<nemgpu_engine*> clones;                      // random starts in lock step: state-only twins of this engine
     char* clone_slab = nullptr; int* clone_flags_host = nullptr; float* clone_par0 = nullptr; size_t clone_bytes = 0;
     bool flags_host_borrowed = false;
-    char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;   // argument blocks of the zipped launches (lead engine)
-    int* zip_flags_host = nullptr; int* zip_flags_dev = nullptr; size_t zip_flags_cap = 0;   // the members' flag blocks, gathered
+    size_t clone_slab_size = 0, clone_flags_size = 0, flags_host_size = 0;   // real sizes of the pooled blocks
+    // What the lead engine of a lock-step batch works with: the slab the members' argument blocks go through, the
+    // area their flag blocks are gathered in, and the launch sequences captured so far (they hold the slabs'
+    // addresses).  It belongs to the device, not to the engine: a lead takes one from the device's pool and hands it
+    // back when it is destroyed, so the next group of problems of the same shape REPLAYS the graphs this one captured.
     struct ZipGraph { uint64_t key; int asked; hipGraphExec_t exec; };
-    std::vector<ZipGraph> zip_graphs;                       // captured launch sequences of lock-step batches, by shape
+    struct ZipContext {
+        char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;
+        int* zip_flags_host = nullptr; int* zip_flags_dev = nullptr; size_t zip_flags_cap = 0;
+        size_t zip_host_size = 0, zip_dev_size = 0, zip_flags_host_size = 0, zip_flags_dev_size = 0;
+        std::vector<ZipGraph> zip_graphs;
+    };
+    ZipContext* zc = nullptr;
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -197,14 +221,127 @@ thread_local hipStream_t g_alloc_stream = nullptr;      // stream of the engine 
 thread_local nemgpu_engine* g_alloc_engine = nullptr;   // ... and the engine itself (owner of the chunks)
 void alloc_for(nemgpu_engine* e) { g_alloc_engine = e; g_alloc_stream = e->stream; }
 
-// What an engine needs before it can do anything -- a stream, a first chunk of device memory, the pinned block the
-// loop control is copied to -- costs ~2 ms to create and up to 2 ms to release; a destroyed engine's set is parked
-// here and handed to the next engine on the same device (PPanGGOLiN calls nem() once per chunk of organisms, each
-// call creating and destroying an engine).  nemgpu_release_cached() frees what is parked.
-struct ParkedSet { int device; hipStream_t stream; char* chunk; int* flags_host; };
-std::mutex g_park_mutex;
-std::vector<ParkedSet> g_parked;
-constexpr size_t kParkMax = 16;
+// What an engine needs before it can do anything -- a stream, device memory, the pinned block the loop control is
+// copied to -- costs ~2 ms to create and up to 2 ms to release (hipFree waits for the whole device, other engines'
+// work included): what a destroyed engine held is kept in a per-device pool and handed to the next engines on that
+// device (PPanGGOLiN calls nem() once per chunk of organisms, each call creating and destroying an engine; a
+// lock-step batch has tens of engines alive at once).  The pool keeps up to NEM_MI355X_POOL_MB (default 8192) of
+// device memory per device; nemgpu_release_cached() frees everything it holds.
+struct ResourcePool {
+    std::mutex m;
+    std::vector<hipStream_t> streams;
+    std::multimap<size_t, char*> dev, pinned;
+    size_t dev_bytes = 0, pinned_bytes = 0;
+    std::vector<nemgpu_engine::ZipContext*> zips;           // lock-step contexts (slabs + captured graphs), most recent last
+};
+constexpr int kPoolDevices = 64;
+constexpr size_t kPoolStreams = 256, kPoolPinnedBytes = (size_t)512 << 20;
+ResourcePool* g_pools = new ResourcePool[kPoolDevices];     // (never destroyed: engines may outlive static destructors)
+size_t pool_dev_cap()
+{
+    static const size_t cap = [] {
+        const char* g = getenv("NEM_MI355X_POOL_MB");
+        return (size_t)(g ? std::max(0ll, atoll(g)) : 8192ll) << 20;
+    }();
+    return cap;
+}
+size_t pool_round(size_t bytes)
+{
+    const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : ((size_t)64 << 10);
+    return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+// a block of at least `bytes` (at most a quarter more) from the pool, else a new one; *got = its real size
+hipError_t pool_get(int device, bool pinned, size_t bytes, char** out, size_t* got)
+{
+    const size_t want = pool_round(bytes);
+    if (device >= 0 && device < kPoolDevices) {
+        ResourcePool& P = g_pools[device];
+        std::lock_guard<std::mutex> lock(P.m);
+        auto& M = pinned ? P.pinned : P.dev;
+        auto it = M.lower_bound(want);
+        if (it != M.end() && it->first <= want + want / 4) {
+            *out = it->second; *got = it->first;
+            (pinned ? P.pinned_bytes : P.dev_bytes) -= it->first;
+            M.erase(it);
+            return hipSuccess;
+        }
+    }
+    *got = want;
+    hipError_t err = pinned ? hipHostMalloc((void**)out, want) : hipMalloc((void**)out, want);
+    if (err != hipSuccess) {                             // out of memory with blocks idle in the pool: give them back
+        (void)hipGetLastError();
+        nemgpu_release_cached();
+        err = pinned ? hipHostMalloc((void**)out, want) : hipMalloc((void**)out, want);
+    }
+    return err;
+}
+void pool_put(int device, bool pinned, char* ptr, size_t size)
+{
+    if (!ptr) return;
+    if (device >= 0 && device < kPoolDevices && size > 0) {
+        ResourcePool& P = g_pools[device];
+        std::lock_guard<std::mutex> lock(P.m);
+        size_t& held = pinned ? P.pinned_bytes : P.dev_bytes;
+        if (held + size <= (pinned ? kPoolPinnedBytes : pool_dev_cap())) {
+            (pinned ? P.pinned : P.dev).emplace(size, ptr);
+            held += size;
+            return;
+        }
+    }
+    if (pinned) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+}
+void release_staging(nemgpu_engine* e);
+void zip_context_release(nemgpu_engine* lead);
+constexpr size_t kStageMax = (size_t)64 << 20;          // larger uploads take the blocking path from the caller's memory
+// a pinned block the engine owns until its next release_staging() -- the source of an asynchronous upload
+char* stage(nemgpu_engine* e, size_t bytes)
+{
+    if (bytes > kStageMax) return nullptr;
+    if (e->staging.size() >= 32) {                       // (an engine whose inputs are replaced over and over)
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return nullptr;
+        release_staging(e);
+    }
+    char* p = nullptr; size_t got = 0;
+    if (pool_get(e->device, true, bytes, &p, &got) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    e->staging.push_back({p, got});
+    return p;
+}
+nemgpu_engine::ZipContext* zip_context(nemgpu_engine* lead)
+{
+    if (lead->zc) return lead->zc;
+    if (lead->device >= 0 && lead->device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[lead->device].m);
+        auto& Z = g_pools[lead->device].zips;
+        if (!Z.empty()) { lead->zc = Z.back(); Z.pop_back(); }
+    }
+    if (!lead->zc) lead->zc = new nemgpu_engine::ZipContext();
+    return lead->zc;
+}
+void zip_context_free(int device, nemgpu_engine::ZipContext* z)
+{
+    for (auto& g : z->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    pool_put(device, true, z->zip_host, z->zip_host_size);
+    pool_put(device, false, z->zip_dev, z->zip_dev_size);
+    pool_put(device, true, (char*)z->zip_flags_host, z->zip_flags_host_size);
+    pool_put(device, false, (char*)z->zip_flags_dev, z->zip_flags_dev_size);
+    delete z;
+}
+void zip_context_release(nemgpu_engine* lead)           // (the lead's stream is idle)
+{
+    nemgpu_engine::ZipContext* z = lead->zc;
+    if (!z) return;
+    lead->zc = nullptr;
+    if (lead->device >= 0 && lead->device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[lead->device].m);
+        if (g_pools[lead->device].zips.size() < 8) { g_pools[lead->device].zips.push_back(z); return; }
+    }
+    zip_context_free(lead->device, z);
+}
+void release_staging(nemgpu_engine* e)                  // (the caller has waited for the stream)
+{
+    for (const nemgpu_engine::Staged& st : e->staging) pool_put(e->device, true, st.p, st.size);
+    e->staging.clear();
+}
 
 // A forked child inherits a HIP runtime it cannot use (and handles parked by its parent that mean nothing to it).
 // PPanGGOLiN's multiprocessing.Pool forks (ppanggolin.py:1039): if the parent has already run nem(), the workers must
@@ -214,8 +351,7 @@ std::once_flag g_atfork_once;
 void atfork_child()
 {
     if (g_hip_used.load()) g_forked_after_hip.store(true);
-    new (&g_park_mutex) std::mutex();                       // the parent may have held it at fork time
-    new (&g_parked) std::vector<ParkedSet>();               // parent's handles: leaked on purpose, never touched
+    g_pools = new ResourcePool[kPoolDevices];               // the parent's handles: leaked on purpose, never touched
 }
 
 constexpr size_t kChunkShared = (size_t)16 << 20;       // small buffers share 16 MB chunks
@@ -224,9 +360,10 @@ constexpr size_t kChunkOwn = (size_t)4 << 20;           // from 4 MB on a buffer
 int chunk_new(nemgpu_engine* e, size_t bytes)
 {
     char* base = nullptr;
-    HIPCHK(hipMalloc((void**)&base, bytes));
-    e->chunks.push_back({base, bytes, 0});
-    HIPCHK(hipMemsetAsync(base, 0, bytes, g_alloc_stream));   // (every later use is on the same stream)
+    size_t got = 0;
+    HIPCHK(pool_get(e->device, false, bytes, &base, &got));
+    e->chunks.push_back({base, got, 0});
+    HIPCHK(hipMemsetAsync(base, 0, got, g_alloc_stream));     // (every later use is on the same stream)
     return NEMGPU_OK;
 }
 
@@ -274,9 +411,20 @@ int alloc_model_buffers(nemgpu_engine* e)
     const size_t kd = (size_t)k * e->d, kdp = (size_t)k * e->dpad;
     int r = NEMGPU_OK;
     auto A = [&](int rr) { if (r == NEMGPU_OK) r = rr; };
-    A(dev_alloc(&e->prop, (size_t)k)); A(dev_alloc(&e->center, kd)); A(dev_alloc(&e->disp, kd));
-    if (e->parent == nullptr) { A(dev_alloc(&e->prop0, (size_t)k)); A(dev_alloc(&e->center0, kd)); A(dev_alloc(&e->disp0, kd)); }
-    A(dev_alloc(&e->nbobs_k, (size_t)k)); A(dev_alloc(&e->iner, kd));
+    {
+        auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        e->par_o_center = a64((size_t)k); e->par_o_disp = e->par_o_center + a64(kd); e->par_o_nb = e->par_o_disp + a64(kd);
+        e->par_words = e->par_o_nb + a64((size_t)k);
+        float* pb = nullptr;
+        A(dev_alloc(&pb, e->par_words));
+        e->prop = pb; e->center = pb + e->par_o_center; e->disp = pb + e->par_o_disp; e->nbobs_k = pb + e->par_o_nb;
+        if (e->parent == nullptr) {
+            float* p0 = nullptr;
+            A(dev_alloc(&p0, e->par_words));
+            e->prop0 = p0; e->center0 = p0 + e->par_o_center; e->disp0 = p0 + e->par_o_disp;
+        }
+    }
+    A(dev_alloc(&e->iner, kd));
     A(dev_alloc(&e->tabT, kdp)); A(dev_alloc(&e->tabL0, kdp));
     A(dev_alloc(&e->nz0, (size_t)k * e->W)); A(dev_alloc(&e->nz1, (size_t)k * e->W));
     A(dev_alloc(&e->am0, (size_t)k * e->W)); A(dev_alloc(&e->am1, (size_t)k * e->W));
@@ -608,7 +756,8 @@ int read_iter_flags(nemgpu_engine* e)
 }
 
 int reset_device(nemgpu_engine* e);
-int reset_state(nemgpu_engine* e);
+int reset_state(nemgpu_engine* e, bool lazy = false);
+int flush_reset(nemgpu_engine* e);
 void drop_graphs(nemgpu_engine* e);
 int criteria_enqueue(nemgpu_engine* e, int buf);
 void fill_result(nemgpu_engine* e, nemgpu_result* res);
@@ -618,6 +767,7 @@ int init_partition(nemgpu_engine* e)
 {
     int r;
     if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
+    if ((r = flush_reset(e))) return r;
     if ((r = ensure_state_buffers(e))) return r;
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
@@ -824,9 +974,11 @@ int loop_begin(nemgpu_engine* e, LoopCursor& lc, int n_iters, bool with_init)
     int r;
     lc = LoopCursor();
     lc.remaining = n_iters; lc.first = with_init;
+    if (!with_init) { if ((r = flush_reset(e))) return r; }
     if (with_init) {
         if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
         if ((r = ensure_state_buffers(e))) return r;
+        e->reset_pending = false;                          // (the head of the first batch is the device half of a reset)
         e->cur = 0; e->sweep_counter = 0;
         e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
         e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
@@ -1061,18 +1213,19 @@ int iterate(nemgpu_engine* e, int n_iters, bool with_init = false)
 // ============================================================================================
 int zip_reserve(nemgpu_engine* lead, size_t bytes)
 {
-    if (lead->zip_cap >= bytes) return NEMGPU_OK;
+    nemgpu_engine::ZipContext* z = zip_context(lead);
+    if (z->zip_cap >= bytes) return NEMGPU_OK;
     HIPCHK(hipStreamSynchronize(lead->stream));
-    for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // (they hold the old slab's addresses)
-    lead->zip_graphs.clear();
-    if (lead->zip_host) (void)hipHostFree(lead->zip_host);
-    if (lead->zip_dev) (void)hipFree(lead->zip_dev);
-    lead->zip_host = nullptr; lead->zip_dev = nullptr; lead->zip_cap = 0;
-    size_t cap = (size_t)1 << 20;
+    for (auto& g : z->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);   // (they hold the old slab's addresses)
+    z->zip_graphs.clear();
+    pool_put(lead->device, true, z->zip_host, z->zip_host_size);
+    pool_put(lead->device, false, z->zip_dev, z->zip_dev_size);
+    z->zip_host = nullptr; z->zip_dev = nullptr; z->zip_cap = 0;
+    size_t cap = (size_t)1 << 20, got = 0;
     while (cap < bytes) cap *= 2;
-    HIPCHK(hipHostMalloc((void**)&lead->zip_host, cap));
-    HIPCHK(hipMalloc((void**)&lead->zip_dev, cap));
-    lead->zip_cap = cap;
+    HIPCHK(pool_get(lead->device, true, cap, &z->zip_host, &got)); z->zip_host_size = got;
+    HIPCHK(pool_get(lead->device, false, cap, &z->zip_dev, &got)); z->zip_dev_size = got;
+    z->zip_cap = cap;
     return NEMGPU_OK;
 }
 
@@ -1081,6 +1234,7 @@ int zip_reserve(nemgpu_engine* lead, size_t bytes)
 int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const std::vector<int>& members, size_t flags_words)
 {
     if (members.empty()) return NEMGPU_OK;
+    nemgpu_engine::ZipContext* z = zip_context(lead);
     // groups of members with the same sequence of (kernel, variant, block, grid height)
     std::vector<std::vector<int>> groups;
     for (int m : members) {
@@ -1111,10 +1265,10 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
             const OpRecord& o0 = recs[g[0]].ops[t];
             const int stride = (o0.nbytes + 15) & ~15;
             Launch L{o0.kind, o0.variant, B, stride, off, 0, 0, o0.gy, o0.block};
-            for (int b = 0; b < B; b++) memcpy(lead->zip_host + off + (size_t)b * stride, recs[g[b]].ops[t].args, (size_t)o0.nbytes);
+            for (int b = 0; b < B; b++) memcpy(z->zip_host + off + (size_t)b * stride, recs[g[b]].ops[t].args, (size_t)o0.nbytes);
             off += (size_t)B * stride;
             L.gx_off = off;
-            int* gx = reinterpret_cast<int*>(lead->zip_host + off);
+            int* gx = reinterpret_cast<int*>(z->zip_host + off);
             for (int b = 0; b < B; b++) { gx[b] = (int)recs[g[b]].ops[t].gx; L.max_gx = std::max(L.max_gx, recs[g[b]].ops[t].gx); }
             off += ((size_t)B * sizeof(int) + 15) & ~(size_t)15;
             launches.push_back(L);
@@ -1123,25 +1277,25 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
     }
     mix(flags_words);
     if (off == 0 && flags_words == 0) return NEMGPU_OK;
-    if (off) HIPCHK(hipMemcpyAsync(lead->zip_dev, lead->zip_host, off, hipMemcpyHostToDevice, lead->stream));
+    if (off) HIPCHK(hipMemcpyAsync(z->zip_dev, z->zip_host, off, hipMemcpyHostToDevice, lead->stream));
     // The launches themselves depend only on the shape (kernels, grids, slab offsets), not on the argument blocks'
     // content: a shape seen before is replayed from its captured graph
     nemgpu_engine::ZipGraph* slot = nullptr;
-    for (auto& g : lead->zip_graphs) if (g.key == key) { slot = &g; break; }
+    for (auto& g : z->zip_graphs) if (g.key == key) { slot = &g; break; }
     if (slot == nullptr && lead->use_graphs) {
-        if (lead->zip_graphs.size() >= 64) {
-            for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-            lead->zip_graphs.clear();
+        if (z->zip_graphs.size() >= 64) {
+            for (auto& g : z->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            z->zip_graphs.clear();
         }
-        lead->zip_graphs.push_back({key, 0, nullptr});
-        slot = &lead->zip_graphs.back();
+        z->zip_graphs.push_back({key, 0, nullptr});
+        slot = &z->zip_graphs.back();
     }
     auto issue = [&]() -> int {
         for (const Launch& L : launches)
-            launch_zipped(L.kind, L.variant, L.B, lead->zip_dev + L.args_off, L.stride, reinterpret_cast<const int*>(lead->zip_dev + L.gx_off),
+            launch_zipped(L.kind, L.variant, L.B, z->zip_dev + L.args_off, L.stride, reinterpret_cast<const int*>(z->zip_dev + L.gx_off),
                           L.max_gx, L.gy, L.block, lead->stream);
         if (flags_words)
-            HIPCHK(hipMemcpyAsync(lead->zip_flags_host, lead->zip_flags_dev, flags_words * sizeof(int), hipMemcpyDeviceToHost, lead->stream));
+            HIPCHK(hipMemcpyAsync(z->zip_flags_host, z->zip_flags_dev, flags_words * sizeof(int), hipMemcpyDeviceToHost, lead->stream));
         return NEMGPU_OK;
     };
     if (slot != nullptr && slot->exec != nullptr) {
@@ -1189,24 +1343,25 @@ int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, st
     }
     const auto t1 = std::chrono::steady_clock::now();
     const size_t fw = lead->flag_words();
+    nemgpu_engine::ZipContext* z = zip_context(lead);
     if (fetch_flags) {
         // every member's flag block goes to one staging area on the device (a last zipped launch) and from there
         // to the host in ONE copy
         const size_t need = fw * E.size();
-        if (lead->zip_flags_cap < need) {
-            if (lead->zip_flags_host) (void)hipHostFree(lead->zip_flags_host);
-            if (lead->zip_flags_dev) (void)hipFree(lead->zip_flags_dev);
-            lead->zip_flags_host = nullptr; lead->zip_flags_dev = nullptr; lead->zip_flags_cap = 0;
-            for (auto& g : lead->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-            lead->zip_graphs.clear();
-            HIPCHK(hipHostMalloc((void**)&lead->zip_flags_host, need * sizeof(int)));
-            HIPCHK(hipMalloc((void**)&lead->zip_flags_dev, need * sizeof(int)));
-            lead->zip_flags_cap = need;
+        if (z->zip_flags_cap < need) {
+            pool_put(lead->device, true, (char*)z->zip_flags_host, z->zip_flags_host_size);
+            pool_put(lead->device, false, (char*)z->zip_flags_dev, z->zip_flags_dev_size);
+            z->zip_flags_host = nullptr; z->zip_flags_dev = nullptr; z->zip_flags_cap = 0;
+            for (auto& g : z->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            z->zip_graphs.clear();
+            HIPCHK(pool_get(lead->device, true, need * sizeof(int), (char**)&z->zip_flags_host, &z->zip_flags_host_size));
+            HIPCHK(pool_get(lead->device, false, need * sizeof(int), (char**)&z->zip_flags_dev, &z->zip_flags_dev_size));
+            z->zip_flags_cap = need;
         }
         size_t slot = 0;
         for (int m : members) {
             set_recorder(&recs[m]);
-            launch_copy_words(E[m]->flags_dev, lead->zip_flags_dev + slot * fw, (int)fw, lead->stream);
+            launch_copy_words(E[m]->flags_dev, z->zip_flags_dev + slot * fw, (int)fw, lead->stream);
             set_recorder(nullptr);
             slot++;
         }
@@ -1216,7 +1371,7 @@ int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, st
     HIPCHK(hipStreamSynchronize(lead->stream));
     if (fetch_flags) {
         size_t slot = 0;
-        for (int m : members) { memcpy(E[m]->flags_host, lead->zip_flags_host + slot * fw, fw * sizeof(int)); slot++; }
+        for (int m : members) { memcpy(E[m]->flags_host, z->zip_flags_host + slot * fw, fw * sizeof(int)); slot++; }
     }
     if (prof) {
         const auto t3 = std::chrono::steady_clock::now();
@@ -1368,20 +1523,34 @@ int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
 
 int reset_device(nemgpu_engine* e)
 {
-    if (e->have_params) {
-        HIPCHK(hipMemcpyAsync(e->prop, e->prop0, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->center, e->center0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->disp, e->disp0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
+    if (e->have_params && e->parent == nullptr) {
+        // (the initial block's tail, where nbobs_k is, stays zero)
+        HIPCHK(hipMemcpyAsync(e->prop, e->prop0, sizeof(float) * e->par_words, hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        if (e->have_params) {
+            HIPCHK(hipMemcpyAsync(e->prop, e->prop0, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->center, e->center0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->disp, e->disp0, sizeof(float) * e->k * e->d, hipMemcpyDeviceToDevice, e->stream));
+        }
+        HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
     }
-    HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
     HIPCHK(hipMemsetAsync(e->sweep_next, 0, sizeof(int), e->stream));
     return NEMGPU_OK;
 }
 
-int reset_state(nemgpu_engine* e)
+int flush_reset(nemgpu_engine* e)
 {
-    int r0 = reset_device(e);
-    if (r0) return r0;
+    if (!e->reset_pending) return NEMGPU_OK;
+    e->reset_pending = false;
+    return reset_device(e);
+}
+
+// host half now; the device half (initial parameters back in place, counters cleared) before the next thing that
+// looks at the device state -- or never, when that is a run whose first launch does it anyway (enqueue_init)
+int reset_state(nemgpu_engine* e, bool lazy)
+{
+    if (lazy) e->reset_pending = true;
+    else { e->reset_pending = false; int r0 = reset_device(e); if (r0) return r0; }
     e->tables_fresh = false;
     e->density_fresh = false;
     e->cur = 0; e->sweep_counter = 0;
@@ -1463,21 +1632,13 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = (g[0] != '0');
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
-    ParkedSet parked{-1, nullptr, nullptr, nullptr};
-    if (!hip_stream) {
-        std::lock_guard<std::mutex> lock(g_park_mutex);
-        for (size_t i = 0; i < g_parked.size(); i++)
-            if (g_parked[i].device == device) { parked = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); break; }
-    }
-    if (parked.device >= 0) {
-        e->stream = parked.stream; e->own_stream = true;
-        e->flags_host = parked.flags_host;
-        e->chunks.push_back({parked.chunk, kChunkShared, 0});
-        e->shared_chunk = 0;
-        if (hipMemsetAsync(parked.chunk, 0, kChunkShared, e->stream) != hipSuccess) { nemgpu_destroy(e); set_error("hipMemsetAsync failed"); return NEMGPU_E_DEVICE; }
-    } else if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
+    if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+        if (device < kPoolDevices) {
+            std::lock_guard<std::mutex> lock(g_pools[device].m);
+            if (!g_pools[device].streams.empty()) { e->stream = g_pools[device].streams.back(); g_pools[device].streams.pop_back(); }
+        }
+        if (!e->stream && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
         e->own_stream = true;
     }
     int r = NEMGPU_OK;
@@ -1488,7 +1649,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     A(dev_alloc(&e->perm, (size_t)e->npad));
     A(dev_alloc(&e->xt, (size_t)d * e->nw64));
     A(alloc_model_buffers(e));
-    if (r == NEMGPU_OK && !e->flags_host && hipHostMalloc((void**)&e->flags_host, e->flag_words() * sizeof(int)) != hipSuccess) {
+    if (r == NEMGPU_OK && !e->flags_host &&
+        pool_get(device, true, e->flag_words() * sizeof(int), (char**)&e->flags_host, &e->flags_host_size) != hipSuccess) {
         set_error("hipHostMalloc failed"); r = NEMGPU_E_DEVICE;
     }
     if (r != NEMGPU_OK) { nemgpu_destroy(e); return r; }
@@ -1504,33 +1666,27 @@ void nemgpu_destroy(nemgpu_engine* e)
     if (!e) return;
     for (nemgpu_engine* c : e->clones) nemgpu_destroy(c);
     e->clones.clear();
-    if (e->clone_slab) (void)hipFree(e->clone_slab);
-    if (e->clone_flags_host) (void)hipHostFree(e->clone_flags_host);
-    e->clone_slab = nullptr; e->clone_flags_host = nullptr;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    pool_put(e->device, false, e->clone_slab, e->clone_slab_size);
+    pool_put(e->device, true, (char*)e->clone_flags_host, e->clone_flags_size);
+    e->clone_slab = nullptr; e->clone_flags_host = nullptr;
     rccl_release(e);
     drop_graphs(e);
     if (g_alloc_engine == e) g_alloc_engine = nullptr;
-    // park the stream, the first shared chunk and the pinned block for the next engine on this device
-    char* keep = nullptr;
-    if (e->own_stream && e->stream && e->flags_host)
-        for (const nemgpu_engine::Chunk& c : e->chunks) if (c.size == kChunkShared) { keep = c.base; break; }
-    if (keep) {
-        std::lock_guard<std::mutex> lock(g_park_mutex);
-        if (g_parked.size() < kParkMax) g_parked.push_back({e->device, e->stream, keep, e->flags_host});
-        else keep = nullptr;
-    }
-    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.base != keep && c.owned) (void)hipFree(c.base);
-    if (e->zip_host) (void)hipHostFree(e->zip_host);
-    if (e->zip_dev) (void)hipFree(e->zip_dev);
-    if (e->zip_flags_host) (void)hipHostFree(e->zip_flags_host);
-    if (e->zip_flags_dev) (void)hipFree(e->zip_flags_dev);
-    for (auto& g : e->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    e->zip_graphs.clear();
-    if (!keep) {
-        if (e->flags_host && !e->flags_host_borrowed) (void)hipHostFree(e->flags_host);
-        if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    // (the stream is idle: everything the engine held goes back to the device's pool for the next engines)
+    release_staging(e);
+    if (e->host_bits_pin) pool_put(e->device, true, (char*)e->host_bits, e->host_bits_pin);
+    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.owned) pool_put(e->device, false, c.base, c.size);
+    zip_context_release(e);
+    if (e->flags_host && !e->flags_host_borrowed) pool_put(e->device, true, (char*)e->flags_host, e->flags_host_size);
+    if (e->own_stream && e->stream) {
+        bool kept = false;
+        if (e->device >= 0 && e->device < kPoolDevices) {
+            std::lock_guard<std::mutex> lock(g_pools[e->device].m);
+            if (g_pools[e->device].streams.size() < kPoolStreams) { g_pools[e->device].streams.push_back(e->stream); kept = true; }
+        }
+        if (!kept) (void)hipStreamDestroy(e->stream);
     }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1539,33 +1695,76 @@ void nemgpu_destroy(nemgpu_engine* e)
 
 void nemgpu_release_cached(void)
 {
-    std::vector<ParkedSet> sets;
-    { std::lock_guard<std::mutex> lock(g_park_mutex); sets.swap(g_parked); }
-    for (const ParkedSet& p : sets) {
-        (void)hipSetDevice(p.device);
-        (void)hipFree(p.chunk);
-        (void)hipHostFree(p.flags_host);
-        (void)hipStreamDestroy(p.stream);
+    for (int dev = 0; dev < kPoolDevices; dev++) {
+        ResourcePool& P = g_pools[dev];
+        std::vector<hipStream_t> streams;
+        std::multimap<size_t, char*> devm, pin;
+        std::vector<nemgpu_engine::ZipContext*> zips;
+        { std::lock_guard<std::mutex> lock(P.m); zips.swap(P.zips); }
+        if (!zips.empty()) (void)hipSetDevice(dev);
+        for (nemgpu_engine::ZipContext* z : zips) zip_context_free(dev, z);      // (its blocks go through the pool ...)
+        {
+            std::lock_guard<std::mutex> lock(P.m);                                // (... which is emptied here)
+            streams.swap(P.streams); devm.swap(P.dev); pin.swap(P.pinned);
+            P.dev_bytes = P.pinned_bytes = 0;
+        }
+        if (streams.empty() && devm.empty() && pin.empty()) continue;
+        (void)hipSetDevice(dev);
+        for (auto& kv : devm) (void)hipFree(kv.second);
+        for (auto& kv : pin) (void)hipHostFree(kv.second);
+        for (hipStream_t st : streams) (void)hipStreamDestroy(st);
     }
 }
 
-int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
+// room for the bit rows on the host: pinned (pooled) when they fit, else the engine's own vector
+static uint32_t* host_bits_reserve(nemgpu_engine* e, size_t words)
 {
-    if (!e || !xbits_host) return NEMGPU_E_FUNCARG;
+    if (e->host_bits_pin) {
+        (void)hipStreamSynchronize(e->stream);             // (a replaced matrix: its upload may still be reading them)
+        pool_put(e->device, true, (char*)e->host_bits, e->host_bits_pin);
+    }
+    e->host_bits = nullptr; e->host_bits_pin = 0; e->host_bits_words = 0;
+    const size_t bytes = std::max<size_t>(words, 1) * sizeof(uint32_t);
+    if (bytes <= kStageMax) {
+        char* p = nullptr; size_t got = 0;
+        if (pool_get(e->device, true, bytes, &p, &got) == hipSuccess) { e->host_bits = (uint32_t*)p; e->host_bits_pin = got; }
+        else (void)hipGetLastError();
+    }
+    if (!e->host_bits) { e->host_bits_own.resize(words); e->host_bits = e->host_bits_own.data(); }
+    else { std::vector<uint32_t>().swap(e->host_bits_own); }
+    e->host_bits_words = words;
+    return e->host_bits;
+}
+
+// bit rows (already in e->host_bits) -> device layouts.  pc: the rows' popcounts when the caller has them, else null.
+// With pinned bit rows nothing here waits for the device: the copies and the layout kernels are ordered on the
+// engine's stream ahead of everything that reads the layouts.
+static int upload_bits(nemgpu_engine* e, const int* pc_in)
+{
     HIPCHK(hipSetDevice(e->device));
+    const uint32_t* xbits_host = e->host_bits;
     uint32_t* xf = nullptr;
+    size_t xf_size = 0;
     const size_t words = (size_t)e->n * e->wf;
     // lane order of the density kernels: inside each 256-family tile, families by popcount (stable)
-    std::vector<int> perm((size_t)e->npad);
+    std::vector<int> perm_own;
+    int* perm = e->host_bits_pin ? (int*)stage(e, (size_t)e->npad * sizeof(int)) : nullptr;
+    const bool async = perm != nullptr;
+    if (!perm) { perm_own.resize((size_t)e->npad); perm = perm_own.data(); }
     for (int i = 0; i < e->npad; i++) perm[i] = i;
     if (e->use_sort) {
-        std::vector<int> pc((size_t)e->n);
-        for (int i = 0; i < e->n; i++) {
-            const uint32_t* row = xbits_host + (size_t)i * e->wf;
-            int c = 0;
-            for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
-            pc[i] = c;
+        std::vector<int> pc_own;
+        if (pc_in == nullptr) {
+            pc_own.resize((size_t)e->n);
+            for (int i = 0; i < e->n; i++) {
+                const uint32_t* row = xbits_host + (size_t)i * e->wf;
+                int c = 0;
+                for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
+                pc_own[i] = c;
+            }
+            pc_in = pc_own.data();
         }
+        const int* pc = pc_in;
         // stable counting sort of every 256-family tile by popcount (0 .. d)
         std::vector<int> slot((size_t)e->d + 2);
         for (int t0 = 0; t0 < e->n; t0 += 256) {
@@ -1578,54 +1777,89 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
             for (int i = t0; i < t1; i++) perm[(size_t)t0 + slot[pc[i]]++] = i;
         }
     }
-    e->host_bits.assign(xbits_host, xbits_host + words);
     // staging copy of the family-major bit rows: small ones live in the engine's chunk, large ones come and go
     const bool staged_in_chunk = words * sizeof(uint32_t) < kChunkOwn;
     if (staged_in_chunk) {
         if (!e->xf_stage) { alloc_for(e); int r = dev_alloc(&e->xf_stage, words); if (r) return r; }
         xf = e->xf_stage;
     } else {
-        HIPCHK(hipMalloc((void**)&xf, words * sizeof(uint32_t)));
+        HIPCHK(pool_get(e->device, false, words * sizeof(uint32_t), (char**)&xf, &xf_size));
     }
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
-        err = hipMemcpyAsync(e->perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
+        err = hipMemcpyAsync(e->perm, perm, (size_t)e->npad * sizeof(int), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess) {
         launch_layout(xf, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->perm, e->xws, e->stream);
         err = hipGetLastError();
     }
-    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    if (!staged_in_chunk) (void)hipFree(xf);
+    if (err == hipSuccess && !(async && staged_in_chunk)) err = hipStreamSynchronize(e->stream);
+    if (!staged_in_chunk) pool_put(e->device, false, (char*)xf, xf_size);
     if (err != hipSuccess) { set_error(std::string("matrix upload failed: ") + hipGetErrorString(err)); return NEMGPU_E_DEVICE; }
     e->have_matrix = true;
     return NEMGPU_OK;
 }
 
+int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
+{
+    if (!e || !xbits_host) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t words = (size_t)e->n * e->wf;
+    memcpy(host_bits_reserve(e, words), xbits_host, words * sizeof(uint32_t));
+    return upload_bits(e, nullptr);
+}
+
+// engines packing a byte matrix right now, in all threads of the process: a lone caller takes helper threads, callers
+// that already run side by side (pangenomenem_amd.batch) pack their own rows
+static std::atomic<int> g_packers{0};
+
 int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
 {
     if (!e || !x_host) return NEMGPU_E_FUNCARG;
-    std::vector<uint32_t> bits((size_t)e->n * e->wf, 0u);
+    HIPCHK(hipSetDevice(e->device));
+    const int d = e->d, wf = e->wf;
+    uint32_t* bits = host_bits_reserve(e, (size_t)e->n * wf);
+    std::vector<int> pc((size_t)e->n);
+    // one pass: 8 values per load (bit 0 of each byte -> one byte), a whole 32-organism word at a time, the row's
+    // popcount (the density kernels' lane order) on the way
     auto pack_rows = [&](int r0, int r1, uint64_t* bad_out) {
         uint64_t bad = 0;
         for (int i = r0; i < r1; i++) {
-            const uint8_t* row = x_host + (size_t)i * e->d;
-            uint32_t* out = bits.data() + (size_t)i * e->wf;
-            int j = 0;
-            for (; j + 8 <= e->d; j += 8) {                        // 8 values per load: bit 0 of each byte -> one byte
-                uint64_t w;
-                memcpy(&w, row + j, 8);
-                bad |= w;
-                const uint32_t b8 = (uint32_t)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-                out[j >> 5] |= b8 << (j & 31);                     // j % 8 == 0: the byte never straddles a word
+            const uint8_t* row = x_host + (size_t)i * d;
+            uint32_t* out = bits + (size_t)i * wf;
+            int j = 0, cnt = 0;
+            for (; j + 32 <= d; j += 32) {
+                uint64_t w[4];
+                memcpy(w, row + j, 32);
+                bad |= (w[0] | w[1]) | (w[2] | w[3]);
+                uint32_t v = 0;
+                for (int q = 0; q < 4; q++)
+                    v |= (uint32_t)(((w[q] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * q);
+                out[j >> 5] = v;
+                cnt += __builtin_popcount(v);
             }
-            for (; j < e->d; j++) { bad |= row[j]; out[j >> 5] |= (uint32_t)(row[j] & 1u) << (j & 31); }
+            if (j < d) {
+                uint32_t v = 0;
+                int b = 0;
+                for (; j + 8 <= d; j += 8, b += 8) {
+                    uint64_t w8;
+                    memcpy(&w8, row + j, 8);
+                    bad |= w8;
+                    v |= (uint32_t)(((w8 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << b;
+                }
+                for (; j < d; j++, b++) { bad |= row[j]; v |= (uint32_t)(row[j] & 1u) << b; }
+                out[wf - 1] = v;
+                cnt += __builtin_popcount(v);
+            }
+            pc[i] = cnt;
         }
         *bad_out = bad;
     };
     // rows are independent: matrices of 4 MB and more are packed by up to 4 threads
-    const size_t bytes = (size_t)e->n * e->d;
+    const size_t bytes = (size_t)e->n * d;
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (int)std::max(1u, std::min({4u, hw ? hw : 1u, (unsigned)(bytes >> 21)}));
+    const int others = g_packers.fetch_add(1);
+    int nt = (int)std::max(1u, std::min({4u, hw ? hw : 1u, (unsigned)(bytes >> 21)}));
+    if (others > 0) nt = 1;
     uint64_t badv[4] = {0, 0, 0, 0};
     {
         std::vector<std::thread> th;
@@ -1634,9 +1868,10 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
         pack_rows(0, (int)((long long)e->n / nt), &badv[0]);
         for (std::thread& x : th) x.join();
     }
+    g_packers.fetch_sub(1);
     const uint64_t bad = badv[0] | badv[1] | badv[2] | badv[3];
-    if (bad & 0xFEFEFEFEFEFEFEFEull) { set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
-    return nemgpu_set_matrix_bits(e, bits.data());
+    if (bad & 0xFEFEFEFEFEFEFEFEull) { e->host_bits_words = 0; set_error("presence/absence matrix must hold 0/1 only"); return NEMGPU_E_ARG; }
+    return upload_bits(e, pc.data());
 }
 
 int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, const float* w)
@@ -1648,20 +1883,29 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     for (int i = 0; i < e->n; i++) if (ptr[i + 1] < ptr[i]) { set_error("graph: ptr not monotone"); return NEMGPU_E_ARG; }
     for (int t = 0; t < nnz; t++)
         if (idx[t] < 0 || idx[t] >= e->n_total) { set_error("graph: neighbour index out of range"); return NEMGPU_E_ARG; }
-    HIPCHK(hipStreamSynchronize(e->stream));
     e->nei_ptr = nullptr; e->nei_idx = nullptr; e->nei_w = nullptr;   // (a replaced graph's arrays stay in their chunk)
     int r;
     alloc_for(e);
-    if ((r = dev_alloc(&e->nei_ptr, (size_t)e->n + 1))) return r;
-    if ((r = dev_alloc(&e->nei_idx, (size_t)nnz))) return r;
-    if ((r = dev_alloc(&e->nei_w, (size_t)nnz))) return r;
-    // three copies, one wait (the sources are the caller's: done before returning)
-    HIPCHK(hipMemcpyAsync(e->nei_ptr, ptr, sizeof(int) * ((size_t)e->n + 1), hipMemcpyHostToDevice, e->stream));
-    if (nnz > 0) {
-        HIPCHK(hipMemcpyAsync(e->nei_idx, idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->nei_w, w, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice, e->stream));
+    // ptr | idx | w in one device block and one pinned block of the engine's: one copy, nothing waits (sources too
+    // large for a pinned block: three copies from the caller's memory and one wait)
+    const size_t b_ptr = sizeof(int) * ((size_t)e->n + 1), b_nz = sizeof(int) * (size_t)nnz;
+    const size_t o_idx = (b_ptr + 255) & ~(size_t)255, o_w = (o_idx + b_nz + 255) & ~(size_t)255, total = o_w + b_nz;
+    char* dev = nullptr;
+    if ((r = dev_alloc(&dev, total))) return r;
+    e->nei_ptr = (int*)dev; e->nei_idx = (int*)(dev + o_idx); e->nei_w = (float*)(dev + o_w);
+    char* st = stage(e, total);
+    if (st) {
+        memcpy(st, ptr, b_ptr);
+        if (nnz > 0) { memcpy(st + o_idx, idx, b_nz); memcpy(st + o_w, w, b_nz); }
+        HIPCHK(hipMemcpyAsync(dev, st, total, hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(e->nei_ptr, ptr, b_ptr, hipMemcpyHostToDevice, e->stream));
+        if (nnz > 0) {
+            HIPCHK(hipMemcpyAsync(e->nei_idx, idx, b_nz, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(e->nei_w, w, b_nz, hipMemcpyHostToDevice, e->stream));
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
     e->nnz = nnz;
     e->has_graph = nnz > 0;
     drop_graphs(e);
@@ -1673,11 +1917,20 @@ int nemgpu_set_params(nemgpu_engine* e, const float* prop, const float* center, 
     if (!e || !prop || !center || !disp) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     const size_t kd = (size_t)e->k * e->d;
-    HIPCHK(copy_sync(e, e->prop0, prop, sizeof(float) * e->k, hipMemcpyHostToDevice));
-    HIPCHK(copy_sync(e, e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
-    HIPCHK(copy_sync(e, e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+    float* st = e->parent == nullptr ? (float*)stage(e, sizeof(float) * e->par_words) : nullptr;
+    if (st) {
+        // one copy of the whole block of initial values (its gaps and its tail are zeros)
+        memset(st, 0, sizeof(float) * e->par_words);
+        memcpy(st, prop, sizeof(float) * e->k); memcpy(st + e->par_o_center, center, sizeof(float) * kd);
+        memcpy(st + e->par_o_disp, disp, sizeof(float) * kd);
+        HIPCHK(hipMemcpyAsync(e->prop0, st, sizeof(float) * e->par_words, hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIPCHK(copy_sync(e, e->prop0, prop, sizeof(float) * e->k, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(e, e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+    }
     e->have_params = true;
-    return reset_state(e);
+    return reset_state(e, true);
 }
 
 int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
@@ -1694,7 +1947,7 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     e->cfg = *cfg;
     HIPCHK(hipSetDevice(e->device));
     drop_graphs(e);                                                // kernel arguments are baked into captured batches
-    return reset_state(e);
+    return reset_state(e, true);
 }
 
 int nemgpu_reset(nemgpu_engine* e)
@@ -1790,12 +2043,141 @@ int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results)
 // restored and EstimPara run on it (:1703-1713).
 static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
 
+// Many whole problems, from host arrays to host arrays, in one call: `workers` threads of the library build the
+// engines (bit packing, uploads out of pinned blocks -- nothing waits for the device), the calling thread runs every
+// `group` of them in lock step as soon as it is complete (nemgpu_run_many), the workers fetch the results and recycle
+// the engines while later groups are being built.  What PPanGGOLiN's chunk loop is when its chunks are arrays.
+int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group)
+{
+    if (!P || count <= 0 || !cfg) return NEMGPU_E_FUNCARG;
+    workers = std::max(1, std::min(workers, 64));
+    group = std::max(1, std::min(group, 256));
+    for (int i = 0; i < count; i++) {
+        nemgpu_problem& q = P[i];
+        q.rc = NEMGPU_OK; q.result = nemgpu_result{};
+        if (q.n <= 0 || q.d <= 0 || q.k <= 0 || (!q.x_bytes == !q.x_bits) || !q.prop || !q.center || !q.disp ||
+            (q.nei_ptr && q.nei_ptr[q.n] > 0 && (!q.nei_idx || !q.nei_w))) {
+            set_error("nemgpu_solve_many: problem " + std::to_string(i) + " is incomplete (sizes, exactly one of x_bytes / x_bits, parameters)");
+            return NEMGPU_E_FUNCARG;
+        }
+    }
+    const int G = (count + group - 1) / group;
+    std::vector<nemgpu_engine*> eng((size_t)count, nullptr);
+    std::vector<std::string> errs((size_t)count);
+    std::vector<int> built((size_t)G, 0);
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<int> fetchq;
+    int build_next = 0, build_limit = std::min(count, 2 * group), fetched = 0;
+    bool quit = false;
+
+    auto build = [&](int i) {
+        nemgpu_problem& q = P[i];
+        nemgpu_engine* e = nullptr;
+        int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, nullptr);
+        if (r == NEMGPU_OK) r = q.x_bits ? nemgpu_set_matrix_bits(e, q.x_bits) : nemgpu_set_matrix_bytes(e, q.x_bytes);
+        if (r == NEMGPU_OK) {
+            if (q.nei_ptr) r = nemgpu_set_graph(e, q.nei_ptr, q.nei_idx, q.nei_w);
+            else { std::vector<int32_t> z((size_t)q.n + 1, 0); r = nemgpu_set_graph(e, z.data(), nullptr, nullptr); }
+        }
+        if (r == NEMGPU_OK) r = nemgpu_set_params(e, q.prop, q.center, q.disp);
+        if (r == NEMGPU_OK) r = nemgpu_configure(e, cfg);
+        if (r != NEMGPU_OK) { errs[(size_t)i] = g_last_error; if (e) nemgpu_destroy(e); e = nullptr; }
+        q.rc = r;
+        eng[(size_t)i] = e;
+    };
+    auto fetch = [&](int i) {
+        nemgpu_problem& q = P[i];
+        nemgpu_engine* e = eng[(size_t)i];
+        if (!e) return;
+        if (q.rc == NEMGPU_OK && (q.out_prop || q.out_center || q.out_disp || q.out_nbobs_k || q.out_c)) {
+            q.rc = nemgpu_get_results(e, q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c);
+            if (q.rc != NEMGPU_OK) errs[(size_t)i] = g_last_error;
+        }
+        nemgpu_destroy(e);
+        eng[(size_t)i] = nullptr;
+    };
+    auto worker = [&]() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lock(m);
+        for (;;) {
+            cv.wait(lock, [&] { return quit || !fetchq.empty() || build_next < build_limit; });
+            if (!fetchq.empty()) {                                 // results first: they free engines for the builders
+                const int i = fetchq.front(); fetchq.pop_front();
+                lock.unlock(); fetch(i); lock.lock();
+                fetched++;
+                cv.notify_all();
+            } else if (build_next < build_limit) {
+                const int i = build_next++;
+                lock.unlock(); build(i); lock.lock();
+                built[(size_t)(i / group)]++;
+                cv.notify_all();
+            } else if (quit) return;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < workers; t++) pool.emplace_back(worker);
+    int rc = NEMGPU_OK;
+    std::string first_err;
+    const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    double t_wait = 0, t_run = 0, t_tail = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
+    for (int g = 0; g < G; g++) {
+        const int i0 = g * group, i1 = std::min(count, i0 + group);
+        {
+            const auto t0 = now();
+            std::unique_lock<std::mutex> lock(m);
+            cv.wait(lock, [&] { return built[(size_t)g] == i1 - i0; });
+            t_wait += since(t0);
+        }
+        std::vector<nemgpu_engine*> E;
+        std::vector<int> who;
+        for (int i = i0; i < i1; i++) if (eng[(size_t)i]) { E.push_back(eng[(size_t)i]); who.push_back(i); }
+        if (!E.empty()) {
+            std::vector<nemgpu_result> R(E.size());
+            (void)hipSetDevice(device);
+            const auto t0 = now();
+            const int r = run_many(E, R.data());
+            t_run += since(t0);
+            for (size_t j = 0; j < E.size(); j++) { P[who[j]].result = R[j]; if (r != NEMGPU_OK) P[who[j]].rc = r; }
+            if (r != NEMGPU_OK && rc == NEMGPU_OK) { rc = r; first_err = g_last_error; }
+        }
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (int i = i0; i < i1; i++) {
+                if (eng[(size_t)i]) fetchq.push_back(i);
+                else fetched++;
+            }
+            build_limit = std::min(count, (g + 3) * group);
+        }
+        cv.notify_all();
+    }
+    {
+        const auto t0 = now();
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return fetched == count; });
+        quit = true;
+        t_tail = since(t0);
+    }
+    if (prof)
+        fprintf(stderr, "[solve_many] %d problems, %d workers, groups of %d: waited for builds %.2f ms, lock-step runs %.2f ms, "
+                        "waited for the last results %.2f ms\n", count, workers, group, t_wait * 1e3, t_run * 1e3, t_tail * 1e3);
+    cv.notify_all();
+    for (std::thread& t : pool) t.join();
+    for (int i = 0; i < count; i++)
+        if (P[i].rc != NEMGPU_OK && rc == NEMGPU_OK) { rc = P[i].rc; first_err = errs[(size_t)i]; }
+    if (rc != NEMGPU_OK && !first_err.empty()) set_error(first_err);
+    return rc;
+}
+
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
 {
     if (!e || n_starts <= 0) return NEMGPU_E_FUNCARG;
     if (e->lo != 0 || e->hi != e->n_total) { set_error("random starts need the whole problem on one engine"); return NEMGPU_E_FUNCARG; }
-    if (!e->have_matrix || e->host_bits.empty()) { set_error("the matrix must be set first"); return NEMGPU_E_FUNCARG; }
+    if (!e->have_matrix || e->host_bits_words == 0) { set_error("the matrix must be set first"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     {
         // the starts are independent EM runs on ONE matrix: by default they run in lock step, every launch serving all
         // of them (NEM_MI355X_BATCH_STARTS=0: one after the other on this engine)
@@ -1935,8 +2317,8 @@ static int ensure_clones(nemgpu_engine* e, int count)
     HIPCHK(hipStreamSynchronize(e->stream));
     for (nemgpu_engine* c : e->clones) nemgpu_destroy(c);
     e->clones.clear();
-    if (e->clone_slab) { (void)hipFree(e->clone_slab); e->clone_slab = nullptr; }
-    if (e->clone_flags_host) { (void)hipHostFree(e->clone_flags_host); e->clone_flags_host = nullptr; }
+    pool_put(e->device, false, e->clone_slab, e->clone_slab_size); e->clone_slab = nullptr;
+    pool_put(e->device, true, (char*)e->clone_flags_host, e->clone_flags_size); e->clone_flags_host = nullptr;
     // what one twin carves: a dry run of its allocations
     {
         nemgpu_engine probe;
@@ -1952,9 +2334,9 @@ static int ensure_clones(nemgpu_engine* e, int count)
     }
     const size_t kd = (size_t)e->k * e->d;
     const size_t par_bytes = (((size_t)count * (e->k + 2 * kd) * sizeof(float)) + 255) & ~(size_t)255;
-    HIPCHK(hipMalloc((void**)&e->clone_slab, par_bytes + (size_t)count * e->clone_bytes));
+    HIPCHK(pool_get(e->device, false, par_bytes + (size_t)count * e->clone_bytes, &e->clone_slab, &e->clone_slab_size));
     HIPCHK(hipMemsetAsync(e->clone_slab, 0, par_bytes + (size_t)count * e->clone_bytes, e->stream));
-    HIPCHK(hipHostMalloc((void**)&e->clone_flags_host, (size_t)count * e->flag_words() * sizeof(int)));
+    HIPCHK(pool_get(e->device, true, (size_t)count * e->flag_words() * sizeof(int), (char**)&e->clone_flags_host, &e->clone_flags_size));
     e->clone_par0 = reinterpret_cast<float*>(e->clone_slab);
     for (int i = 0; i < count; i++) {
         nemgpu_engine* c = nullptr;
@@ -2128,6 +2510,7 @@ int nemgpu_density(nemgpu_engine* e)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
@@ -2139,6 +2522,7 @@ int nemgpu_sweep(nemgpu_engine* e, float beta, int* rounds)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     if ((r = ensure_state_buffers(e))) return r;
     if ((r = do_sweep(e, beta, rounds))) return r;
@@ -2151,6 +2535,7 @@ int nemgpu_mstep(nemgpu_engine* e, int* emptyk)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     if ((r = ensure_state_buffers(e))) return r;
     if ((r = do_mstep(e))) return r;
@@ -2163,6 +2548,7 @@ int nemgpu_criteria(nemgpu_engine* e, float crit6[6])
 {
     if (!e || !crit6) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     return criteria(e, crit6);
 }
 
@@ -2210,6 +2596,7 @@ int nemgpu_shard_begin(nemgpu_engine* e)
     if (e->sh_stride == 0) { set_error("nemgpu_shard_layout must be called first"); return NEMGPU_E_FUNCARG; }
     if (e->libc()) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
     e->stop_ptr = e->ctrl() + C_STOP;
     return NEMGPU_OK;
@@ -2221,6 +2608,7 @@ int nemgpu_shard_counts(nemgpu_engine* e, int32_t* stats_dev)
 {
     if (!e || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
@@ -2231,6 +2619,7 @@ int nemgpu_shard_mstep_partial(nemgpu_engine* e, const uint8_t* labels_cur_dev, 
 {
     if (!e || !labels_cur_dev || !stats_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     launch_labels_post(e->n, e->lo, e->k, e->nw64, labels_cur_dev, nullptr, e->mask, e->iter_flags(), e->stop_ptr,
                        nullptr, e->stream);
     launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
@@ -2246,6 +2635,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
 {
     if (!e || !labels_old_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     const bool fused = stats_dev != nullptr && e->fused_update();
     if (fused) {
@@ -2559,6 +2949,7 @@ int nemgpu_criteria_previous(nemgpu_engine* e, float crit6[6])
 {
     if (!e || !crit6) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     return criteria(e, crit6, (e->cur + 2) % 3);
 }
 
@@ -2567,6 +2958,7 @@ int nemgpu_set_partition(nemgpu_engine* e, const float* c_nk)
     // test hook: load a partition (row-major [n_total x k], HOST) as the current state
     if (!e || !c_nk) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     if ((r = ensure_state_buffers(e))) return r;
     if (e->ncem()) {
@@ -2590,42 +2982,69 @@ int nemgpu_get_labels(nemgpu_engine* e, uint8_t* labels)
     if (!e || !labels) return NEMGPU_E_FUNCARG;
     if (!e->ncem() || !e->lab[e->cur]) { set_error("labels exist only for ncem runs"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(copy_sync(e, labels, e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
     for (int i = 0; i < e->n; i++) labels[i] &= 0x7F;              // (bit 7: the site drew, TIE_LIBC)
     return NEMGPU_OK;
 }
 
+// the final partition and parameters in one round trip: every piece is copied into one pinned block, one wait
+int nemgpu_get_results(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k, float* c_nk)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
+    const size_t kd = (size_t)e->k * e->d, n = (size_t)e->n, k = (size_t)e->k;
+    if (c_nk) {
+        if (e->ncem() ? !e->lab[e->cur] : !e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
+    }
+    const size_t b_part = c_nk ? (e->ncem() ? (n + 3) & ~(size_t)3 : sizeof(float) * n * k) : 0;
+    const bool want_par = prop || center || disp || nbobs_k;
+    const size_t o_prop = b_part, o_center = o_prop + sizeof(float) * e->par_o_center, o_disp = o_prop + sizeof(float) * e->par_o_disp,
+                 o_nb = o_prop + sizeof(float) * e->par_o_nb, total = o_prop + (want_par ? sizeof(float) * e->par_words : 0);
+    char* st = nullptr; size_t got = 0;
+    std::vector<char> own;
+    const bool pinned = total <= kStageMax && pool_get(e->device, true, total, &st, &got) == hipSuccess;
+    if (!pinned) { (void)hipGetLastError(); own.resize(total); st = own.data(); }
+    hipError_t err = hipSuccess;
+    auto D2H = [&](size_t off, const void* src, size_t bytes) {
+        if (err == hipSuccess && bytes) err = hipMemcpyAsync(st + off, src, bytes, hipMemcpyDeviceToHost, e->stream);
+    };
+    if (c_nk) {
+        if (e->ncem()) D2H(0, e->lab[e->cur] + e->lo, n);
+        else D2H(0, e->cbuf[e->cur] + (size_t)e->lo * k, sizeof(float) * n * k);
+    }
+    if (want_par) D2H(o_prop, e->prop, sizeof(float) * e->par_words);   // prop | center | disp | nbobs_k: one block
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) {
+        if (c_nk) {
+            if (e->ncem()) {
+                const uint8_t* lab = (const uint8_t*)st;
+                for (size_t i = 0; i < n; i++)                      // LabelToClassVector, nem_alg.c:649-664
+                    for (size_t h = 0; h < k; h++) c_nk[i * k + h] = ((size_t)(lab[i] & 0x7F) == h) ? 1.0f : 0.0f;
+            } else memcpy(c_nk, st, sizeof(float) * n * k);
+        }
+        if (prop) memcpy(prop, st + o_prop, sizeof(float) * k);
+        if (center) memcpy(center, st + o_center, sizeof(float) * kd);
+        if (disp) memcpy(disp, st + o_disp, sizeof(float) * kd);
+        if (nbobs_k) memcpy(nbobs_k, st + o_nb, sizeof(float) * k);
+    }
+    if (pinned) pool_put(e->device, true, st, got);
+    HIPCHK(err);
+    return NEMGPU_OK;
+}
+
 int nemgpu_get_partition(nemgpu_engine* e, float* c_nk)
 {
     if (!e || !c_nk) return NEMGPU_E_FUNCARG;
-    HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->ncem()) {
-        if (!e->lab[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
-        std::vector<uint8_t> lab((size_t)e->n);
-        HIPCHK(copy_sync(e, lab.data(), e->lab[e->cur] + e->lo, (size_t)e->n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < e->n; i++)                             // LabelToClassVector, nem_alg.c:649-664
-            for (int k = 0; k < e->k; k++) c_nk[(size_t)i * e->k + k] = ((lab[i] & 0x7F) == k) ? 1.0f : 0.0f;
-    } else {
-        if (!e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
-        HIPCHK(copy_sync(e, c_nk, e->cbuf[e->cur] + (size_t)e->lo * e->k, sizeof(float) * (size_t)e->n * e->k,
-                         hipMemcpyDeviceToHost));
-    }
-    return NEMGPU_OK;
+    return nemgpu_get_results(e, nullptr, nullptr, nullptr, nullptr, c_nk);
 }
 
 int nemgpu_get_params(nemgpu_engine* e, float* prop, float* center, float* disp, float* nbobs_k)
 {
     if (!e) return NEMGPU_E_FUNCARG;
-    HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    const size_t kd = (size_t)e->k * e->d;
-    if (prop) HIPCHK(copy_sync(e, prop, e->prop, sizeof(float) * e->k, hipMemcpyDeviceToHost));
-    if (center) HIPCHK(copy_sync(e, center, e->center, sizeof(float) * kd, hipMemcpyDeviceToHost));
-    if (disp) HIPCHK(copy_sync(e, disp, e->disp, sizeof(float) * kd, hipMemcpyDeviceToHost));
-    if (nbobs_k) HIPCHK(copy_sync(e, nbobs_k, e->nbobs_k, sizeof(float) * e->k, hipMemcpyDeviceToHost));
-    return NEMGPU_OK;
+    return nemgpu_get_results(e, prop, center, disp, nbobs_k, nullptr);
 }
 
 int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
@@ -2633,6 +3052,7 @@ int nemgpu_get_density(nemgpu_engine* e, double* pkfki_nk, float* logpkfki_nk)
     // device layout is class-major [k][npad]; hand back the reference's row-major [n][k]
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t m = (size_t)e->k * e->npad;
     if (pkfki_nk) {
@@ -2656,6 +3076,7 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
 {
     if (!e || reps <= 0) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
     int r;
     if ((r = do_tables(e))) return r;
     if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }

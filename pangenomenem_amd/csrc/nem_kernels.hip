@@ -23,6 +23,14 @@
 
 namespace nemk {
 
+// development probe (-DNEM_PHASE_PROF): block 0 / thread 0 stamps the 100 MHz wall clock at phase boundaries
+#ifdef NEM_PHASE_PROF
+__device__ unsigned long long g_phase[32];
+#define NEM_PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase[i] = wall_clock64(); } while (0)
+#else
+#define NEM_PHASE(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
@@ -1437,6 +1445,7 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
             }
             __syncthreads();
         }
+        NEM_PHASE(8);
         bool any_seq = false;
         for (int k = kb; k < ke; k++) any_seq |= (s_seq[k] != 0);
         // per class: sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains (InerToDispK_,
@@ -1453,6 +1462,7 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
                 for (int kk = 0; kk < kn; kk++)
                     for (int d = tid; d < D; d += 1024) s_in[kk * Dp + d] = iner[(k0 + kk) * D + d];
                 __syncthreads();
+                NEM_PHASE(9);
                 if ((tid & 63) == 0) {
                     for (int c = tid >> 6; c < 2 * kn; c += 16) {
                         const int kk = c >> 1, k = k0 + kk;
@@ -1480,6 +1490,7 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
                     }
                 }
                 __syncthreads();
+                NEM_PHASE(10);
                 if (tid < kn && s_seq[k0 + tid]) {
                     const int k = k0 + tid;
                     const float nk = nbobs_k[k];
@@ -1564,6 +1575,7 @@ __device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
         }
         __syncthreads();
     } else if (a.stop != nullptr && *a.stop) return;
+    NEM_PHASE(0);
     if (a.mode == 1) {
         // (every block needs every class size for the empty-class flag; its own class's entries otherwise)
         if (tid < a.K) a.nbobs_k[tid] = (float)stat_sum(a.stats, tid, a.stats_ranks, a.stats_rank_stride);
@@ -1571,15 +1583,19 @@ __device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
             centers_ncem_entry(a.K, a.D, a.stats, a.stats_ranks, a.stats_rank_stride, a.center, a.nbobs_k, a.iner, t);
         __syncthreads();
     }
+    NEM_PHASE(1);
     if (a.mode != 0) {
         disp_body(a.K, a.D, a.n_total, a.disper, a.propor, a.mode == 1, a.nbobs_k, a.iner, a.disp, a.prop, a.flags, kb, ke);
         __syncthreads();
     }
+    NEM_PHASE(2);
     if (tid >= kb && tid < ke) a.nonuni[tid] = 0;
     __syncthreads();
     for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_flag_general(a, t);
     __syncthreads();
+    NEM_PHASE(3);
     for (int t = kb * a.dpad + tid; t < ke * a.dpad; t += 1024) table_entry(a, t);   // dpad and 1024 are multiples of 64
+    NEM_PHASE(4);
     if (a.use_ff && a.ffq != nullptr) {
         // the uniform chain's fast-forward increments (nem_ff.hpp), one table per class that stays on that chain
         __syncthreads();                                 // (uni[k] / nonuni[k] of this block's classes are settled)
@@ -1594,6 +1610,7 @@ __device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
             }
         }
     }
+    NEM_PHASE(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2844,5 +2861,12 @@ void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStr
 {
     hipLaunchKernelGGL(k_calib_read16, dim3(256 * 16), dim3(256), 0, s, (const uint4*)buf, words / 4, sink);
 }
+
+#ifdef NEM_PHASE_PROF
+extern "C" int nemgpu_debug_phases(unsigned long long* out32)
+{
+    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32);
+}
+#endif
 
 }  // namespace nemk

@@ -31,6 +31,40 @@ def test_concurrent_engines_give_the_single_engine_answers(gpu_lib, oracle):
     assert np.array_equal(crowd[3]["c"], want["c"]) and crowd[3]["iters"] == want["iters"]
 
 
+def test_solve_many_groups_bit_rows_and_problems_without_a_graph(gpu_lib):
+    """nemgpu_solve_many: groups smaller than the batch (builders run ahead of the lock-step runs), bit rows instead
+    of bytes, a problem without neighbours -- every answer is the problem's own solve()."""
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import solve
+    probs = _problems(11)
+    probs[4] = (probs[4][0], None) + probs[4][2:]
+    cfg = dict(algo="ncem", beta=0.5, disper="skd", tie="hash", seed=9)
+    want = [solve(*p, **cfg) for p in probs]
+    as_bits = []
+    for x, nei, k, prop, center, disp in probs:
+        b = np.packbits(x, axis=1, bitorder="little")
+        b = np.pad(b, ((0, 0), (0, (-b.shape[1]) % 4)))
+        as_bits.append((np.ascontiguousarray(b).view(np.uint32), nei, k, prop, center, disp))
+    for batch in (solve_many(probs, workers=3, group=4, **cfg), solve_many(as_bits, workers=5, group=3, **cfg),
+                  solve_many(probs[:1], workers=2, group=8, **cfg)):
+        for got, w in zip(batch, want):
+            assert got["iters"] == w["iters"] and got["status"] == w["status"] and got["converged"] == w["converged"]
+            for f in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+                assert np.array_equal(got[f], w[f]), f
+
+
+def test_solve_many_reports_the_problem_that_is_wrong(gpu_lib):
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import NemGpuError
+    probs = _problems(5, n=800, d=40)
+    bad = probs[2][0].copy()
+    bad[5, 7] = 3                                               # not a presence/absence value
+    probs[2] = (bad,) + probs[2][1:]
+    with pytest.raises(NemGpuError, match="0/1"):
+        solve_many(probs, workers=2, group=2, algo="ncem", beta=0.5)
+    assert len(solve_many(probs[:2], workers=2, group=2, algo="ncem", beta=0.5)) == 2    # (the library is fine afterwards)
+
+
 def test_concurrent_dropin_calls(gpu_lib, tmp_path):
     from pangenomenem_amd.batch import nem_many
     probs = _problems(8, n=1500, d=60)
