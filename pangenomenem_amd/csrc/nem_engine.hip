@@ -3178,6 +3178,14 @@ int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
 
 // ---- test hooks for the exact segmented chains (nem_chain.hpp) ----
 // mode 0: plain sequential loop; 1: the host emulation of the device procedure.  No GPU needed.
+extern "C" float nemgpu_repeat_add_host(float x, long long times, int mode)
+{
+    if (mode != 0) return nemk::ff_repeat_add(x, times);
+    volatile float s = 0.0f;
+    for (long long j = 0; j < times; j++) s = s + x;
+    return s;
+}
+
 extern "C" float nemgpu_chain_host(const double* x, long long n, float init, int mode)
 {
     return mode == 0 ? nemchain::run_sequential(x, n, init) : nemchain::run_segmented(x, n, init);

@@ -67,4 +67,45 @@ NEMFF_HD inline void ff_entry(double A, double b0, int E, uint32_t& q0, uint32_t
     }
 }
 
+// s = 0; repeat `times`: s = RN24(s + x) -- the N_KD chain of InerToDispK_ (reference nem_mod.c:1054-1058: the class
+// size added once per organism) -- without the `times` dependent adds.  Inside one binade [2^(e-1), 2^e) with float
+// spacing U the sum is m * U and a step adds the same integer c = RNE(x / U) to m every time; when x / U is an exact
+// tie the rounding goes to the even neighbour, which leaves m even, and from an even m every tie step adds q rounded
+// to even (q = floor(x / U)).  So a binade costs one division instead of its steps; the step that reaches or passes
+// the end of the binade -- the only one whose rounding grid differs -- is a real float add.  All quantities are
+// integers below 2^53 held in doubles (x / U is an exact power-of-two scaling).  x > 0 finite; anything else takes
+// the plain loop.  tests/test_fastforward.py checks it against the loop.
+NEMFF_HD inline float ff_repeat_add(float x, long long times)
+{
+    float s = 0.0f;
+    if (!(x > 0.0f) || !(x <= 3.402823466e+38f)) {          // zero, negative, NaN, inf: nothing to gain, few steps matter
+        for (long long j = 0; j < times && j < 4; j++) s += x;   // (0, NaN and inf are fixed points after one step ...
+        if (x < 0.0f) for (long long j = 4; j < times; j++) s += x;   //  ... a negative x is not: the plain loop)
+        return s;
+    }
+    long long left = times;
+    while (left > 0) {
+        if (!(s <= 3.402823466e+38f)) return s;                 // overflowed: inf + x = inf
+        int e = 0;
+        (void)frexp((double)s, &e);                             // s in [2^(e-1), 2^e)
+        if (s == 0.0f || e - 24 < -149 + 1) { s += x; left--; continue; }   // zero / subnormal spacing: step for real
+        const double U = ldexp(1.0, e - 24);
+        double m = (double)s / U;                               // integer in [2^23, 2^24)
+        const double xq = (double)x / U, q = floor(xq), fr = xq - q;
+        double c;
+        if (fr > 0.5) c = q + 1.0;
+        else if (fr < 0.5) c = q;
+        else {
+            if (fmod(m, 2.0) != 0.0) { s += x; left--; continue; }   // a tie step from an odd m: for real (m becomes even)
+            c = q + fmod(q, 2.0);
+        }
+        if (c == 0.0) return s;                                 // x vanishes against s: nothing changes any more
+        double j = floor((16777215.0 - m) / c);                  // steps that stay below 2^24
+        if (j > (double)left) j = (double)left;
+        if (j > 0.0) { m += j * c; left -= (long long)j; s = (float)(m * U); }
+        if (left > 0) { s += x; left--; }                       // the step that reaches the end of the binade
+    }
+    return s;
+}
+
 }  // namespace nemk

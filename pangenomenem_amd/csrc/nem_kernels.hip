@@ -1554,6 +1554,248 @@ __device__ inline void disp_body(int K, int D, int n_total, int disper, int prop
     }
 }
 
+// The same update for ONE class per block (the class-separable models sk_ / skd and tables-only launches) and
+// dpad <= 1024 * NI: every thread keeps its organisms' centre, inertia and dispersion in registers from the counts
+// to the tables, so no phase waits for the stores of the phase before it (each such store -> barrier -> load costs
+// 1.5-2 us, and the generic form below has five of them); the class constants' logs are taken once; the N_KD chain
+// of the sk_ model is its closed form (nem_ff.hpp) and the inertia chain -- the only sequential part left, D
+// dependent float adds on one lane -- reads its values from LDS one group ahead of the adds.
+template <int NI>
+__device__ __forceinline__ void finish_lean(const FinishArgs& a)
+{
+    constexpr int CAP = 1024 * NI;
+    __shared__ float4 s_in4[CAP / 4];
+    __shared__ float s_si, s_sn, s_eps0;
+    __shared__ double s_l1, s_l0;
+    __shared__ unsigned long long s_tot2;
+    float* s_in = reinterpret_cast<float*>(s_in4);
+    const int tid = threadIdx.x, k = blockIdx.x, K = a.K, D = a.D, dpad = a.dpad;
+    const int lane = tid & 63;
+    const bool restart = a.reset_prop != nullptr;
+    if (restart) {
+        // initial parameters back in place, loop control cleared (the stop word may still be set from the run before;
+        // every later kernel of the batch reads it after this launch)
+        if (tid == 0) a.nbobs_k[k] = 0.0f;
+        if (k == 0) {
+            if (tid < a.reset_ctrl_words && tid != C_FOLD) a.reset_ctrl[tid] = 0;
+            if (tid == 0) a.reset_sweep_next[0] = 0;
+        }
+    } else if (a.stop != nullptr && *a.stop) return;
+    NEM_PHASE(0);
+    float mu[NI], in[NI], eps[NI];
+    float nkf = 0.0f;
+    if (tid == 0) s_tot2 = 0ull;
+    // ---- centres and inertia
+    if (a.mode == 1) {
+        // (every block needs every class size for the empty-class flag; its own class's entries otherwise)
+        if (tid < K) a.nbobs_k[tid] = (float)stat_sum(a.stats, tid, a.stats_ranks, a.stats_rank_stride);
+        const int nk = stat_sum(a.stats, k, a.stats_ranks, a.stats_rank_stride);
+        nkf = (float)nk;
+        const bool live = (double)nkf > kEpsilonD;
+        const float half = nkf / 2;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int d = tid + 1024 * i;
+            mu[i] = 0.0f; in[i] = 0.0f;
+            if (d < D) {
+                const int t = k * D + d;
+                if (live) {                                      // centers_ncem_entry
+                    const int s1 = stat_sum(a.stats, K + t, a.stats_ranks, a.stats_rank_stride);
+                    const float s0f = (float)(nk - s1);
+                    if (s0f > half) { mu[i] = 0.0f; in[i] = (float)s1; }
+                    else if (s0f == half) { mu[i] = 0.5f; in[i] = 0.5f * nkf; }
+                    else { mu[i] = 1.0f; in[i] = s0f; }
+                    a.center[t] = mu[i];
+                } else mu[i] = a.center[t];
+                a.iner[t] = in[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int d = tid + 1024 * i;
+            mu[i] = 0.0f; in[i] = 0.0f;
+            if (d < D) {
+                const int t = k * D + d;
+                if (restart) { mu[i] = a.reset_center[t]; a.center[t] = mu[i]; }
+                else mu[i] = a.center[t];
+                if (a.mode == 2) in[i] = a.iner[t];
+            }
+        }
+        if (a.mode == 2) nkf = a.nbobs_k[k];
+    }
+    NEM_PHASE(1);
+    // ---- dispersion (InerToDispKD / InerToDispK_) and proportions
+    if (a.mode == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int d = tid + 1024 * i;
+            eps[i] = 0.0f;
+            if (d < D) {
+                if (restart) { eps[i] = a.reset_disp[k * D + d]; a.disp[k * D + d] = eps[i]; }
+                else eps[i] = a.disp[k * D + d];
+            }
+        }
+    } else if (a.disper == NEMGPU_DISP_KD) {
+        const bool live = (double)nkf > kEpsilonD;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int d = tid + 1024 * i;
+            eps[i] = 0.0f;
+            if (d < D) {
+                if (live) { eps[i] = in[i] / nkf; a.disp[k * D + d] = eps[i]; }
+                else eps[i] = a.disp[k * D + d];
+            }
+        }
+    } else {                                                     // sk_
+        float dk = 0.0f;
+        const bool valid = nkf > 0.0f;
+        if (valid) {
+            bool seq = true;
+            if (a.mode == 1) {
+                // the inertia values are non-negative multiples of 1/2 and N_K is an integer: a d-ordered float chain
+                // whose total stays below 2^24 half-units never rounds and equals the closed form
+                long long acc = 0;
+#pragma unroll
+                for (int i = 0; i < NI; i++) acc += (long long)(2.0f * in[i]);
+                acc = wave_reduce_add_ll(acc);
+                __syncthreads();                                 // (s_tot2 = 0 is in place)
+                if (lane == 0 && acc != 0) atomicAdd(&s_tot2, (unsigned long long)acc);
+                __syncthreads();
+                const long long tot2 = (long long)s_tot2, cap = 1ll << 24;
+                if (tot2 <= cap && (long long)nkf * (long long)D <= cap) {
+                    seq = false;
+                    dk = (0.5f * (float)tot2) / (nkf * (float)D);
+                }
+            }
+            if (seq) {
+                // sn = sum_d N_KD, si = sum_d Iner, both d-ordered float chains (InerToDispK_, nem_mod.c:1054-1058)
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < NI; i++) s_in[tid + 1024 * i] = in[i];        // (zeros beyond D: si + 0 = si)
+                __syncthreads();
+                NEM_PHASE(9);
+                if (tid == 64) s_sn = ff_repeat_add(nkf, D);
+                if (tid == 0) {
+                    float si = 0.0f;
+                    const int ng = (D + 31) >> 5;                // groups of 32 values, the next one loaded over the adds
+                    float4 cur[8], nxt[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cur[j] = s_in4[j];
+                    for (int g = 0; g < ng; g++) {
+                        const int gn = min(g + 1, CAP / 32 - 1);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) nxt[j] = s_in4[gn * 8 + j];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) si = (((si + cur[j].x) + cur[j].y) + cur[j].z) + cur[j].w;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+                    }
+                    s_si = si;
+                }
+                __syncthreads();
+                NEM_PHASE(10);
+                dk = s_si / s_sn;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int d = tid + 1024 * i;
+            eps[i] = 0.0f;
+            if (d < D) {
+                if (valid) { eps[i] = dk; a.disp[k * D + d] = dk; }
+                else eps[i] = a.disp[k * D + d];
+            }
+        }
+    }
+    float propk = 0.0f;
+    if (tid == 0) {
+        if (a.mode == 0) propk = restart ? a.reset_prop[k] : a.prop[k];
+        else propk = (a.propor == NEMGPU_PROP_K) ? nkf / (float)a.n_total : (float)(1.0 / K);
+        if (a.mode != 0 || restart) a.prop[k] = propk;
+        if (a.mode != 0 && k == 0) {                             // EstimLaplaceCenters :1404-1408
+            int ek = 0;
+            for (int c = 0; c < K; c++) {
+                const float nc = a.mode == 1 ? (float)stat_sum(a.stats, c, a.stats_ranks, a.stats_rank_stride) : a.nbobs_k[c];
+                if (!((double)nc > kEpsilonD)) ek = c + 1;
+            }
+            a.flags[FLAG_EMPTYK] = ek;
+        }
+        s_eps0 = eps[0];
+    }
+    NEM_PHASE(2);
+    __syncthreads();
+    // ---- density tables (table_flag_general + table_entry, from the registers)
+    const float eps0 = s_eps0;
+    bool general = false;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int d = tid + 1024 * i;
+        if (d < D) {
+            const int ad0 = abs((int)(0.0f - mu[i])), ad1 = abs((int)(1.0f - mu[i]));
+            general |= (ad0 > 1) || (ad1 > 1) || (__float_as_uint(eps[i]) != __float_as_uint(eps0)) ||
+                       !((double)eps[i] > kEpsilonD) || (dpad >> 5) > kDensMaskWords;
+        }
+    }
+    if (tid == 0 && (double)eps0 > kEpsilonD) {
+        const double l1 = log((double)((1.0f - eps0) / eps0)), l0 = log((double)(1.0f - eps0));
+        if (!general && (!isfinite(l1) || !isfinite(l0))) general = true;   // 0 * inf / NaN must propagate as in the reference
+        s_l1 = l1; s_l0 = l0;
+        a.uni[k] = make_double2(l1, l0);
+    }
+    const bool nonuni = __syncthreads_or(general ? 1 : 0) != 0;
+    NEM_PHASE(3);
+    if (tid == 0) {
+        a.nonuni[k] = nonuni ? 1 : 0;
+        const double p = (double)propk;                          // ComputePkFkiM, nem_alg.c:2262-2271
+        a.pk[k] = p;
+        if (p > kEpsilonD) a.logpk[k] = (float)log(p);
+        else { a.logpk[k] = -INFINITY; atomicOr(&a.flags[FLAG_EMPTY_PROP], 1); }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int dd = tid + 1024 * i;                           // dpad and 1024 are multiples of 64: whole waves
+        if (dd < dpad) {
+            double t0 = 0.0, t1 = 0.0, l0 = 0.0;
+            int n0 = 0, n1 = 0, a0 = 0, a1 = 0;
+            if (dd < D) {
+                const int ad0 = abs((int)(0.0f - mu[i])), ad1 = abs((int)(1.0f - mu[i]));
+                a0 = (ad0 != 0); a1 = (ad1 != 0);
+                if ((double)eps[i] > kEpsilonD) {
+                    if (nonuni) {
+                        const double l1 = log((double)((1.0f - eps[i]) / eps[i]));
+                        l0 = log((double)(1.0f - eps[i]));
+                        t0 = (double)ad0 * l1;
+                        t1 = (double)ad1 * l1;
+                    }
+                } else { n0 = a0; n1 = a1; }
+            }
+            const int t = k * dpad + dd;
+            if (dd >= D || nonuni) {                             // (padding entries are always written: zeros)
+                a.tabT[t] = make_double2(t0, t1);
+                a.tabL0[t] = l0;
+            }
+            const uint64_t m0 = __ballot(n0), m1 = __ballot(n1), b0 = __ballot(a0), b1 = __ballot(a1);
+            if (lane == 0) {
+                const int w = t >> 5;                            // word index inside [K][dpad/32]
+                a.nz0[w] = (uint32_t)m0; a.nz0[w + 1] = (uint32_t)(m0 >> 32);
+                a.nz1[w] = (uint32_t)m1; a.nz1[w + 1] = (uint32_t)(m1 >> 32);
+                a.am0[w] = (uint32_t)b0; a.am0[w + 1] = (uint32_t)(b0 >> 32);
+                a.am1[w] = (uint32_t)b1; a.am1[w + 1] = (uint32_t)(b1 >> 32);
+            }
+        }
+    }
+    NEM_PHASE(4);
+    if (a.use_ff && a.ffq != nullptr && !nonuni && tid < 256) {
+        // the uniform chain's fast-forward increments (nem_ff.hpp) for a class that stays on that chain
+        uint32_t q0, q1;
+        ff_entry(s_l1, -s_l0, tid, q0, q1);
+        if (q0 == kFFInvalid) q1 = kFFInvalid;
+        a.ffq[k * 256 + tid] = make_uint2(q0, q1 - q0);
+    }
+    NEM_PHASE(5);
+}
+
 // The whole parameter update behind the sufficient statistics in ONE single-block launch:
 // centres + inertia (NCEM, from the counts), dispersion + proportions, then the density tables
 // E1 reads.  K*D is small (1 500 at configs[1], 15 000 at configs[3]); the only long part is the
@@ -1562,6 +1804,10 @@ __device__ __forceinline__ void finish_body(const FinishArgs& a, const int nblk)
 {
     const int tid = threadIdx.x;
     // grid = K blocks (one class each) for the class-separable dispersion models, else one block for all classes
+    if (nblk > 1 && a.dpad <= 8192 && (a.mode == 0 || a.disper == NEMGPU_DISP_K_ || a.disper == NEMGPU_DISP_KD)) {
+        finish_lean<8>(a);
+        return;
+    }
     const int kb = (nblk > 1) ? blockIdx.x : 0;
     const int ke = (nblk > 1) ? kb + 1 : a.K;
     if (a.reset_prop != nullptr) {

@@ -188,3 +188,24 @@ def test_whole_chain_control_flow(eps, p_mismatch, D):
         got, slow = emulate_chain_ff(words, D, l1, l0, q0, q1)
         assert got == int(bits[0])
         assert slow < D // 2 + 40                     # it really fast-forwards
+
+
+def test_repeated_add_closed_form_equals_the_loop():
+    """ff_repeat_add: the N_KD chain of InerToDispK_ (s += N_k, once per organism) per binade instead of per step."""
+    lib = load_library()
+    f = lib.nemgpu_repeat_add_host
+    f.restype = ctypes.c_float
+    f.argtypes = [ctypes.c_float, ctypes.c_longlong, ctypes.c_int]
+    rng = np.random.Generator(np.random.PCG64(3))
+    xs = [1.0, 3.0, 5.0, 7.0, 0.5, 1.5, 2.5, 0.1, 1e-3, 66667.0, 16777215.0, 16777216.0, 33554432.0, 1e30, 3e38,
+          1e-45, 1e-39, 0.0, -0.0, 123456.789]
+    xs += list(rng.integers(1, 200000, 200).astype(np.float32))                # class sizes
+    xs += list((rng.integers(1, 4000, 100) * 0.5).astype(np.float32))          # half-integers: exact ties on every grid
+    xs += list(rng.uniform(0, 1e6, 100).astype(np.float32))
+    for x in xs:
+        for times in (0, 1, 2, 3, 5, 17, 500, 5000, 5001, 40000):
+            a, b = f(x, times, 0), f(x, times, 1)
+            assert np.float32(a).tobytes() == np.float32(b).tobytes(), (x, times, a, b)
+    for x in (-1.0, -0.3, float("inf")):                                         # no closed form: the loop itself
+        assert f(x, 300, 0) == f(x, 300, 1)
+    assert np.isnan(f(float("nan"), 9, 1))
