@@ -1675,23 +1675,36 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                 for (int i = 0; i < NI; i++) s_in[tid + 1024 * i] = in[i];        // (zeros beyond D: si + 0 = si)
                 __syncthreads();
                 NEM_PHASE(9);
-                if (tid == 64) s_sn = ff_repeat_add(nkf, D);
+                if (tid == 64) {
+                    s_sn = ff_repeat_add(nkf, D);
+#ifdef NEM_PHASE_PROF
+                    if (blockIdx.x == 0) g_phase[12] = wall_clock64();
+#endif
+                }
                 if (tid == 0) {
                     float si = 0.0f;
-                    const int ng = (D + 31) >> 5;                // groups of 32 values, the next one loaded over the adds
-                    float4 cur[8], nxt[8];
+                    // groups of 32 values, two register sets: one is loaded from LDS while the other is added
+                    const int ng = (D + 31) >> 5, last = CAP / 32 - 1;
+                    float4 A[8], B[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) cur[j] = s_in4[j];
-                    for (int g = 0; g < ng; g++) {
-                        const int gn = min(g + 1, CAP / 32 - 1);
+                    for (int j = 0; j < 8; j++) A[j] = s_in4[j];
+                    for (int g = 0; g < ng; g += 2) {
+                        const int g1 = min(g + 1, last), g2 = min(g + 2, last);
 #pragma unroll
-                        for (int j = 0; j < 8; j++) nxt[j] = s_in4[gn * 8 + j];
+                        for (int j = 0; j < 8; j++) B[j] = s_in4[g1 * 8 + j];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) si = (((si + cur[j].x) + cur[j].y) + cur[j].z) + cur[j].w;
+                        for (int j = 0; j < 8; j++) si = (((si + A[j].x) + A[j].y) + A[j].z) + A[j].w;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+                        for (int j = 0; j < 8; j++) A[j] = s_in4[g2 * 8 + j];
+                        if (g + 1 < ng) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) si = (((si + B[j].x) + B[j].y) + B[j].z) + B[j].w;
+                        }
                     }
                     s_si = si;
+#ifdef NEM_PHASE_PROF
+                    if (blockIdx.x == 0) g_phase[11] = wall_clock64();
+#endif
                 }
                 __syncthreads();
                 NEM_PHASE(10);

@@ -31,9 +31,9 @@ def main():
     rc = lib.nemgpu_debug_phases(out)
     t = [int(v) for v in out]
     names = {0: "entry", 1: "centres", 2: "dispersion done", 3: "flags", 4: "table entries", 5: "ff tables",
-             8: "  closed-form test", 9: "  staged", 10: "  chains"}
+             8: "  closed-form test", 9: "  staged", 10: "  chains", 11: "    inertia chain", 12: "    N_KD closed form"}
     base = t[0]
-    for i in (0, 1, 8, 9, 10, 2, 3, 4, 5):
+    for i in (0, 1, 8, 9, 12, 11, 10, 2, 3, 4, 5):
         print("%-22s +%.2f us" % (names[i], (t[i] - base) / 100.0))
     return rc
 
