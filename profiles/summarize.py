@@ -137,6 +137,9 @@ def main():
         b = os.path.join(OUT, "%s_%s" % (R, name))
         if os.path.isfile(b) and os.path.getsize(b) > 0:
             shutil.copy(b, os.path.join(HERE, "%s_%s" % (R, name)))
+    b = os.path.join(OUT, "dropin_whole_call.json")     # (written by tests/test_gpu_dropin_fullsize.py, no round in its name)
+    if os.path.isfile(b) and os.path.getsize(b) > 0:
+        shutil.copy(b, os.path.join(HERE, "%s_dropin_whole_call.json" % R))
     ks = os.path.join(OUT, "%s_ksweep.jsonl" % R)
     if os.path.isfile(ks):
         rows = []

@@ -69,7 +69,7 @@ def test_dropin_whole_call_at_configs1(gpu_lib, tmp_path):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r01_dropin_whole_call.json"), "w") as f:
+        with open(os.path.join(out, "dropin_whole_call.json"), "w") as f:
             json.dump(rec, f, indent=1)
     except OSError:
         pass
