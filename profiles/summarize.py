@@ -47,15 +47,15 @@ def per_kernel(counter_csv, stat="mean"):
 
 
 def full_launch_us(trace_csv, kernel):
-    """duration of the kernel's FULL launches in a lock-step batch: the median of the top decile of its launches
-    (members converge at different iterations, so most launches of a batch serve fewer than all members; launches
-    that return at the stop word are a few microseconds)"""
+    """duration of the kernel's FULL launches in a lock-step batch: the median of the launches within 10 % of the
+    longest one (members converge at different iterations, so later launches of a batch serve fewer and fewer of its
+    members; launches that return at the stop word are a few microseconds)"""
     d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace_csv))
                if short(r["Kernel_Name"]) == kernel)
     if not d:
-        return None, 0
-    top = d[-max(1, len(d) // 10):]
-    return top[len(top) // 2], len(d)
+        return None, 0, 0
+    top = [x for x in d if x >= 0.9 * d[-1]]
+    return top[len(top) // 2], len(d), len(top)
 
 
 def main():
@@ -109,7 +109,7 @@ def main():
         out = {"workload": "16 independent configs[1]-sized problems (20000 x 500, K=3) per launch, nemgpu_run_many",
                "kernels": {}}
         for kern in ("k_density_b", "k_density_fused_b"):
-            us, calls = full_launch_us(trace, kern)
+            us, calls, full = full_launch_us(trace, kern)
             if us is None:
                 continue
             n, d, k, B = 20000, 500, 3, 16
@@ -118,7 +118,7 @@ def main():
             for w in workloads:
                 if w.get("problems_per_launch") == 16 and kern in w["kernels"]:
                     tr = w["kernels"][kern]["traffic_bytes_per_launch"]
-            out["kernels"][kern] = {"bound": "hbm", "full_launch_us": us, "launches_in_trace": calls,
+            out["kernels"][kern] = {"bound": "hbm", "full_launch_us": us, "launches_in_trace": calls, "full_launches": full,
                                     "algorithmic_bytes_per_launch": alg, "achieved": alg / (us * 1e-6) / 1e9,
                                     "peak": HBM_PEAK, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK,
                                     "traffic": tr}
