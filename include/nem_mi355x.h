@@ -310,7 +310,8 @@ int nemgpu_ff_table(double l1, double l0, uint32_t* q0_256, uint32_t* q1_256);
    nemgpu_chain_host -- mode 0: the plain sequential loop, mode 1: the host emulation of the device procedure
    (no GPU needed); nemgpu_chain_device -- the device procedure itself. */
 float nemgpu_chain_host(const double* x, long long n, float init, int mode);
-/* s = 0; `times` times s += x in float: mode 0 the loop, mode 1 its closed form per binade (csrc/nem_ff.hpp) */
+/* s = 0; `times` times s += x in float: mode 0 the loop, mode 1 its closed form per binade, mode 2 the integer form of
+   that for integer x below 2^24 (csrc/nem_ff.hpp) */
 float nemgpu_repeat_add_host(float x, long long times, int mode);
 int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out);
 

@@ -3180,6 +3180,7 @@ int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
 // mode 0: plain sequential loop; 1: the host emulation of the device procedure.  No GPU needed.
 extern "C" float nemgpu_repeat_add_host(float x, long long times, int mode)
 {
+    if (mode == 2) return (x > 0.0f && x < 16777216.0f && x == (float)(uint32_t)x) ? nemk::ff_repeat_add_u24((uint32_t)x, times) : nemk::ff_repeat_add(x, times);
     if (mode != 0) return nemk::ff_repeat_add(x, times);
     volatile float s = 0.0f;
     for (long long j = 0; j < times; j++) s = s + x;

@@ -22,6 +22,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #if defined(__HIPCC__)
 #define NEMFF_HD __host__ __device__
@@ -104,6 +105,49 @@ NEMFF_HD inline float ff_repeat_add(float x, long long times)
         if (j > (double)left) j = (double)left;
         if (j > 0.0) { m += j * c; left -= (long long)j; s = (float)(m * U); }
         if (left > 0) { s += x; left--; }                       // the step that reaches the end of the binade
+    }
+    return s;
+}
+
+// The same chain for an integer addend 0 < H < 2^24 (an NCEM class size), in integer arithmetic: exact adds while the
+// sum stays at or below 2^24, then per binade the constant increment of the 24-bit significand -- one 32-bit
+// division per binade instead of its steps, no double-precision library calls (ff_repeat_add's frexp / ldexp / fmod
+// cost as much as a thousand dependent adds on a lone GPU lane).
+NEMFF_HD inline float ff_repeat_add_u24(uint32_t H, long long times)
+{
+    if (times <= 0 || H == 0u) return 0.0f;
+    const uint32_t L = 1u << 24;
+    long long j0 = (long long)(L / H);
+    if (j0 > times) j0 = times;
+    float s = (float)((uint32_t)j0 * H);                     // <= 2^24: exact
+    long long left = times - j0;
+    const float x = (float)H;
+    while (left > 0) {
+        uint32_t bits;
+        memcpy(&bits, &s, 4);
+        const int E = (int)((bits >> 23) & 255u);
+        const int sh = E - 150;                                 // s = m * 2^sh, m in [2^23, 2^24)
+        if (sh < 0 || E == 255) { s = s + x; left--; continue; }   // (cannot happen for a sum that left the exact range)
+        if (sh >= 25) return s;                                 // H < 2^24 <= half a spacing: nothing changes any more
+        uint32_t m = (bits & 0x7FFFFFu) | 0x800000u;
+        const uint32_t q = H >> sh, r = H & ((1u << sh) - 1u), half = sh ? (1u << (sh - 1)) : 0u;
+        uint32_t c;
+        if (sh == 0 || r < half) c = q;
+        else if (r > half) c = q + 1u;
+        else {
+            if (m & 1u) { s = s + x; left--; continue; }        // a tie step from an odd significand: for real (it becomes even)
+            c = q + (q & 1u);
+        }
+        if (c == 0u) return s;
+        long long j = (long long)((L - 1u - m) / c);            // steps that stay inside the binade
+        if (j > left) j = left;
+        if (j > 0) {
+            m += (uint32_t)j * c;
+            left -= j;
+            bits = ((uint32_t)E << 23) | (m & 0x7FFFFFu);
+            memcpy(&s, &bits, 4);
+        }
+        if (left > 0) { s = s + x; left--; }                    // the step that reaches the end of the binade
     }
     return s;
 }

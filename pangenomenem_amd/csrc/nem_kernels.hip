@@ -271,6 +271,10 @@ __device__ __forceinline__ float chain_plain(const uint4* __restrict__ xw4, int 
 // boundary step with the reference's own arithmetic, reloads the increments of the new binade and goes on.
 // sQ0 / sQ1: the class's 256-entry increment tables (LDS).  Bit-identical to chain_plain.
 constexpr int kFFPlainWords = 1;
+#ifndef NEM_FF_PLAIN_STEPS
+#define NEM_FF_PLAIN_STEPS 32
+#endif
+constexpr int kFFPlainSteps = NEM_FF_PLAIN_STEPS;      // organisms of the first word that are stepped (the rest of it is fast-forwarded)
 
 // sQ0[E] = q0, sDQ[E] = q1 - q0 (both at most 2^23: 24-bit multiplies), see ff_build
 __device__ __forceinline__ void ff_load(const uint32_t* sQ0, const uint32_t* sDQ, uint32_t bits, uint32_t& q0, uint32_t& dq,
@@ -365,9 +369,10 @@ __device__ __forceinline__ void ff_group(const uint4& xv, int g, const uint2* am
             // the first organisms run through small binades (a crossing every few steps): stepping is cheaper
             float dk0 = __uint_as_float(bits);
 #pragma unroll
-            for (int b = 0; b < 32; b++) dk0 = bern_step(dk0, m, b, l1h, l0);
+            for (int b = 0; b < kFFPlainSteps; b++) dk0 = bern_step(dk0, m, b, l1h, l0);
             bits = __float_as_uint(dk0);
             ff_load(sQ0, sQ1, bits, q0, q1, end);
+            if (kFFPlainSteps < 32) ff_word(bits, q0, q1, end, m >> kFFPlainSteps, 32 - kFFPlainSteps, sQ0, sQ1, l1h, l0);
         } else {
             ff_word(bits, q0, q1, end, m, 32, sQ0, sQ1, l1h, l0);
         }
@@ -640,8 +645,11 @@ __device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
     if (a.disper == NEMGPU_DISP_K_) {
         if (nkf > 0) {
             const long long cap = 1ll << 24;
-            if ((long long)sTot2 <= cap && (long long)nkI * (long long)D <= cap) {         // (block-uniform)
-                if (tid == 0) sEps = (0.5f * (float)(long long)sTot2) / (nkf * (float)D);  // the d-ordered chains never round here
+            if ((long long)sTot2 <= cap && nkI < (1 << 24)) {                              // (block-uniform)
+                // the d-ordered inertia chain never rounds here (multiples of 1/2 below 2^23); the N_KD chain -- the
+                // class size added D times -- is its closed form (nem_ff.hpp: exact while N_K * D <= 2^24, then one
+                // division per binade)
+                if (tid == 0) sEps = (0.5f * (float)(long long)sTot2) / ff_repeat_add_u24((uint32_t)nkI, D);
             } else {
                 // the two d-ordered chains of InerToDispK_ (nem_mod.c:1054-1058), each on a wave of its own: the
                 // inertia values sixteen at a time from LDS ahead of the dependent adds, the N_KD chain from a register
@@ -658,10 +666,13 @@ __device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
                     for (; d < D; d++) si += sVal[d];
                     sChain[0] = si;
                 } else if (tid == 64) {
-                    float sn = 0.0f;
+                    if (nkI < (1 << 24)) sChain[1] = ff_repeat_add_u24((uint32_t)nkI, D);
+                    else {
+                        float sn = 0.0f;
 #pragma unroll 8
-                    for (int d = 0; d < D; d++) sn += nkf;
-                    sChain[1] = sn;
+                        for (int d = 0; d < D; d++) sn += nkf;
+                        sChain[1] = sn;
+                    }
                 }
                 __syncthreads();
                 if (tid == 0) sEps = sChain[0] / sChain[1];
@@ -1663,9 +1674,12 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                 if (lane == 0 && acc != 0) atomicAdd(&s_tot2, (unsigned long long)acc);
                 __syncthreads();
                 const long long tot2 = (long long)s_tot2, cap = 1ll << 24;
-                if (tot2 <= cap && (long long)nkf * (long long)D <= cap) {
+                if (tot2 <= cap && nkf < 16777216.0f) {
+                    // (the N_KD chain in closed form: exact while N_K * D <= 2^24, then one division per binade)
                     seq = false;
-                    dk = (0.5f * (float)tot2) / (nkf * (float)D);
+                    if (tid == 0) s_sn = ff_repeat_add_u24((uint32_t)nkf, D);
+                    __syncthreads();
+                    dk = (0.5f * (float)tot2) / s_sn;
                 }
             }
             if (seq) {
@@ -1676,7 +1690,7 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                 __syncthreads();
                 NEM_PHASE(9);
                 if (tid == 64) {
-                    s_sn = ff_repeat_add(nkf, D);
+                    s_sn = (a.mode == 1 && nkf < 16777216.0f) ? ff_repeat_add_u24((uint32_t)nkf, D) : ff_repeat_add(nkf, D);
 #ifdef NEM_PHASE_PROF
                     if (blockIdx.x == 0) g_phase[12] = wall_clock64();
 #endif

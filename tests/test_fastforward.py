@@ -209,3 +209,19 @@ def test_repeated_add_closed_form_equals_the_loop():
     for x in (-1.0, -0.3, float("inf")):                                         # no closed form: the loop itself
         assert f(x, 300, 0) == f(x, 300, 1)
     assert np.isnan(f(float("nan"), 9, 1))
+
+
+def test_repeated_add_integer_form_equals_the_loop():
+    """ff_repeat_add_u24: the same chain for an integer class size, in integer arithmetic (what the kernels call)."""
+    lib = load_library()
+    f = lib.nemgpu_repeat_add_host
+    f.restype = ctypes.c_float
+    f.argtypes = [ctypes.c_float, ctypes.c_longlong, ctypes.c_int]
+    rng = np.random.Generator(np.random.PCG64(5))
+    xs = [1, 2, 3, 5, 7, 16777215, 16777214, 8388608, 8388607, 8388609, 9000000, 6000000, 66667, 16777, 16778, 33333,
+          100000, 3355443, 4194304, 5592405]
+    xs += list(rng.integers(1, 1 << 24, 150)) + list(rng.integers(1, 70000, 150))
+    for x in xs:
+        for times in (0, 1, 2, 3, 4, 5, 17, 500, 1000, 1001, 5000, 5001, 40000):
+            a, b = f(float(x), times, 0), f(float(x), times, 2)
+            assert np.float32(a).tobytes() == np.float32(b).tobytes(), (x, times, a, b)
