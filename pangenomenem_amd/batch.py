@@ -15,7 +15,11 @@ the density kernel, launch-bound everywhere else), so the native way to run chun
 """
 from concurrent.futures import ThreadPoolExecutor
 
-from .engine import solve_many as _solve_many
+import ctypes as C
+
+import numpy as np
+
+from .engine import (ALGO, CVT, DISP, PROP, STATUS_OK, TIE, Config, NemGpuError, Problem, load_library)
 from .nem import nem
 
 
@@ -25,9 +29,56 @@ def nem_many(calls, workers=8):
         return list(pool.map(lambda kw: nem(**kw), calls))
 
 
-def solve_many(problems, workers=8, group=32, device=0, **cfg):
+def solve_many(problems, workers=8, group=32, device=0, algo="ncem", beta=0.5, disper="sk_", propor="pk", cvtest="clas",
+               cvthres=1e-8, it_max=100, param_fix=False, tie="hash", seed=0):
     """problems = [(x, nei, k, prop, center, disp), ...]; returns their solve() results, each bit-identical to the
     problem solved alone.  ONE library call (nemgpu_solve_many, include/nem_mi355x.h): `workers` threads of the library
     build the engines (bit packing, uploads) and fetch the results, every `group` of problems runs in lock step, and
-    while one group runs the next ones are being built."""
-    return _solve_many(problems, workers=workers, group=group, device=device, **cfg)
+    while one group runs the next ones are being built.  x: uint8 [n][d] of 0/1, or uint32 bit rows [n][ceil(d/32)]
+    (then d is taken from the shape of `center`)."""
+    if not problems:
+        return []
+    lib = load_library()
+    cfg = Config(ALGO[algo], beta, DISP[disper], PROP[propor], CVT[cvtest], cvthres, it_max, int(param_fix), TIE[tie], seed)
+    arr = (Problem * len(problems))()
+    keep, outs = [], []
+    addr = lambda a: a.ctypes.data
+    for q, (x, nei, k, prop, center, disp) in zip(arr, problems):
+        bits = x.dtype == np.uint32
+        x = np.ascontiguousarray(x, np.uint32 if bits else np.uint8)
+        n = x.shape[0]
+        d = np.asarray(center).size // int(k) if bits else x.shape[1]
+        prop = np.ascontiguousarray(prop, np.float32)
+        center = np.ascontiguousarray(center, np.float32).reshape(k, d)
+        disp = np.ascontiguousarray(disp, np.float32).reshape(k, d)
+        q.n, q.d, q.k = n, d, int(k)
+        if bits:
+            assert x.shape == (n, (d + 31) // 32)
+            q.x_bits = addr(x)
+        else:
+            q.x_bytes = addr(x)
+        keep += [x, prop, center, disp]
+        if nei is not None:
+            ptr, idx, w = (np.ascontiguousarray(nei[0], np.int32), np.ascontiguousarray(nei[1], np.int32),
+                           np.ascontiguousarray(nei[2], np.float32))
+            assert ptr.shape == (n + 1,)
+            q.nei_ptr, q.nei_idx, q.nei_w = addr(ptr), addr(idx), addr(w)
+            keep += [ptr, idx, w]
+        q.prop, q.center, q.disp = addr(prop), addr(center), addr(disp)
+        o = dict(prop=np.zeros(k, np.float32), center=np.zeros((k, d), np.float32), disp=np.zeros((k, d), np.float32),
+                 nbobs_k=np.zeros(k, np.float32), c=np.zeros((n, k), np.float32))
+        q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c = (addr(o[f]) for f in ("prop", "center", "disp", "nbobs_k", "c"))
+        outs.append(o)
+    rc = lib.nemgpu_solve_many(arr, len(problems), C.byref(cfg), int(device), int(workers), int(group))
+    if rc not in (STATUS_OK,):
+        raise NemGpuError("nemgpu_solve_many failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
+    res = []
+    for q, o in zip(arr, outs):
+        r = q.result
+        meta = dict(status=r.status, iters=r.iters, converged=bool(r.converged), emptyk=r.emptyk,
+                    n_zero_density=r.zero_density_sites, first_zero_density_site=r.first_zero_density_site,
+                    sweep_rounds=r.sweep_rounds, crit=np.array(list(r.crit), np.float32),
+                    loop_seconds=r.loop_seconds, tie_draws=r.tie_draws)
+        meta.update(o)
+        res.append(meta)
+    return res
