@@ -53,6 +53,27 @@ def test_solve_many_groups_bit_rows_and_problems_without_a_graph(gpu_lib):
                 assert np.array_equal(got[f], w[f]), f
 
 
+def test_pooled_resources_and_captured_batches_are_reused_without_changing_results(gpu_lib):
+    """Streams, device / pinned blocks and the lock-step contexts (slabs + captured graphs) of destroyed engines go to
+    a per-device pool: later groups of the same shape replay the graphs earlier ones captured.  Same answers on every
+    pass, also after the pool has been emptied."""
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import load_library
+    nei = synth.contiguity_graph(4000, 5)
+    prop, center, disp = synth.default_init(96)
+    probs = [(synth.ushaped_pa_matrix(4000, 96, 5 + p)[0], nei, 3, prop, center, disp) for p in range(24)]
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", tie="hash", seed=2)
+    first = solve_many(probs, workers=4, group=6, **cfg)           # 4 groups of one shape: plain, captured, replayed
+    again = solve_many(probs, workers=4, group=6, **cfg)
+    load_library().nemgpu_release_cached()
+    fresh = solve_many(probs, workers=2, group=6, **cfg)
+    assert len({r["iters"] for r in first}) > 1                      # (members of a group stop at different iterations)
+    for a, b, c in zip(first, again, fresh):
+        assert a["iters"] == b["iters"] == c["iters"]
+        for f in ("c", "prop", "center", "disp", "crit"):
+            assert np.array_equal(a[f], b[f]) and np.array_equal(a[f], c[f]), f
+
+
 def test_solve_many_reports_the_problem_that_is_wrong(gpu_lib):
     from pangenomenem_amd.batch import solve_many
     from pangenomenem_amd.engine import NemGpuError
