@@ -237,7 +237,8 @@ def _run(world, n, d, beta, kind="normal"):
 
 
 @pytest.mark.parametrize("world,n,d,beta", [(2, 2048, 15, 0.5), (3, 1000, 24, 1.0), (2, 1501, 15, 0.0),
-                                            (3, 7, 5, 0.5), (2, 1025, 33, 2.5), (3, 301, 20, 0.0)])
+                                            (3, 7, 5, 0.5), (2, 1025, 33, 2.5), (3, 301, 20, 0.0),
+                                            (4, 2048, 15, 0.5), (8, 4001, 20, 0.5)])   # (8: the driver's largest launch)
 def test_sharded_em_equals_single_process_oracle(oracle, world, n, d, beta):
     from pangenomenem_amd import synth
     outs = _run(world, n, d, beta)
