@@ -143,8 +143,8 @@ struct nemgpu_engine {
     bool flags_clean = false;     // MOVED + round window are zero (set by k_density, consumed by a sweep)
 
     // captured batches of the pipelined loop, keyed by (current buffer, iterations in the batch)
-    hipGraphExec_t graphs[2][3][8] = {};   // [with initial sweeps][current buffer][iterations]
-    uint8_t graph_asked[2][3][8] = {};   // how often a batch shape was enqueued before it got a graph
+    hipGraphExec_t graphs[2][3][8][8] = {};   // [with initial sweeps][current buffer][iterations][leading iterations with one round more]
+    uint8_t graph_asked[2][3][8][8] = {};   // how often a batch shape was enqueued before it got a graph
     bool use_graphs = true;
     // relaxation rounds enqueued per sweep before anybody looks (round 0, its verification, and one more that costs
     // an early-exit launch when it is not needed and a host round trip when it is missing); NEM_MI355X_ROUNDS=2..4
@@ -153,7 +153,12 @@ struct nemgpu_engine {
     // then every later one gets round_batch.  (Labels are sticky: on the bench's pre-convergence data only the sweep
     // that starts from the blind partition needs a third round; an early-exit launch per iteration costs 2.5 us.)
     int rounds_iter = 2;
-    int rounds_enqueued = 2;             // ... what the iterations of the batch in flight were given
+    // ... but not all iterations are alike: the first ones after a start move many labels and tend to need the
+    // extra round, the later ones almost never do.  The first deep_iters iterations of a run get round_batch rounds;
+    // an iteration further on whose sweep the host had to finish moves the mark (it is kept across restarts: the
+    // bench and PPanGGOLiN's repeated solves of similar problems find the same pattern every time).
+    int deep_iters = 2;
+    int run_deep_used = 0; bool run_tracked = false;   // this run: the last iteration that used the extra round
     bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
     int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
     int ff_mode = -1;                    // density: binade fast-forward of the uniform chain (nem_ff.hpp): 0 off, 1 on, -1 auto
@@ -831,7 +836,7 @@ int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id, int launc
 // enqueue one whole iteration whose current partition is buffer `cur`.  defer_ctrl: another iteration follows in
 // the same batch -- an NCEM iteration's loop control then runs in that iteration's counts launch (k_mstep_counts)
 // instead of in a last-block ticket at the tail of the last sweep round.
-int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_ctrl)
+int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_ctrl, bool deep)
 {
     int r;
     const int saved = e->cur;
@@ -871,8 +876,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     CtrlArgs ca{};
     // (members of a lock-step batch all take the same number of rounds: a member with a sequence of its own would
     //  need launches of its own)
-    const int it_rounds = current_recorder() != nullptr ? e->round_batch : e->rounds_iter;
-    e->rounds_enqueued = it_rounds;
+    const int it_rounds = (current_recorder() != nullptr || deep) ? e->round_batch : e->rounds_iter;
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = it_rounds;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
@@ -965,6 +969,7 @@ struct LoopCursor {
     bool first = false;           // the next batch starts with the restart + the two initial sweeps
     // the batch in flight
     int g = 0, base = 0; uint32_t sweep0 = 0; bool batch_first = false;
+    int deep = 0;                 // leading iterations of the batch that get round_batch relaxation rounds
     bool active() const { return remaining > 0 || first; }
 };
 
@@ -979,6 +984,7 @@ int loop_begin(nemgpu_engine* e, LoopCursor& lc, int n_iters, bool with_init)
         if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
         if ((r = ensure_state_buffers(e))) return r;
         e->reset_pending = false;                          // (the head of the first batch is the device half of a reset)
+        e->run_deep_used = 0; e->run_tracked = true;
         e->cur = 0; e->sweep_counter = 0;
         e->iters = 0; e->converged = 0; e->emptyk = 0; e->status = NEMGPU_OK;
         e->zero_density = 0; e->first_zero = -1; e->sweep_rounds = 0; e->masks_valid = false;
@@ -998,6 +1004,7 @@ int batch_plan(nemgpu_engine* e, LoopCursor& lc)
     lc.batch_first = lc.first;
     lc.base = lc.first ? 2 : e->cur;
     lc.sweep0 = lc.first ? 2u : e->sweep_counter;
+    lc.deep = current_recorder() != nullptr ? lc.g : std::max(0, std::min(lc.g, e->deep_iters - (lc.first ? 0 : e->iters)));
     // class masks of the current labels, fresh tables when the parameters are fixed (otherwise k_finish rebuilds them
     // inside the batch)
     if (!lc.first) {
@@ -1024,7 +1031,7 @@ int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
     e->stop_ptr = e->ctrl() + C_STOP;
     if (lc.batch_first && herr == hipSuccess) r = enqueue_init(e, lc.g > 0);
     for (int j = 0; j < lc.g && r == NEMGPU_OK && herr == hipSuccess; j++)
-        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g);
+        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g, j < lc.deep);
     e->stop_ptr = nullptr;
     if (herr == hipSuccess && r == NEMGPU_OK && with_copy)
         herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream);
@@ -1074,21 +1081,30 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
     e->cur = (base + commits) % 3;
     e->sweep_counter = sweep0 + (uint32_t)done;
     lc.remaining -= done;
+    if (c[C_DEEP] > 0) e->run_deep_used = std::max(e->run_deep_used, e->iters - done + c[C_DEEP]);
+    // a whole run in which the leading iterations did not use their extra round: one of them loses it next time
+    auto run_ends = [&]() {
+        if (e->run_tracked && current_recorder() == nullptr && (e->converged || e->iters >= e->deep_iters) &&
+            e->run_deep_used < e->deep_iters) e->deep_iters--;
+        e->run_tracked = false;
+    };
     if (c[C_STATUS] == NEMGPU_W_EMPTYCLASS) {                  // nem_alg.c:1831-1838
         e->status = NEMGPU_W_EMPTYCLASS;
         e->emptyk = c[C_EMPTYK];
         e->masks_valid = false;                                // the speculative E-step rebuilt them for a discarded partition
+        run_ends();
         return NEMGPU_OK;
     }
-    if (c[C_CONVERGED]) { e->converged = 1; return NEMGPU_OK; }
+    if (c[C_CONVERGED]) { e->converged = 1; run_ends(); return NEMGPU_OK; }
     if (c[C_NEED_ROUNDS]) {
         // iteration #commits of this batch ran its M-step, density and the enqueued relaxation rounds and is
         // not at the fixed point yet: continue its rounds from the host, then redo the bookkeeping.
         const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), e->rounds_enqueued))) return r;
-        if (e->rounds_iter < e->round_batch) { e->rounds_iter = e->round_batch; drop_graphs(e); }   // from now on: one round more
+        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), done - 1 < lc.deep ? e->round_batch : e->rounds_iter))) return r;
+        e->deep_iters = std::max(e->deep_iters, e->iters);          // from now on: one round more up to this iteration of a run
+        e->run_deep_used = std::max(e->run_deep_used, e->iters);
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         int rounds = 0;
         if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
@@ -1102,6 +1118,7 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
             else e->converged = !moved;
         }
     }
+    if (e->converged || lc.remaining <= 0) run_ends();
     return NEMGPU_OK;
 }
 
@@ -1124,10 +1141,11 @@ int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
         const int g = lc.g, base = lc.base;
         const bool first = lc.batch_first;
         bool graphed = e->use_graphs && g < 8;
-        hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g] : nullptr;
+        const int deep = lc.deep;
+        hipGraphExec_t exec = graphed ? e->graphs[first ? 1 : 0][base][g][deep] : nullptr;
         // the first batch of a shape goes out as plain launches: capturing and instantiating a graph costs more than
         // it saves unless the batch is replayed, and a nem() call's engine enqueues most shapes once
-        if (graphed && exec == nullptr && e->graph_asked[first ? 1 : 0][base][g]++ == 0 && !e->capture_first) graphed = false;
+        if (graphed && exec == nullptr && e->graph_asked[first ? 1 : 0][base][g][deep]++ == 0 && !e->capture_first) graphed = false;
         if (exec == nullptr) {
             if (graphed) e->n_captured++; else e->n_plain++;
             if (graphed) HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -1137,7 +1155,7 @@ int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
                 hipError_t cerr = hipStreamEndCapture(e->stream, &graph);
                 if (r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr &&
                     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    e->graphs[first ? 1 : 0][base][g] = exec;
+                    e->graphs[first ? 1 : 0][base][g][deep] = exec;
                 } else {
                     exec = nullptr;
                     e->n_captured--;
@@ -1472,8 +1490,9 @@ void drop_graphs(nemgpu_engine* e)
 {
     for (auto& plane : e->graphs)
         for (auto& row : plane)
-            for (auto& g : row)
-                if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+            for (auto& col : row)
+                for (auto& g : col)
+                    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
 }
 
 int ensure_crit_buffers(nemgpu_engine* e)

@@ -842,6 +842,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     }
     if (last < 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
     c[C_SWEEP_ROUNDS] += last + 1;
+    if (last >= 2) c[C_DEEP] = c[C_ITERS];
     if (f[FLAG_NZERO] > 0) {
         c[C_NZERO] += f[FLAG_NZERO];
         if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];

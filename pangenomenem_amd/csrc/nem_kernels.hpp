@@ -24,7 +24,8 @@ enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 
 // C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
 // zero-density sites" (how the next sweeps tally them, see k_sweep); it survives a restart.
 enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
-       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_WORDS = 16 };
+       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_DEEP = 12, C_WORDS = 16 };
+// C_DEEP: the last iteration of the batch (1-based) whose sweep used more than two of its relaxation rounds
 
 struct CtrlArgs {
     int* ctrl; const int* iter_flags; const int* round0;   // round0: flag slot of relaxation round 0 (round r: r slots on)
