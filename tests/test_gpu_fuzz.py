@@ -83,7 +83,7 @@ def test_random_problem(gpu_lib, oracle, seed):
     assert got["n_zero_density"] == want["n_zero_density"], ctx
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("NEM_FUZZ_LARGE_SEEDS", "10")))))
 def test_random_large_problem(gpu_lib, oracle, seed):
     """Sizes where the other code paths live: sums above 2^24 (sequential dispersion chains in k_finish), long
     chains (fast-forward over many binades), several density tiles per class, 1024-site sweep blocks."""
