@@ -121,10 +121,20 @@ static inline void put_fixed(std::string& out, float v, int width, int dec)
     }
 }
 
+struct LogParams { std::vector<float> prop, center, disp, nk; };
+
+void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known);
+
 void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool sizes_known)
 {
-    std::vector<float> prop(k), center((size_t)k * d), disp((size_t)k * d), nk(k);
-    nemgpu_get_params(e, prop.data(), center.data(), disp.data(), nk.data());
+    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
+    nemgpu_get_params(e, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data());
+    log_classes(fl, P, beta, k, d, sizes_known);
+}
+
+void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known)
+{
+    const std::vector<float>&prop = P.prop, &center = P.center, &disp = P.disp, &nk = P.nk;
     // WriteLogClasses' formats: " %5.3f" beta and proportions, " %7.3f" centres and dispersions, " %7.1f" NbObs_KD
     std::string line;
     line.reserve((size_t)k * d * 3 * 9 + 64);
@@ -163,18 +173,19 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
     log_header(fl, k, d);
     nemgpu_result r1{};
     nemgpu_iterate(e, 0, &r1);                                               // (fills the counters of the start)
+    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
     double loop_s = 0.0;
     for (int iter = 1; iter <= cfg.it_max && !r1.converged && r1.status == NEMGPU_OK; iter++) {
         fprintf(fl, "%4d ", iter);
-        if ((rc = nemgpu_iterate(e, 1, &r1))) return rc;
+        // the iteration, both criteria evaluations and the parameters: one submission, one wait
+        if ((rc = nemgpu_iterate_logged(e, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data()))) return rc;
         loop_s += r1.loop_seconds;
         if (r1.status == NEMGPU_W_EMPTYCLASS) {                             // :1835-1837
             fprintf(fl, " Class %d empty at iteration %d\n", r1.emptyk, iter);
             break;
         }
-        if ((rc = nemgpu_criteria_previous(e, cb)) || (rc = nemgpu_criteria(e, ca))) return rc;
         log_crit(fl, cb, mult); log_crit(fl, ca, mult);
-        log_classes(fl, e, cfg.beta, k, d, !cfg.param_fix);
+        log_classes(fl, P, cfg.beta, k, d, !cfg.param_fix);
     }
     *res = r1;
     res->loop_seconds = loop_s;

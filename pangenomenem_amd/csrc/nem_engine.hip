@@ -2006,6 +2006,74 @@ int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
     return NEMGPU_OK;
 }
 
+// One EM iteration with everything a line of the reference's log needs -- the criteria of the partition the sweep
+// started from and of the new one (WriteLogCrit, nem_alg.c:2361, 2398), the parameters (WriteLogClasses) -- in ONE
+// stream submission and one wait: the two criteria passes and the copies are enqueued behind the iteration before
+// anyone knows how it ended.  An iteration the host has to finish (more relaxation rounds) or a criterion-driven
+// convergence test takes the plain sequence of calls instead.
+int nemgpu_iterate_logged(nemgpu_engine* e, nemgpu_result* res, float crit_before[6], float crit_after[6],
+                          float* prop, float* center, float* disp, float* nbobs_k)
+{
+    if (!e || !crit_before || !crit_after) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    int r;
+    auto plain_tail = [&]() -> int {
+        if (e->status == NEMGPU_W_EMPTYCLASS) return NEMGPU_OK;          // (the E-step did not run: nothing to log)
+        int rr;
+        if ((rr = criteria(e, crit_before, (e->cur + 2) % 3))) return rr;
+        if ((rr = criteria(e, crit_after, -1))) return rr;
+        return nemgpu_get_results(e, prop, center, disp, nbobs_k, nullptr);
+    };
+    bool speculated = false;
+    char* st = nullptr; size_t got = 0;
+    if (!crit_test(e) && e->lo == 0 && e->hi == e->n_total) {
+        LoopCursor lc;
+        if ((r = loop_begin(e, lc, 1, false))) return r;
+        if (loop_wants_batch(e, lc)) {
+            if ((r = batch_plan(e, lc))) return r;
+            const int oldbuf = lc.base, newbuf = (lc.base + 1) % 3;
+            const size_t words = 12 + e->par_words;
+            if (pool_get(e->device, true, words * sizeof(float), &st, &got) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+            e->n_plain++;
+            if ((r = batch_enqueue(e, lc, true))) { if (st) pool_put(e->device, true, st, got); return r; }
+            if (st) {
+                float* f = reinterpret_cast<float*>(st);
+                r = criteria_enqueue(e, oldbuf);
+                if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                if (r == NEMGPU_OK) r = criteria_enqueue(e, newbuf);
+                if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f + 6, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f + 12, e->prop, e->par_words * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                if (r) { (void)hipStreamSynchronize(e->stream); pool_put(e->device, true, st, got); return r; }
+            }
+            HIPCHK(hipStreamSynchronize(e->stream));
+            const bool clean = e->h_ctrl()[C_NEED_ROUNDS] == 0 && e->h_ctrl()[C_STATUS] != NEMGPU_W_EMPTYCLASS;
+            if ((r = batch_finish(e, lc))) { if (st) pool_put(e->device, true, st, got); return r; }
+            speculated = st != nullptr && clean;
+        }
+    } else {
+        if ((r = iterate(e, 1))) return r;
+    }
+    if (speculated) {
+        const float* f = reinterpret_cast<const float*>(st);
+        memcpy(crit_before, f, 6 * sizeof(float));
+        memcpy(crit_after, f + 6, 6 * sizeof(float));
+        const size_t kd = (size_t)e->k * e->d;
+        if (prop) memcpy(prop, f + 12, sizeof(float) * e->k);
+        if (center) memcpy(center, f + 12 + e->par_o_center, sizeof(float) * kd);
+        if (disp) memcpy(disp, f + 12 + e->par_o_disp, sizeof(float) * kd);
+        if (nbobs_k) memcpy(nbobs_k, f + 12 + e->par_o_nb, sizeof(float) * e->k);
+    }
+    if (st) pool_put(e->device, true, st, got);
+    if (!speculated && (r = plain_tail())) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fill_result(e, res);
+    if (res) res->loop_seconds = secs;
+    return NEMGPU_OK;
+}
+
 int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
 {
     // reset + ComputePartitionFromPara(Needinit=1) + up to n_iters EM iterations as ONE pipelined batch sequence
