@@ -184,10 +184,11 @@ int nemgpu_glibc_random(uint32_t seed, int count, int32_t* out);
 int nemgpu_init_partition(nemgpu_engine* e);              /* ComputePartitionFromPara(Needinit=1) */
 int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res);  /* up to n_iters EM iterations */
 int nemgpu_reset(nemgpu_engine* e);                       /* back to the initial parameters, zero partition */
-/* One EM iteration plus what a line of the reference's log needs (the criteria of the partition the sweep started
-   from and of the new one, the parameters), all in one stream submission and one wait (HOST buffers; the parameter
-   pointers may be NULL).  res->loop_seconds covers the criteria as well. */
-int nemgpu_iterate_logged(nemgpu_engine* e, nemgpu_result* res, float crit_before[6], float crit_after[6],
+/* One EM iteration -- or, with_init != 0, the start: reset + the two initial sweeps, no iteration -- plus what a line
+   of the reference's log needs (the criteria of the partition the sweep started from and of the new one, the
+   parameters), all in one stream submission and one wait (HOST buffers; the parameter pointers may be NULL).
+   res->loop_seconds covers the criteria as well. */
+int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, float crit_before[6], float crit_after[6],
                           float* prop, float* center, float* disp, float* nbobs_k);
 int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res);  /* reset + init + n iterations, one pipeline */
 int nemgpu_density(nemgpu_engine* e);                     /* E1 only */

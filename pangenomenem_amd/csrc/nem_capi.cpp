@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <future>
+#include <memory>
 #include <unistd.h>
 #include <string>
 #include <vector>
@@ -73,10 +75,18 @@ float log_mult(int npt)
     return (float)exp(-((int)(log(npt / 1000.) / log(10))) * log(10));      // :1495, :2638
 }
 
+void log_crit(std::string& out, const float crit6[6], float mult)
+{
+    char buf[128];
+    const int m = snprintf(buf, sizeof buf, " %5.0f %5.0f %5.3f", (double)(float)(crit6[2] * mult), (double)(float)(crit6[3] * mult),
+                           (double)std::nanf(""));                           // U, M, error rate (no reference partition)
+    out.append(buf, (size_t)m);
+}
 void log_crit(FILE* fl, const float crit6[6], float mult)
 {
-    fprintf(fl, " %5.0f %5.0f %5.3f", (double)(float)(crit6[2] * mult), (double)(float)(crit6[3] * mult),
-            (double)std::nanf(""));                                          // U, M, error rate (no reference partition)
+    std::string t;
+    log_crit(t, crit6, mult);
+    fwrite(t.data(), 1, t.size(), fl);
 }
 
 void log_header(FILE* fl, int k, int d)
@@ -88,12 +98,27 @@ void log_header(FILE* fl, int k, int d)
     fprintf(fl, " ");
     for (int h = 0; h < k; h++) fprintf(fl, " %3s%02d", "P", h + 1);
     fprintf(fl, " ");
-    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "M", h + 1, j + 1);
-    fprintf(fl, " ");
-    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "D", h + 1, j + 1);
-    fprintf(fl, " ");
-    for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) fprintf(fl, " %3s%02d_%1d", "n", h + 1, j + 1);
-    fprintf(fl, "\n");
+    // 3 K D column names " %3s%02d_%1d": put together by hand (thousands of fprintf calls cost more than the EM loop)
+    std::string line;
+    line.reserve((size_t)3 * k * d * 12 + 16);
+    auto names = [&](char letter) {
+        for (int h = 0; h < k; h++)
+            for (int j = 0; j < d; j++) {
+                char buf[32];
+                int m = 0;
+                buf[m++] = ' '; buf[m++] = ' '; buf[m++] = ' '; buf[m++] = letter;
+                if (h + 1 < 100) { buf[m++] = (char)('0' + (h + 1) / 10); buf[m++] = (char)('0' + (h + 1) % 10); }
+                else m += snprintf(buf + m, sizeof buf - (size_t)m, "%02d", h + 1);
+                buf[m++] = '_';
+                char dg[12];
+                int nd = 0;
+                for (int v = j + 1; v > 0; v /= 10) dg[nd++] = (char)('0' + v % 10);
+                while (nd > 0) buf[m++] = dg[--nd];
+                line.append(buf, (size_t)m);
+            }
+    };
+    names('M'); line += " "; names('D'); line += " "; names('n'); line += "\n";
+    fwrite(line.data(), 1, line.size(), fl);
 }
 
 // " %<width>.<dec>f" of a float, as printf prints it (dec <= 3).  A float times 10^dec is exact in a double (24 + 10
@@ -123,7 +148,13 @@ static inline void put_fixed(std::string& out, float v, int width, int dec)
 
 struct LogParams { std::vector<float> prop, center, disp, nk; };
 
-void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known);
+void log_classes(std::string& line, const LogParams& P, float beta, int k, int d, bool sizes_known);
+void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known)
+{
+    std::string line;
+    log_classes(line, P, beta, k, d, sizes_known);
+    fwrite(line.data(), 1, line.size(), fl);
+}
 
 void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool sizes_known)
 {
@@ -132,12 +163,11 @@ void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool size
     log_classes(fl, P, beta, k, d, sizes_known);
 }
 
-void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known)
+void log_classes(std::string& line, const LogParams& P, float beta, int k, int d, bool sizes_known)
 {
     const std::vector<float>&prop = P.prop, &center = P.center, &disp = P.disp, &nk = P.nk;
     // WriteLogClasses' formats: " %5.3f" beta and proportions, " %7.3f" centres and dispersions, " %7.1f" NbObs_KD
-    std::string line;
-    line.reserve((size_t)k * d * 3 * 9 + 64);
+    line.reserve(line.size() + (size_t)k * d * 3 * 9 + 64);
     line += " ";
     put_fixed(line, beta, 5, 3);
     line += " ";
@@ -150,7 +180,6 @@ void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool si
     // NbObs_KD: zero until the first EstimPara (calloc, nem_exe.c:320), then N_K for every organism (no missing data)
     for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) put_fixed(line, sizes_known ? nk[h] : 0.0f, 7, 1);
     line += "\n";
-    fwrite(line.data(), 1, line.size(), fl);
 }
 
 // The INIT_PARAM_FILE run with the reference's log: one EM iteration per engine call, two criteria evaluations
@@ -164,29 +193,42 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
     fprintf(fl, "%4d ", 0);
     int rc;
     float cb[6], ca[6];
-    if ((rc = nemgpu_reset(e))) return rc;
-    if ((rc = nemgpu_init_partition(e))) return rc;
-    if ((rc = nemgpu_criteria_previous(e, cb)) || (rc = nemgpu_criteria(e, ca))) return rc;
+    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
+    nemgpu_result r1{};
+    // the start (reset, the two initial sweeps), both criteria evaluations and the parameters: one submission, one wait
+    if ((rc = nemgpu_iterate_logged(e, 1, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data()))) return rc;
     log_crit(fl, cb, mult); log_crit(fl, ca, mult);
-    log_classes(fl, e, cfg.beta, k, d, false);
+    log_classes(fl, P, cfg.beta, k, d, false);
     fprintf(fl, "\n");                                                     // Needinit, :1985-1986
     log_header(fl, k, d);
-    nemgpu_result r1{};
-    nemgpu_iterate(e, 0, &r1);                                               // (fills the counters of the start)
-    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
     double loop_s = 0.0;
+    // the line of an iteration (9 000 numbers at configs[1]) is put together by a helper thread while the device runs
+    // the next iteration; the lines reach the file in order
+    std::future<std::string> pending;
+    auto flush_line = [&]() { if (pending.valid()) { const std::string t = pending.get(); fwrite(t.data(), 1, t.size(), fl); } };
     for (int iter = 1; iter <= cfg.it_max && !r1.converged && r1.status == NEMGPU_OK; iter++) {
-        fprintf(fl, "%4d ", iter);
         // the iteration, both criteria evaluations and the parameters: one submission, one wait
-        if ((rc = nemgpu_iterate_logged(e, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data()))) return rc;
+        rc = nemgpu_iterate_logged(e, 0, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data());
+        flush_line();
+        if (rc) return rc;
         loop_s += r1.loop_seconds;
+        fprintf(fl, "%4d ", iter);
         if (r1.status == NEMGPU_W_EMPTYCLASS) {                             // :1835-1837
             fprintf(fl, " Class %d empty at iteration %d\n", r1.emptyk, iter);
             break;
         }
-        log_crit(fl, cb, mult); log_crit(fl, ca, mult);
-        log_classes(fl, P, cfg.beta, k, d, !cfg.param_fix);
+        struct Line { float cb[6], ca[6]; LogParams P; };
+        auto L = std::make_shared<Line>();
+        memcpy(L->cb, cb, sizeof cb); memcpy(L->ca, ca, sizeof ca); L->P = P;
+        const float beta = cfg.beta; const bool sizes = !cfg.param_fix;
+        pending = std::async(std::launch::async, [L, mult, beta, k, d, sizes]() {
+            std::string t;
+            log_crit(t, L->cb, mult); log_crit(t, L->ca, mult);
+            log_classes(t, L->P, beta, k, d, sizes);
+            return t;
+        });
     }
+    flush_line();
     *res = r1;
     res->loop_seconds = loop_s;
     if (r1.iters == 0) {                                                    // :1845-1851

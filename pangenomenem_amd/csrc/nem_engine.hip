@@ -2011,7 +2011,7 @@ int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
 // stream submission and one wait: the two criteria passes and the copies are enqueued behind the iteration before
 // anyone knows how it ended.  An iteration the host has to finish (more relaxation rounds) or a criterion-driven
 // convergence test takes the plain sequence of calls instead.
-int nemgpu_iterate_logged(nemgpu_engine* e, nemgpu_result* res, float crit_before[6], float crit_after[6],
+int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, float crit_before[6], float crit_after[6],
                           float* prop, float* center, float* disp, float* nbobs_k)
 {
     if (!e || !crit_before || !crit_after) return NEMGPU_E_FUNCARG;
@@ -2028,12 +2028,24 @@ int nemgpu_iterate_logged(nemgpu_engine* e, nemgpu_result* res, float crit_befor
     };
     bool speculated = false;
     char* st = nullptr; size_t got = 0;
-    if (!crit_test(e) && e->lo == 0 && e->hi == e->n_total) {
+    if (with_init && (crit_test(e) || e->libc() || !(e->lo == 0 && e->hi == e->n_total))) {
+        // (the start whose two sweeps the host completes one after the other: the plain sequence of calls)
+        if ((r = reset_state(e))) return r;
+        if ((r = init_partition(e))) return r;
+        e->crit_ref = 0.0f;
+        if (e->cfg.cvtest == NEMGPU_CV_CRIT_LOGGED) {              // (what the first iteration's criterion is compared with)
+            float c6[6];
+            if ((r = criteria(e, c6))) return r;
+            e->crit_ref = c6[3];
+        }
+    } else if (!crit_test(e) && e->lo == 0 && e->hi == e->n_total) {
         LoopCursor lc;
-        if ((r = loop_begin(e, lc, 1, false))) return r;
+        if (with_init) e->draws = 0;
+        if ((r = loop_begin(e, lc, with_init ? 0 : 1, with_init != 0))) return r;
         if (loop_wants_batch(e, lc)) {
             if ((r = batch_plan(e, lc))) return r;
-            const int oldbuf = lc.base, newbuf = (lc.base + 1) % 3;
+            // (a start: the blind sweep's partition is in buffer 1, the beta sweep's in 2)
+            const int oldbuf = with_init ? 1 : lc.base, newbuf = with_init ? 2 : (lc.base + 1) % 3;
             const size_t words = 12 + e->par_words;
             if (pool_get(e->device, true, words * sizeof(float), &st, &got) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
             e->n_plain++;
