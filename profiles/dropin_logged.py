@@ -36,9 +36,8 @@ def main():
             dt = time.perf_counter() - t0
             assert rc == 0
             best = dt if best is None else min(best, dt)
-        out[key] = dict(whole_call_ms=best * 1e3,
+        out[key] = dict(whole_call_ms=best * 1e3, log_bytes=os.path.getsize(base + ".log"),
                         phases=[l.strip() for l in open(base + ".stderr").read().splitlines() if "[engine]" in l])
-    out["log_bytes"] = os.path.getsize(base + ".log")
     print(json.dumps(out, indent=1))
 
 
