@@ -74,6 +74,34 @@ def test_pooled_resources_and_captured_batches_are_reused_without_changing_resul
             assert np.array_equal(a[f], b[f]) and np.array_equal(a[f], c[f]), f
 
 
+def test_without_the_resource_pool(gpu_lib, tmp_path):
+    """NEM_MI355X_POOL_MB=0: nothing is kept, every engine allocates and frees for itself -- same answers."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from pangenomenem_amd import synth\n"
+        "from pangenomenem_amd.batch import solve_many\n"
+        "from pangenomenem_amd.engine import solve\n"
+        "nei = synth.contiguity_graph(1500, 3)\n"
+        "prop, center, disp = synth.default_init(70)\n"
+        "probs = [(synth.ushaped_pa_matrix(1500, 70, 40 + p)[0], nei, 3, prop, center, disp) for p in range(6)]\n"
+        "cfg = dict(algo='ncem', beta=0.5, disper='sk_', tie='hash', seed=1)\n"
+        "a = solve_many(probs, workers=3, group=2, **cfg)\n"
+        "b = [solve(*p, **cfg) for p in probs]\n"
+        "assert all(np.array_equal(x['c'], y['c']) and x['iters'] == y['iters'] for x, y in zip(a, b))\n"
+        "print('ok', sum(x['iters'] for x in a))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mb in ("0", "8192"):
+        env = dict(os.environ, NEM_MI355X_POOL_MB=mb, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and outs[0].startswith("ok")
+
+
 def test_solve_many_reports_the_problem_that_is_wrong(gpu_lib):
     from pangenomenem_amd.batch import solve_many
     from pangenomenem_amd.engine import NemGpuError
