@@ -297,6 +297,25 @@ void pool_put(int device, bool pinned, char* ptr, size_t size)
 }
 void release_staging(nemgpu_engine* e);
 void zip_context_release(nemgpu_engine* lead);
+// a non-blocking stream from the device's pool (creating one costs ~6 ms on this stack, destroying one ~2 ms)
+hipError_t pool_stream_get(int device, hipStream_t* out)
+{
+    *out = nullptr;
+    if (device >= 0 && device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[device].m);
+        if (!g_pools[device].streams.empty()) { *out = g_pools[device].streams.back(); g_pools[device].streams.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void pool_stream_put(int device, hipStream_t s)             // (idle)
+{
+    if (!s) return;
+    if (device >= 0 && device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[device].m);
+        if (g_pools[device].streams.size() < kPoolStreams) { g_pools[device].streams.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
 constexpr size_t kStageMax = (size_t)64 << 20;          // larger uploads take the blocking path from the caller's memory
 // a pinned block the engine owns until its next release_staging() -- the source of an asynchronous upload
 char* stage(nemgpu_engine* e, size_t bytes)
@@ -1320,7 +1339,10 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
         HIPCHK(hipGraphLaunch(slot->exec, lead->stream));
         return NEMGPU_OK;
     }
-    const bool capture = slot != nullptr && (slot->asked++ > 0 || lead->capture_first);
+    // Capturing and instantiating costs ~160 us per node (8 ms for a batch of 7 iterations) and a replay saves
+    // 0.15-0.35 ms of issue time: a shape pays for its graph after some thirty replays.  The contexts live as long as
+    // the process (a pangenome's chunks are hundreds of batches of one shape), so: from the fourth sighting on.
+    const bool capture = slot != nullptr && (slot->asked++ >= 3 || lead->capture_first);
     if (capture) {
         HIPCHK(hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
         r = issue();
@@ -1653,11 +1675,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
     else {
-        if (device < kPoolDevices) {
-            std::lock_guard<std::mutex> lock(g_pools[device].m);
-            if (!g_pools[device].streams.empty()) { e->stream = g_pools[device].streams.back(); g_pools[device].streams.pop_back(); }
-        }
-        if (!e->stream && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+        if (pool_stream_get(device, &e->stream) != hipSuccess) { delete e; set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
         e->own_stream = true;
     }
     int r = NEMGPU_OK;
@@ -1699,14 +1717,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     for (const nemgpu_engine::Chunk& c : e->chunks) if (c.owned) pool_put(e->device, false, c.base, c.size);
     zip_context_release(e);
     if (e->flags_host && !e->flags_host_borrowed) pool_put(e->device, true, (char*)e->flags_host, e->flags_host_size);
-    if (e->own_stream && e->stream) {
-        bool kept = false;
-        if (e->device >= 0 && e->device < kPoolDevices) {
-            std::lock_guard<std::mutex> lock(g_pools[e->device].m);
-            if (g_pools[e->device].streams.size() < kPoolStreams) { g_pools[e->device].streams.push_back(e->stream); kept = true; }
-        }
-        if (!kept) (void)hipStreamDestroy(e->stream);
-    }
+    if (e->own_stream && e->stream) pool_stream_put(e->device, e->stream);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -2170,10 +2181,17 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     int build_next = 0, build_limit = std::min(count, 2 * group), fetched = 0;
     bool quit = false;
 
-    auto build = [&](int i) {
+    // Streams are the expensive resource of this stack (6 ms to create one): the engines a worker builds share that
+    // worker's stream, the lock-step runs have one of their own, so that a group's run and the next groups' uploads
+    // are not ordered behind each other.
+    std::vector<hipStream_t> wstream((size_t)workers, nullptr);
+    hipStream_t rstream = nullptr;
+    (void)hipSetDevice(device);
+    if (pool_stream_get(device, &rstream) != hipSuccess) { set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+    auto build = [&](int i, hipStream_t st) {
         nemgpu_problem& q = P[i];
         nemgpu_engine* e = nullptr;
-        int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, nullptr);
+        int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, st);
         if (r == NEMGPU_OK) r = q.x_bits ? nemgpu_set_matrix_bits(e, q.x_bits) : nemgpu_set_matrix_bytes(e, q.x_bytes);
         if (r == NEMGPU_OK) {
             if (q.nei_ptr) r = nemgpu_set_graph(e, q.nei_ptr, q.nei_idx, q.nei_w);
@@ -2196,8 +2214,9 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
         nemgpu_destroy(e);
         eng[(size_t)i] = nullptr;
     };
-    auto worker = [&]() {
+    auto worker = [&](int w) {
         (void)hipSetDevice(device);
+        (void)pool_stream_get(device, &wstream[(size_t)w]);        // (nullptr: the engines take streams of their own)
         std::unique_lock<std::mutex> lock(m);
         for (;;) {
             cv.wait(lock, [&] { return quit || !fetchq.empty() || build_next < build_limit; });
@@ -2208,14 +2227,14 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
                 cv.notify_all();
             } else if (build_next < build_limit) {
                 const int i = build_next++;
-                lock.unlock(); build(i); lock.lock();
+                lock.unlock(); build(i, wstream[(size_t)w]); lock.lock();
                 built[(size_t)(i / group)]++;
                 cv.notify_all();
             } else if (quit) return;
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < workers; t++) pool.emplace_back(worker);
+    for (int t = 0; t < workers; t++) pool.emplace_back(worker, t);
     int rc = NEMGPU_OK;
     std::string first_err;
     const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
@@ -2237,7 +2256,14 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
             std::vector<nemgpu_result> R(E.size());
             (void)hipSetDevice(device);
             const auto t0 = now();
-            const int r = run_many(E, R.data());
+            // (the lead's own stream is a worker's: what it still has to upload is waited for, then the run moves)
+            hipStream_t lead_own = E[0]->stream;
+            int r = hipStreamSynchronize(lead_own) == hipSuccess ? NEMGPU_OK : NEMGPU_E_DEVICE;
+            if (r == NEMGPU_OK) {
+                if (!E[0]->own_stream) E[0]->stream = rstream;
+                r = run_many(E, R.data());
+                if (!E[0]->own_stream) { (void)hipStreamSynchronize(rstream); E[0]->stream = lead_own; }
+            }
             t_run += since(t0);
             for (size_t j = 0; j < E.size(); j++) { P[who[j]].result = R[j]; if (r != NEMGPU_OK) P[who[j]].rc = r; }
             if (r != NEMGPU_OK && rc == NEMGPU_OK) { rc = r; first_err = g_last_error; }
@@ -2264,6 +2290,9 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
                         "waited for the last results %.2f ms\n", count, workers, group, t_wait * 1e3, t_run * 1e3, t_tail * 1e3);
     cv.notify_all();
     for (std::thread& t : pool) t.join();
+    for (hipStream_t st : wstream) if (st) { (void)hipStreamSynchronize(st); pool_stream_put(device, st); }
+    (void)hipStreamSynchronize(rstream);
+    pool_stream_put(device, rstream);
     for (int i = 0; i < count; i++)
         if (P[i].rc != NEMGPU_OK && rc == NEMGPU_OK) { rc = P[i].rc; first_err = errs[(size_t)i]; }
     if (rc != NEMGPU_OK && !first_err.empty()) set_error(first_err);

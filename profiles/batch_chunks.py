@@ -44,7 +44,11 @@ def main():
     nem_many(calls[:1], 1)
     assert open(calls[0]["Fname"].decode() + ".uf", "rb").read() == ref_uf          # same answer alone and in a crowd
     solo = solve_many(problems[:1], 1, algo="ncem", beta=0.5, disper="sk_")[0]
+    t0 = time.perf_counter()
     solve_many(problems, 8, algo="ncem", beta=0.5, disper="sk_")                        # (fills the library's pools)
+    dt = time.perf_counter() - t0
+    out["in_memory_first_call"] = dict(workers=8, seconds=dt, problems_per_s=P / dt,
+                                       note="the first job of the process: empty resource pool, no captured batch")
     d = cfg["x"].shape[1]
     pad = (-((d + 7) // 8)) % 4
     as_bits = [(np.ascontiguousarray(np.pad(np.packbits(p[0], axis=1, bitorder="little"), ((0, 0), (0, pad))).view(np.uint32)),)
