@@ -96,7 +96,8 @@ struct nemgpu_engine {
     int *fz_lastz = nullptr, *fz_any1 = nullptr;
     float *fz_in0 = nullptr, *fz_in1 = nullptr, *fz_inh = nullptr;
     float* fz_ct = nullptr;       // class-major copy of the memberships, [k][npad] (the wave-per-chain M-step)
-    bool fuzzy_chains = true;     // NEM_MI355X_FUZZY_CHAINS=0: the one-lane-per-chain kernels
+    float* fz_chk = nullptr;      // the zeros' chains every 64 families, [k][ceil(n/64) + 1][64 ceil(d/64)] (producer/consumer M-step)
+    int fuzzy_chains = 2;         // NEM_MI355X_FUZZY_CHAINS: 2 producer/consumer (lane per chain, adds only), 1 wave per chain, 0 lane per chain as in round 1
     double2* tabT = nullptr;
     double* tabL0 = nullptr;
     uint32_t *nz0 = nullptr, *nz1 = nullptr, *am0 = nullptr, *am1 = nullptr;
@@ -482,6 +483,7 @@ int ensure_state_buffers(nemgpu_engine* e)
             if ((r = dev_alloc(&e->fz_lastz, kd))) return r;
             if ((r = dev_alloc(&e->fz_any1, kd))) return r;
             if ((r = dev_alloc(&e->fz_ct, (size_t)e->k * ((size_t)(e->n + 1023) / 1024 * 1024)))) return r;   // [k][n up to whole 1024-family windows]
+            if ((r = dev_alloc(&e->fz_chk, (size_t)e->k * ((size_t)(e->n + 63) / 64 + 1) * ((size_t)(e->d + 63) / 64 * 64)))) return r;
         }
     }
     return NEMGPU_OK;
@@ -762,7 +764,8 @@ int do_mstep(nemgpu_engine* e, const CtrlArgs* prev_ctrl = nullptr)
     } else {
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, e->cbuf[e->cur] + (size_t)e->lo * e->k,
                            e->fuzzy_chains ? e->fz_ct : nullptr, e->nbobs_k,
-                           e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream);
+                           e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream,
+                           e->fuzzy_chains == 2 ? e->fz_chk : nullptr);
         launch_finish(finish_args(e, 2, nullptr), e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -1670,7 +1673,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_ROUNDS_ITER")) e->rounds_iter = std::max(2, std::min(e->round_batch, atoi(g)));
     e->rounds_iter = std::min(e->rounds_iter, e->round_batch);
-    if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = (g[0] != '0');
+    if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = std::max(0, std::min(2, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
@@ -2420,7 +2423,8 @@ static int make_clone(nemgpu_engine* p, nemgpu_engine** out, char* slab, size_t 
     c->cfg = p->cfg; c->have_matrix = true; c->have_params = true; c->has_graph = p->has_graph;
     c->xw = p->xw; c->xws = p->xws; c->perm = p->perm; c->xt = p->xt; c->use_sort = p->use_sort;
     c->nei_ptr = p->nei_ptr; c->nei_idx = p->nei_idx; c->nei_w = p->nei_w; c->nnz = p->nnz;
-    c->use_graphs = p->use_graphs; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch; c->rounds_iter = p->rounds_iter;   // (graphs: the zipped sequences')
+    c->use_graphs = p->use_graphs; c->ff_mode = p->ff_mode; c->round_batch = p->round_batch; c->rounds_iter = p->rounds_iter;
+    c->fuzzy_chains = p->fuzzy_chains;   // (graphs: the zipped sequences')
     c->parent = p; c->carve_all = true;
     c->chunks.push_back({slab, slab_bytes, 0, false});
     c->shared_chunk = 0;

@@ -2338,6 +2338,284 @@ __device__ __forceinline__ void transpose_c_body(int n, int ctpad, int K, const 
     for (int k = 0; k < K; k++) ct[(size_t)k * ctpad + i] = i < n ? c[(size_t)i * K + k] : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------
+// The fuzzy sums with one LANE per chain again, at the chain's own speed.  A chain is N dependent float adds on one
+// lane: ~10 cycles each whatever else the wave does -- 96 us for 20 000 families -- and the round-1 kernels spent
+// three instructions per family on it (bit -> mask, and, add) at a lone wave's one instruction per ~8 cycles.  Here
+// the lane that owns the chain does the adds and nothing else: eight PRODUCER waves of the block (on all the CU's
+// SIMDs) turn the next 64 families into the addends -- c_ik where the organism's bit says so, +0 elsewhere; adding
+// +0 leaves a sum that is >= +0 as it is -- and hand them over through LDS, 64 organisms x 256 families per hand-over,
+// double-buffered, one barrier per hand-over; the CONSUMER wave reads its lanes' rows sixteen bytes at a time and adds
+// in family order: 1.25 instructions per family.  The zeros' chains leave their value every 64 families (`chk`):
+// ComputeMedian's prefix scan over the zeros IS that chain, so the median kernel looks up the window in which a
+// chain reached N_k / 2 and walks those 64 families again instead of all of them.  The two order-free facts of the
+// tie rule (last zero / some one of weight >= EPSILON) ride with the producers.
+// roles along blockIdx.x: [0, DB) the ones, [DB, 2 DB) the zeros, 2 DB: N_k, 2 DB + 1: inertia for mu = 1/2
+// ------------------------------------------------------------------------------------------
+constexpr int kPcWaves = 10;                            // a consumer wave, eight producer waves and an idle one per block (see below)
+constexpr int kPcStride = 260;                           // floats per organism row of a hand-over (256 + 4: rows stay 16-byte aligned)
+
+struct PcIn { uint32_t lo, hi; float c; };
+
+template <int J0, int J1>
+__device__ __forceinline__ void pc_produce(float* __restrict__ rowA, const PcIn& in)
+{
+    // addends of families J0 .. J1-1 of the window for this lane's organism
+#pragma unroll
+    for (int j = J0; j < J1; j += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = j + u;
+            const int cj = __builtin_amdgcn_readlane(__float_as_int(in.c), jj);            // c of family jj: wave-uniform
+            const int m = __builtin_amdgcn_sbfe((int)(jj < 32 ? in.lo : in.hi), jj & 31, 1);  // all ones where the bit is set
+            v[u] = __int_as_float(cj & m);
+        }
+        *reinterpret_cast<float4*>(rowA + j) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
+{
+    if (a.stop != nullptr && *a.stop) return;
+    const int n = a.n, D = a.D;
+    const int DB = (D + 63) >> 6;
+    const int k = blockIdx.y;
+    const int role = (int)blockIdx.x < 2 * DB ? (int)blockIdx.x / DB : 2 + (int)blockIdx.x - 2 * DB;
+    const int bx = role < 2 ? (int)blockIdx.x - role * DB : 0;
+    // The block's waves go to the CU's four SIMDs in turn (0 4 8 | 1 5 9 | 2 6 | 3 7): the consumer's chain is a string
+    // of dependent adds, and every instruction another wave issues on its SIMD can hold the next add back a few cycles.
+    // So the consumer is hardware wave 2 and hardware wave 6, its only SIMD mate, does nothing but meet the barriers;
+    // wv: 0 the consumer, 1..8 the producers, 9 the idle wave.
+    const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;
+    const int wv = hw == 2 ? 0 : hw == 6 ? 9 : hw < 2 ? hw + 1 : hw < 6 ? hw : hw - 1;   // hw 0 1 3 4 5 7 8 9 -> 1 .. 8
+    const int nwin = (n + 63) >> 6;
+    const int d = bx * 64 + lane;
+    const float* __restrict__ ctk = a.ct + (size_t)k * a.ctpad;
+    const uint64_t* __restrict__ row = a.xt + (size_t)min(d, D - 1) * a.nw64;
+    const uint32_t flip = role == 1 ? ~0u : 0u;          // role 1 sums over the zeros
+    __shared__ float4 sA4[2][64 * kPcStride / 4];
+    auto fetch = [&](int w) -> PcIn {                    // window w as a producer lane sees it (zeros past the end)
+        PcIn r{0u, 0u, 0.0f};
+        if (w < nwin) {
+            const uint64_t own = row[w];
+            r.lo = (uint32_t)own ^ flip; r.hi = (uint32_t)(own >> 32) ^ flip;
+            const int i = 64 * w + lane;
+            r.c = i < n ? ctk[i] : 0.0f;
+        }
+        return r;
+    };
+    if (role >= 2) {
+        // ---- N_k (nem_mod.c:1308: every membership) and the inertia for mu = 1/2 (:1683 with |x - 0.5| = 0.5:
+        // inh = (float)((double)inh + (double)c * 0.5) -- the float sum inh + c/2 whenever c/2 is a float, i.e. always
+        // but for an odd subnormal c).  One chain per class: the consumer wave alone, 256 memberships per step (one
+        // 16-byte load per lane, requested a step ahead), through LDS to every lane, added in family order.
+        if (wv != 0) return;
+        float acc = 0.0f;
+        const int nstep = (n + 255) >> 8;                // (ct is zero from n up to its padded length, a multiple of 256)
+        const float4* __restrict__ c4 = reinterpret_cast<const float4*>(ctk);
+        __shared__ float4 sC4[2][64];
+        float4 cur4 = nstep > 0 ? c4[lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int H = 0; H < nstep; H++) {
+            const float4 nxt4 = H + 1 < nstep ? c4[64 * (H + 1) + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const int cnt = min(256, n - 256 * H);
+            bool plain = true;
+            float4 put = cur4;
+            if (role == 3) {
+                // (c/2 is not a float only for an odd subnormal c, less than 2^-127: against a sum of 2^-100 or more
+                //  -- spacing 2^-123 at least -- it is below an eighth of the spacing, the double form returns the
+                //  sum unchanged, and so does the float add of the rounded half: the double form matters only while
+                //  the sum itself is tiny)
+                const float4 hv = make_float4(cur4.x * 0.5f, cur4.y * 0.5f, cur4.z * 0.5f, cur4.w * 0.5f);
+                const bool odd = hv.x * 2.0f != cur4.x || hv.y * 2.0f != cur4.y || hv.z * 2.0f != cur4.z || hv.w * 2.0f != cur4.w;
+                plain = acc >= 0x1p-100f || __ballot(odd) == 0;           // (the padding is zeros: never odd)
+                if (plain) put = hv;
+            }
+            sC4[H & 1][lane] = put;
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // (lgkmcnt(0): one wave writes and reads its own LDS lines)
+            __builtin_amdgcn_wave_barrier();
+            if (plain) {
+#pragma unroll 16
+                for (int q = 0; q < 64; q++) {
+                    const float4 v = sC4[H & 1][q];
+                    acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+                }
+            } else {
+                const float* sCf = reinterpret_cast<const float*>(sC4[H & 1]);
+                for (int j = 0; j < cnt; j++) acc = (float)((double)acc + (double)sCf[j] * 0.5);
+            }
+            cur4 = nxt4;
+        }
+        if (lane == 0) (role == 2 ? a.nbobs_k : a.inh_k)[k] = acc;
+        return;
+    }
+    // ---- the ones' / the zeros' chains of 64 organisms.  A hand-over is 256 families (four 64-family sub-windows):
+    // a barrier of the block's nine waves costs ~0.3 us, as much as a sub-window's work.  Producer wave p makes
+    // families [32 h, 32 h + 32) of sub-window s, (s, h) = ((p - 1) / 2, (p - 1) % 2): one word of bits and one vector
+    // of memberships per hand-over, requested a hand-over ahead.
+    const int DW = DB * 64;
+    float* __restrict__ chk = (role == 1 && a.chk != nullptr) ? a.chk + (size_t)k * (nwin + 1) * DW + d : nullptr;
+    float acc = 0.0f;
+    int last = -1; int some = 0;                         // (producers with h = 0: the tie rule's two facts of their sub-windows)
+    const bool prod = wv >= 1 && wv <= 8;
+    const int ps = prod ? (wv - 1) >> 1 : 0, ph = prod ? (wv - 1) & 1 : 0;
+    const int nhand = (nwin + 3) >> 2;
+    auto produce = [&](int buf, int w, const PcIn& in) {  // sub-window w of the families, into hand-over buffer buf
+        if (w >= nwin) return;                           // (nothing there: the consumer does not read it)
+        float* rowA = reinterpret_cast<float*>(sA4[buf]) + lane * kPcStride + 64 * ps;
+        if (ph == 0) {
+            // last zero of weight >= EPSILON / some one of such weight (nem_mod.c:1470-1483): order-free, from the
+            // sub-window's 64 weights against the lane's own bits (held flipped in the zeros' role)
+            const int cnt = min(64, n - 64 * w);
+            const uint64_t big = __ballot(lane < cnt && !((double)in.c < kEpsilonD));
+            const uint64_t sel = (((uint64_t)in.hi << 32) | in.lo) & big;  // zeros' role: the zeros; ones' role: the ones
+            if (role == 1) { if (sel != 0) last = 64 * w + 63 - __clzll((long long)sel); }
+            else some |= (sel != 0);
+            pc_produce<0, 32>(rowA, in);
+        } else pc_produce<32, 64>(rowA, in);
+    };
+    PcIn cur = prod ? fetch(ps) : PcIn{0u, 0u, 0.0f};
+    PcIn nxt = prod ? fetch(4 + ps) : PcIn{0u, 0u, 0.0f};
+    if (prod) { produce(0, ps, cur); cur = nxt; }
+    __syncthreads();
+#ifdef NEM_PHASE_PROF
+    unsigned long long t_work = 0, t_begin = wall_clock64();
+#endif
+    for (int H = 0; H < nhand; H++) {
+#ifdef NEM_PHASE_PROF
+        const unsigned long long t_a = wall_clock64();
+#endif
+        if (wv == 0) {
+            // two register sets: the next sub-window's 64 addends are read from LDS while this one's are added
+            const float4* r4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sA4[H & 1]) + lane * kPcStride);
+            float4 vA[16], vB[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) vA[q] = r4[q];
+#pragma unroll
+            for (int sw = 0; sw < 4; sw++) {
+                const int g = 4 * H + sw;
+                if (g < nwin) {
+                    if (chk != nullptr) chk[(size_t)g * DW] = acc;
+                    if (sw < 3 && g + 1 < nwin) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) (sw & 1 ? vA : vB)[q] = r4[16 * (sw + 1) + q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {                       // family order
+                        const float4 v = (sw & 1 ? vB : vA)[q];
+                        acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+                    }
+                }
+            }
+        } else if (prod && H + 1 < nhand) {
+            nxt = fetch(4 * (H + 2) + ps);               // (for the hand-over after the next)
+            produce((H + 1) & 1, 4 * (H + 1) + ps, cur);
+            cur = nxt;
+        }
+#ifdef NEM_PHASE_PROF
+        t_work += wall_clock64() - t_a;
+#endif
+        __syncthreads();
+    }
+#ifdef NEM_PHASE_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { g_phase[10 + wv] = t_work; if (wv == 0) g_phase[24] = wall_clock64() - t_begin; }
+#endif
+    // the facts of the four sub-window series: the latest zero, any one
+    __shared__ int sFact[4][64];
+    if (prod && ph == 0) sFact[ps][lane] = role == 1 ? last : some;
+    __syncthreads();
+    if (wv == 0) {
+        if (chk != nullptr) chk[(size_t)nwin * DW] = acc;
+        if (d < D) {
+            (role == 0 ? a.in0 : a.in1)[k * D + d] = acc;
+            const int f0 = sFact[0][lane], f1 = sFact[1][lane], f2 = sFact[2][lane], f3 = sFact[3][lane];
+            if (role == 1) a.lastz[k * D + d] = max(max(f0, f1), max(f2, f3));
+            else a.any1[k * D + d] = (f0 | f1 | f2 | f3) ? 1 : 0;
+        }
+    }
+}
+
+// the medians from the zeros' checkpoints: which window reached N_k / 2, then that window's families again
+__device__ __forceinline__ void mstep_fuzzy_med2_body(const FuzzyArgs& a)
+{
+    if (a.stop != nullptr && *a.stop) return;
+    const int n = a.n, K = a.K, D = a.D;
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x * 64 + lane;
+    const int t = k * D + min(d, D - 1);
+    const float nk = a.nbobs_k[k];
+    if (!((double)nk > kEpsilonD)) {
+        // "empty" class (nem_mod.c:1404-1408): the centre is kept, and EstimLaplaceIner (:1669-1686) still runs
+        // against that old centre (see mstep_fuzzy_b_body)
+        FuzzyWalk w = fuzzy_walk(n, a.npad, K, D, k, blockIdx.x, a.xw, a.c);
+        const float mu = a.center[t];
+        const double a1 = fabs((double)(1.0f - mu)), a0 = fabs((double)(0.0f - mu));
+        float in = 0.0f;
+        w.run([&](float cv, uint32_t xl, uint32_t xh, int j) {
+            const float ci = lane_f32(cv, j);
+            const bool one = __builtin_amdgcn_inverse_ballot_w64(lane_mask(xl, xh, j));
+            in = (float)((double)in + (double)ci * (one ? a1 : a0));     // :1683
+        });
+        if (d < D) a.iner[t] = in;
+        return;
+    }
+    const int DB = (D + 63) >> 6, DW = DB * 64, nwin = (n + 63) >> 6;
+    const float half = nk / 2;                           // nem_mod.c:1439
+    const double half_eps = (double)half + kEpsilonD;    // nem_mod.c:1464
+    const float* __restrict__ ck = a.chk + (size_t)k * (nwin + 1) * DW + d;
+    // the weights are >= 0: a chain that has reached N_k / 2 stays there -- the first window at whose end it has, by
+    // bisection over the (non-decreasing) checkpoints; a NaN anywhere counts as reached, as in the walk
+    int gstar = -1;
+    if (!(ck[(size_t)nwin * DW] < half)) {
+        int lo = 0, hi = nwin - 1;                       // the answer is in [lo, hi]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (!(ck[(size_t)(mid + 1) * DW] < half)) hi = mid; else lo = mid + 1;
+        }
+        gstar = lo;
+    }
+    float cum = 0.0f;
+    int istar = n;
+    const bool ph0 = gstar >= 0;
+    if (ph0) {
+        float r2 = ck[(size_t)gstar * DW];
+        const uint64_t own = a.xt[(size_t)min(d, D - 1) * a.nw64 + gstar];
+        const float4* __restrict__ cw4 = reinterpret_cast<const float4*>(a.ct + (size_t)k * a.ctpad + 64 * gstar);
+        const int cnt = min(64, n - 64 * gstar);
+        // the window's 64 memberships first (sixteen independent loads), then the walk from registers
+        float4 cv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) cv[q] = cw4[q];
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const float cj = j % 4 == 0 ? cv[j / 4].x : j % 4 == 1 ? cv[j / 4].y : j % 4 == 2 ? cv[j / 4].z : cv[j / 4].w;
+            const bool zero = j < cnt && !((own >> j) & 1ull);           // (a one is not in this chain)
+            const float nx = r2 + cj;
+            const bool hit = zero && !found && !(nx < half);
+            cum = hit ? nx : cum;
+            istar = hit ? 64 * gstar + j : istar;
+            found = found || hit;
+            r2 = (zero && !found) ? nx : r2;
+        }
+    }
+    const bool gt0 = (double)cum > half_eps;             // cum is the value at the crossing
+    float mu;
+    if (ph0) {                                           // median position among the zeros
+        const bool next0 = a.lastz[t] > istar;           // a zero of weight >= EPSILON follows the crossing
+        if (gt0 || next0) mu = 0.0f;                     // x_med = 0 (or midway to another 0)
+        else if (a.any1[t]) mu = 0.5f;                   // midway to the first one with weight
+        else mu = 0.0f;                                  // reference runs off the array here (UB)
+    } else {
+        mu = 1.0f;                                       // x_med = 1 (or midway to another 1)
+    }
+    if (d < D) {
+        a.center[t] = mu;
+        a.iner[t] = (mu == 0.0f) ? a.in0[t] : (mu == 1.0f ? a.in1[t] : a.inh_k[k]);
+    }
+}
+
 // pass A: chains [0, D) inertia for mu = 0 (the ones), [D, 2D) for mu = 1 (the zeros), 2D: N_k, 2D + 1: mu = 1/2
 __device__ __forceinline__ void mstep_fuzzy_sums_body(const FuzzyArgs& a)
 {
@@ -2838,6 +3116,10 @@ __global__ __launch_bounds__(64) void k_mstep_fuzzy_b_b(const void* arr, int str
     mstep_fuzzy_b_body(a.n, a.npad, a.K, a.D, a.xw, a.xt, a.nw64, a.c, a.nbobs_k, a.in0, a.in1, a.inh_k, a.lastz, a.any1, a.center,
                        a.iner, a.stop);
 }
+__global__ __launch_bounds__(64 * kPcWaves) void k_mstep_fuzzy_pc(FuzzyArgs a) { mstep_fuzzy_pc_body(a); }
+__global__ __launch_bounds__(64 * kPcWaves) void k_mstep_fuzzy_pc_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_pc_body(a); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_med2(FuzzyArgs a) { mstep_fuzzy_med2_body(a); }
+__global__ __launch_bounds__(64) void k_mstep_fuzzy_med2_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) mstep_fuzzy_med2_body(a); }
 __global__ void k_transpose_c(FuzzyArgs a) { transpose_c_body(a.n, a.ctpad, a.K, a.c, a.ct, a.stop); }
 __global__ void k_transpose_c_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FuzzyArgs) transpose_c_body(a.n, a.ctpad, a.K, a.c, a.ct, a.stop); }
 __global__ __launch_bounds__(64 * kFuzzyWaves) void k_mstep_fuzzy_sums(FuzzyArgs a) { mstep_fuzzy_sums_body(a); }
@@ -3032,11 +3314,21 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
                         float* ct, float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
-                        float* iner, const int* stop, hipStream_t s)
+                        float* iner, const int* stop, hipStream_t s, float* chk)
 {
     const int DB = (D + 63) / 64;
     const int ctpad = (n + kWin - 1) / kWin * kWin;
-    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct, ctpad};
+    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct, ctpad, chk};
+    if (ct != nullptr && chk != nullptr) {
+        // one lane per chain at the chain's own speed: producer waves make the addends (see mstep_fuzzy_pc_body)
+        if (!record_op(OP_FUZZY_T, 0, dim3(ctpad / 256), 256, a))
+            hipLaunchKernelGGL(k_transpose_c, dim3(ctpad / 256), dim3(256), 0, s, a);
+        if (!record_op(OP_FUZZY_PC, 0, dim3(2 * DB + 2, K), 64 * kPcWaves, a))
+            hipLaunchKernelGGL(k_mstep_fuzzy_pc, dim3(2 * DB + 2, K), dim3(64 * kPcWaves), 0, s, a);
+        if (!record_op(OP_FUZZY_MED2, 0, dim3(DB, K), 64, a))
+            hipLaunchKernelGGL(k_mstep_fuzzy_med2, dim3(DB, K), dim3(64), 0, s, a);
+        return;
+    }
     if (ct == nullptr) {                                 // one lane per chain (kept for comparison: NEM_MI355X_FUZZY_CHAINS=0)
         if (!record_op(OP_FUZZY_A, 0, dim3(4 * DB + 2, K), 64, a))
             hipLaunchKernelGGL(k_mstep_fuzzy_a, dim3(4 * DB + 2, K), dim3(64), 0, s, a);
@@ -3107,6 +3399,8 @@ void launch_zipped(int kind, int variant, int B, const void* arr, int stride, co
     case OP_FUZZY_T: hipLaunchKernelGGL(k_transpose_c_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FUZZY_SUMS: hipLaunchKernelGGL(k_mstep_fuzzy_sums_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FUZZY_MED: hipLaunchKernelGGL(k_mstep_fuzzy_median_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_PC: hipLaunchKernelGGL(k_mstep_fuzzy_pc_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_FUZZY_MED2: hipLaunchKernelGGL(k_mstep_fuzzy_med2_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_CONV_FUZZY: hipLaunchKernelGGL(k_conv_fuzzy_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_ONEHOT: hipLaunchKernelGGL(k_onehot_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_CRIT_TERMS: hipLaunchKernelGGL(k_crit_terms_b, grid, blk, 0, s, arr, stride, gx); break;

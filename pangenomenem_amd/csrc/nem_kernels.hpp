@@ -86,7 +86,8 @@ struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const 
 struct CountsArgs { int K, D, nw64; const uint64_t* xt; const uint64_t* mask; int* stats; const int* stop; CtrlArgs prev_ctrl; };
 struct FuzzyArgs { int n, npad, K, D; const uint32_t* xw; const uint64_t* xt; int nw64; const float* c; float* nbobs_k;
                    float* in0; float* in1; float* inh_k; int* lastz; int* any1; float* center; float* iner; const int* stop;
-                   float* ct; int ctpad; };   // ct: class-major copy of c, [K][ctpad] (nullptr: the one-lane-per-chain kernels)
+                   float* ct; int ctpad;      // ct: class-major copy of c, [K][ctpad] (nullptr: the one-lane-per-chain kernels)
+                   float* chk; };             // producer/consumer kernels: the zeros' chains every 64 families, [K][nwin + 1][64 DB]
 struct ConvFuzzyArgs { size_t m; const float* c; const float* cold; float thres; int* flags; const int* stop; CtrlArgs ca; };
 struct OnehotArgs { int n, K; const uint8_t* lab; float* c; };
 struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const float* nei_w; int use_nei; float beta;
@@ -101,7 +102,8 @@ struct CopyArgs { const int* src; int* dst; int words; };
 // (same argument blocks, same grids); the batch driver (nem_engine.hip) records one sequence per problem, checks that
 // the sequences agree launch for launch, and issues each position once for all problems with launch_zipped.
 enum OpKind { OP_FINISH = 1, OP_DENSITY, OP_DENSITY_FUSED, OP_SWEEP, OP_COUNTS, OP_LABELS_POST, OP_CTRL, OP_FUZZY_A, OP_FUZZY_B,
-              OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL, OP_COPY, OP_FUZZY_T, OP_FUZZY_SUMS, OP_FUZZY_MED };
+              OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL, OP_COPY, OP_FUZZY_T, OP_FUZZY_SUMS, OP_FUZZY_MED,
+              OP_FUZZY_PC, OP_FUZZY_MED2 };
 constexpr int kOpArgBytes = 512;
 struct OpRecord {
     int kind, variant;             // variant: template instance / block size, part of what must agree across problems
@@ -158,7 +160,7 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
                          const int* stop, const CtrlArgs* prev_ctrl, hipStream_t s);
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
                         float* ct, float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
-                        float* iner, const int* stop, hipStream_t s);
+                        float* iner, const int* stop, hipStream_t s, float* chk = nullptr);
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
                        const CtrlArgs* ctrl, hipStream_t s);
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s);
