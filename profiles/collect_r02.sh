@@ -51,6 +51,7 @@ python3 profiles/batch_chunks.py > $O/${R}_batch_chunks.json 2> /dev/null
 python3 profiles/pcie_inclusive.py > $O/${R}_pcie_inclusive.json 2> /dev/null
 python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep.txt 2> /dev/null
 NEM_MI355X_FUZZY_CHAINS=0 python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep_lane_per_chain.txt 2> /dev/null
+NEM_MI355X_FUZZY_CHAINS=1 python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep_wave_per_chain.txt 2> /dev/null
 # the drop-in nem() against the reference's own nem() on the same files (writes gpurun_out/dropin_whole_call.json)
 python3 -m pytest tests/test_gpu_dropin_fullsize.py -q -m gpu -k whole_call > $O/${R}_dropin_test.log 2>&1 || true
 python3 profiles/dropin_logged.py > $O/${R}_dropin_logged.json 2> /dev/null

@@ -1,6 +1,7 @@
 """The fuzzy M-step alone (EstimPara on a float partition, nem_mod.c:415-469) on configs[1]: microseconds per call for a
-one-hot, a real (three fuzzy EM iterations), a random and a constant partition.  NEM_MI355X_FUZZY_CHAINS=0 times the
-one-lane-per-chain kernels of round 1."""
+one-hot, a real (three fuzzy EM iterations), a random and a constant partition (launches and the wait included).
+NEM_MI355X_FUZZY_CHAINS=0 times the one-lane-per-chain kernels of round 1, =1 the wave-per-chain kernels, default (2):
+the producer / consumer kernels."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
