@@ -2474,18 +2474,38 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
             pc_produce<0, 32>(rowA, in);
         } else pc_produce<32, 64>(rowA, in);
     };
-    PcIn cur = prod ? fetch(ps) : PcIn{0u, 0u, 0.0f};
-    PcIn nxt = prod ? fetch(4 + ps) : PcIn{0u, 0u, 0.0f};
-    if (prod) { produce(0, ps, cur); cur = nxt; }
+    // Hand-overs without a barrier of the whole block (one costs the consumer ~0.3 us, a quarter of a hand-over's adds):
+    // two counters in LDS.  s_ready[b]: producer waves that have finished writing buffer b, over all its tenants;
+    // s_done: hand-overs the consumer has finished reading.  A producer writes its slice, waits for its LDS writes
+    // (workgroup-scope release), bumps s_ready; the consumer reads a buffer once all eight producers of that tenant
+    // are in (acquire), and says so in s_done when its last read has come back; a producer does not touch a buffer
+    // before the consumer is done with its previous tenant.  The producers run ahead and sleep on s_done; the
+    // consumer's check is one LDS read.  Spins are bounded: a broken hand-over ends the kernel, wrong, not hung.
+    __shared__ int s_ready[2], s_done;
+    if (threadIdx.x == 0) { s_ready[0] = 0; s_ready[1] = 0; s_done = -1; }
     __syncthreads();
+    constexpr int kSpinCap = 1 << 22;
 #ifdef NEM_PHASE_PROF
     unsigned long long t_work = 0, t_begin = wall_clock64();
 #endif
-    for (int H = 0; H < nhand; H++) {
+    if (prod) {
+        PcIn cur = fetch(ps), nxt = fetch(4 + ps);
+        for (int H = 0; H < nhand; H++) {
+            // buffer H & 1 held hand-over H - 2
+            for (int spin = 0; spin < kSpinCap && __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < H - 2; spin++)
+                __builtin_amdgcn_s_sleep(4);
+            produce(H & 1, 4 * H + ps, cur);
+            if (lane == 0) __hip_atomic_fetch_add(&s_ready[H & 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cur = nxt;
+            nxt = fetch(4 * (H + 2) + ps);               // (for the hand-over after the next)
+        }
+    } else if (wv == 0) {
+        for (int H = 0; H < nhand; H++) {
 #ifdef NEM_PHASE_PROF
-        const unsigned long long t_a = wall_clock64();
+            const unsigned long long t_a = wall_clock64();
 #endif
-        if (wv == 0) {
+            const int need = 8 * ((H >> 1) + 1);         // all eight producers of this tenant of the buffer
+            for (int spin = 0; spin < kSpinCap && __hip_atomic_load(&s_ready[H & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spin++) { }
             // two register sets: the next sub-window's 64 addends are read from LDS while this one's are added
             const float4* r4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sA4[H & 1]) + lane * kPcStride);
             float4 vA[16], vB[16];
@@ -2507,18 +2527,15 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
                     }
                 }
             }
-        } else if (prod && H + 1 < nhand) {
-            nxt = fetch(4 * (H + 2) + ps);               // (for the hand-over after the next)
-            produce((H + 1) & 1, 4 * (H + 1) + ps, cur);
-            cur = nxt;
-        }
+            // (every read of the buffer has come back: its values are in the sums)
+            if (lane == 0) __hip_atomic_store(&s_done, H, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef NEM_PHASE_PROF
-        t_work += wall_clock64() - t_a;
+            t_work += wall_clock64() - t_a;
 #endif
-        __syncthreads();
+        }
     }
 #ifdef NEM_PHASE_PROF
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { g_phase[10 + wv] = t_work; if (wv == 0) g_phase[24] = wall_clock64() - t_begin; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wv == 0) { g_phase[10] = t_work; g_phase[24] = wall_clock64() - t_begin; }
 #endif
     // the facts of the four sub-window series: the latest zero, any one
     __shared__ int sFact[4][64];
