@@ -135,6 +135,10 @@ struct nemgpu_engine {
     float* c_onehot = nullptr;                        // lazily allocated (criteria / NCEM)
     float *crit_dik = nullptr, *crit_gik = nullptr, *crit6_dev = nullptr;
     double *crit_lfi = nullptr, *crit_lzi = nullptr;
+    // a second set: the logged run evaluates the criteria of two partitions in the same launches (criteria_pair_enqueue)
+    float *crit2_dik = nullptr, *crit2_gik = nullptr, *crit2_6 = nullptr, *c_onehot2 = nullptr;
+    double *crit2_lfi = nullptr, *crit2_lzi = nullptr;
+    char* crit_pair_dev = nullptr;                   // the two argument blocks of each of those launches
 
     // run state
     uint32_t sweep_counter = 0;
@@ -1556,6 +1560,61 @@ int criteria_enqueue(nemgpu_engine* e, int buf = -1)
     if (!current_recorder()) HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
+// The criteria of TWO partitions of the engine (label / membership buffers buf_a and buf_b) in the same launches --
+// problem = blockIdx.z, through the kernels' batched twins: the i-ordered reductions are four lone blocks each and
+// take as long for two partitions as for one.  Results: crit6_dev (buf_a), crit2_6 (buf_b).
+int criteria_pair_enqueue(nemgpu_engine* e, int buf_a, int buf_b)
+{
+    int r;
+    if (e->lo != 0 || e->hi != e->n_total) { set_error("criteria need the whole partition on one engine"); return NEMGPU_E_FUNCARG; }
+    if ((r = ensure_crit_buffers(e))) return r;
+    const size_t nk = (size_t)e->n * e->k;
+    if (!e->crit2_dik) {
+        alloc_for(e);
+        if ((r = dev_alloc(&e->crit2_dik, nk))) return r;
+        if ((r = dev_alloc(&e->crit2_gik, nk))) return r;
+        if ((r = dev_alloc(&e->crit2_lfi, (size_t)e->n))) return r;
+        if ((r = dev_alloc(&e->crit2_lzi, (size_t)e->n))) return r;
+        if ((r = dev_alloc(&e->crit2_6, 16))) return r;
+        if (e->ncem()) { if ((r = dev_alloc(&e->c_onehot2, (size_t)e->n_total * e->k))) return r; }
+        if ((r = dev_alloc(&e->crit_pair_dev, 2048))) return r;
+    }
+    // argument blocks: [2 x OnehotArgs | gx] [2 x CritArgs | gx terms | gx reduce | gx final]
+    constexpr int so = (sizeof(OnehotArgs) + 15) & ~15, sc = (sizeof(CritArgs) + 15) & ~15;
+    static_assert(2 * so + 16 + 2 * sc + 48 <= 2048, "argument slab of the paired criteria");
+    char* st = stage(e, 2048);
+    if (!st) { set_error("no staging memory for the paired criteria"); return NEMGPU_E_DEVICE; }
+    memset(st, 0, 2048);
+    const int o_oh = 0, o_ohgx = 2 * so, o_cr = o_ohgx + 16, o_gxt = o_cr + 2 * sc, o_gxr = o_gxt + 16, o_gxf = o_gxr + 16;
+    const float* cpart[2];
+    const int bufs[2] = {buf_a, buf_b};
+    float* onehots[2] = {e->c_onehot, e->c_onehot2};
+    const unsigned g_oh = (unsigned)(((size_t)e->n_total * e->k + 255) / 256), g_t = (unsigned)((e->n + 255) / 256);
+    for (int p = 0; p < 2; p++) {
+        if (e->ncem()) {
+            OnehotArgs oa{e->n_total, e->k, e->lab[bufs[p]], onehots[p]};
+            memcpy(st + o_oh + p * so, &oa, sizeof oa);
+            cpart[p] = onehots[p];
+        } else cpart[p] = e->cbuf[bufs[p]];
+        CritArgs ca{e->n, e->k, e->npad, e->nei_ptr, e->nei_idx, e->nei_w, e->has_graph ? 1 : 0, e->cfg.beta, cpart[p], e->pkfki, e->logpkfki,
+                    p ? e->crit2_dik : e->crit_dik, p ? e->crit2_gik : e->crit_gik, p ? e->crit2_lfi : e->crit_lfi,
+                    p ? e->crit2_lzi : e->crit_lzi, p ? e->crit2_6 : e->crit6_dev, e->ncem() ? 1 : 0};
+        memcpy(st + o_cr + p * sc, &ca, sizeof ca);
+        reinterpret_cast<int*>(st + o_ohgx)[p] = (int)g_oh;
+        reinterpret_cast<int*>(st + o_gxt)[p] = (int)g_t;
+        reinterpret_cast<int*>(st + o_gxr)[p] = 4;
+        reinterpret_cast<int*>(st + o_gxf)[p] = 1;
+    }
+    HIPCHK(hipMemcpyAsync(e->crit_pair_dev, st, 2048, hipMemcpyHostToDevice, e->stream));
+    const char* dv = e->crit_pair_dev;
+    if (e->ncem()) launch_zipped(OP_ONEHOT, 0, 2, dv + o_oh, so, reinterpret_cast<const int*>(dv + o_ohgx), g_oh, 1, 256, e->stream);
+    launch_zipped(OP_CRIT_TERMS, 0, 2, dv + o_cr, sc, reinterpret_cast<const int*>(dv + o_gxt), g_t, 1, 256, e->stream);
+    launch_zipped(OP_CRIT_REDUCE, 0, 2, dv + o_cr, sc, reinterpret_cast<const int*>(dv + o_gxr), 4, 1, (unsigned)kCritReduceThreads, e->stream);
+    launch_zipped(OP_CRIT_FINAL, 0, 2, dv + o_cr, sc, reinterpret_cast<const int*>(dv + o_gxf), 1, 1, 1, e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
 int criteria(nemgpu_engine* e, float crit6[6], int buf = -1)
 {
     int r;
@@ -2066,9 +2125,8 @@ int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, f
             if ((r = batch_enqueue(e, lc, true))) { if (st) pool_put(e->device, true, st, got); return r; }
             if (st) {
                 float* f = reinterpret_cast<float*>(st);
-                r = criteria_enqueue(e, oldbuf);
-                if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-                if (r == NEMGPU_OK) r = criteria_enqueue(e, newbuf);
+                r = criteria_pair_enqueue(e, newbuf, oldbuf);                  // both partitions in the same launches
+                if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f, e->crit2_6, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f + 6, e->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 if (r == NEMGPU_OK) HIPCHK(hipMemcpyAsync(f + 12, e->prop, e->par_words * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 if (r) { (void)hipStreamSynchronize(e->stream); pool_put(e->device, true, st, got); return r; }

@@ -2882,6 +2882,7 @@ __device__ __forceinline__ void crit_terms_body(int n, int K, int npad, const in
 // reference's conditional adds (nem_alg.c:2727-2736) bit for bit.
 // ------------------------------------------------------------------------------------------
 constexpr int CH_T = 1024, CH_C = 4, CH_W = CH_T * CH_C;
+static_assert(CH_T == kCritReduceThreads, "launchers outside this file use kCritReduceThreads");
 
 struct ChainShared {
     double x[CH_W];

@@ -166,6 +166,7 @@ void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres,
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s);
 void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStream_t s);
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s);
+constexpr int kCritReduceThreads = 1024;   // block size of k_crit_reduce (CH_T in nem_kernels.hip)
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
                      float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
                      double* lfi, double* lzi, float* crit6, int hard, hipStream_t s);   // hard: one-hot rows (NCEM)
