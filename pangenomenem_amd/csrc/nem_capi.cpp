@@ -204,6 +204,7 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
     double loop_s = 0.0;
     // the line of an iteration (9 000 numbers at configs[1]) is put together by a helper thread while the device runs
     // the next iteration; the lines reach the file in order
+    bool last_logged = false;                                                // ca holds the criteria of the final partition
     std::future<std::string> pending;
     auto flush_line = [&]() { if (pending.valid()) { const std::string t = pending.get(); fwrite(t.data(), 1, t.size(), fl); } };
     for (int iter = 1; iter <= cfg.it_max && !r1.converged && r1.status == NEMGPU_OK; iter++) {
@@ -215,8 +216,10 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
         fprintf(fl, "%4d ", iter);
         if (r1.status == NEMGPU_W_EMPTYCLASS) {                             // :1835-1837
             fprintf(fl, " Class %d empty at iteration %d\n", r1.emptyk, iter);
+            last_logged = false;
             break;
         }
+        last_logged = true;
         struct Line { float cb[6], ca[6]; LogParams P; };
         auto L = std::make_shared<Line>();
         memcpy(L->cb, cb, sizeof cb); memcpy(L->ca, ca, sizeof ca); L->P = P;
@@ -237,6 +240,8 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
         if (rc != NEMGPU_OK && rc != NEMGPU_W_EMPTYCLASS) return rc;
         if ((rc = nemgpu_density(e))) return rc;
     }
+    // (the last logged iteration's second criteria evaluation was of the final partition, on the final densities)
+    if (last_logged && r1.iters > 0) { memcpy(res->crit, ca, sizeof ca); return NEMGPU_OK; }
     return nemgpu_criteria(e, res->crit);
 }
 
