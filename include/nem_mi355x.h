@@ -87,7 +87,10 @@ enum { NEMGPU_TIE_LIBC = 0, NEMGPU_TIE_FIRST = 1, NEMGPU_TIE_HASH = 2 };
 /* status codes = StatusET (nem_typ.h:106-117) */
 enum { NEMGPU_OK = 0, NEMGPU_W_EMPTYCLASS = 2, NEMGPU_E_ARG = 3, NEMGPU_E_MEMORY = 4,
        NEMGPU_E_FILEIN = 5, NEMGPU_E_FILEOUT = 6, NEMGPU_E_FILE = 7, NEMGPU_E_FUNCARG = 8,
-       NEMGPU_E_DEVICE = 9 };
+       NEMGPU_E_DEVICE = 9,
+       /* a kernel reported that it could not finish its work (e.g. a producer/consumer hand-over of the fuzzy M-step
+          that never completed): the results of the call are not to be used.  nem() returns 6 (EXIT_E_BUG). */
+       NEMGPU_E_INTERNAL = 10 };
 
 typedef struct {
     int   algo;        /* NEMGPU_ALGO_*  */
@@ -117,8 +120,15 @@ typedef struct {
 
 const char* nemgpu_last_error(void);
 
-/* Number of usable HIP devices (0 when none). */
+/* Number of usable HIP devices (0 when none, and in a process forked from one that had already used the GPU). */
 int nemgpu_device_count(void);
+/* The device a call that was not given one runs on -- what the drop-in nem() uses.  NEM_MI355X_DEVICE = <index>: that
+   device (anything but a valid index is NEMGPU_E_ARG); NEM_MI355X_DEVICE = auto: processes spread over the node's
+   devices, LOCAL_RANK (a launcher's) when set, else the process id, modulo the device count (PPanGGOLiN runs its
+   chunks in a multiprocessing.Pool, ppanggolin.py:1039-1095); unset: the calling thread's current HIP device, i.e.
+   the one the embedding application selected (device 0 when it selected none).  Fails with NEMGPU_E_DEVICE, before
+   any HIP call, in a forked child of a process that had used the GPU. */
+int nemgpu_default_device(int* device);
 
 /* Create an engine for n_total families x d organisms, k classes on `device`.
    [site_lo, site_hi) is the family shard this engine owns (0, n_total for a single GPU).
@@ -131,7 +141,8 @@ void nemgpu_destroy(nemgpu_engine* e);
    [(site_hi-site_lo) x d], HOST memory.  Bit-packs, uploads and builds both device layouts. */
 int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host);
 /* Same, family-major bit-packed rows: word w of row i holds organisms 32w..32w+31 (bit b =
-   organism 32w+b), ceil(d/32) words per row, HOST memory. */
+   organism 32w+b), ceil(d/32) words per row, HOST memory.  Bits above organism d-1 in a row's last word are
+   padding: the library clears them in its own copy (the caller's buffer is not written), whatever they hold. */
 int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host);
 /* Neighbourhood graph of the owned shard in CSR, .nei file order inside a row; neighbour
    indices are GLOBAL family indices (0-based).  ptr has (site_hi-site_lo)+1 entries.  HOST memory. */

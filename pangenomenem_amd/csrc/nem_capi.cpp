@@ -400,15 +400,12 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
     nemgpu_engine* e = nullptr;
     nemgpu_result res{};
     bool full_log = false;
-    // which GPU: NEM_MI355X_DEVICE when set; otherwise processes spread over the node's GPUs by pid (PPanGGOLiN runs
-    // its chunks in a multiprocessing.Pool, ppanggolin.py:1039-1095: every worker would otherwise land on GPU 0)
+    // which GPU: the calling thread's current HIP device unless NEM_MI355X_DEVICE says otherwise (an index, or "auto":
+    // processes spread over the node's GPUs -- PPanGGOLiN runs its chunks in a multiprocessing.Pool,
+    // ppanggolin.py:1039-1095); decided behind the library's fork guard (nemgpu_default_device)
     int device = 0;
-    {
-        const int ndev = nemgpu_device_count();
-        if (const char* s = getenv("NEM_MI355X_DEVICE")) device = atoi(s);
-        else if (ndev > 1) device = (int)((unsigned long)getpid() % (unsigned long)ndev);
-    }
-    int rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, device, nullptr);
+    int rc = nemgpu_default_device(&device);
+    if (rc == NEMGPU_OK) rc = nemgpu_create(&e, in.n, in.d, nk, 0, in.n, device, nullptr);
     if (rc == NEMGPU_OK) rc = nemgpu_set_matrix_bits(e, in.xbits.data());
     if (rc == NEMGPU_OK) rc = nemgpu_set_graph(e, in.nei_ptr.data(), in.nei_idx.data(), in.nei_w.data());
     if (rc == NEMGPU_OK && !random_init) rc = nemgpu_set_params(e, in.prop.data(), in.center.data(), in.disp.data());
@@ -437,7 +434,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
         fprintf(stderr, "nem (MI355X engine): %s\n", nemgpu_last_error());
         if (e) nemgpu_destroy(e);
         lg.close();
-        return rc == NEMGPU_E_ARG ? EXIT_E_ARGS_ : (rc == NEMGPU_E_MEMORY ? EXIT_E_MEMORY_ : EXIT_E_SYSTEM_);
+        return rc == NEMGPU_E_ARG ? EXIT_E_ARGS_ : (rc == NEMGPU_E_MEMORY ? EXIT_E_MEMORY_ : (rc == NEMGPU_E_INTERNAL ? EXIT_E_BUG_ : EXIT_E_SYSTEM_));
     }
 
     lg.pr("  Iterations : %4d \n", res.iters);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <pthread.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -178,6 +179,9 @@ struct nemgpu_engine {
         return d <= kFusedMaxD && (cfg.disper == NEMGPU_DISP_KD || cfg.disper == NEMGPU_DISP_K_);
     }
     bool use_ff() const { return ff_mode < 0 ? d >= 256 : ff_mode != 0; }
+    // a kernel's FLAG_FAULT seen on the host (cleared, device word included, by the next reset / restart);
+    // fault_inject: NEM_MI355X_FAULT_INJECT=fuzzy_pc makes one producer of k_mstep_fuzzy_pc skip a hand-over (tests)
+    bool fault_seen = false; int fault_inject = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
 
@@ -203,7 +207,9 @@ struct nemgpu_engine {
     // area their flag blocks are gathered in, and the launch sequences captured so far (they hold the slabs'
     // addresses).  It belongs to the device, not to the engine: a lead takes one from the device's pool and hands it
     // back when it is destroyed, so the next group of problems of the same shape REPLAYS the graphs this one captured.
-    struct ZipGraph { uint64_t key; int asked; hipGraphExec_t exec; };
+    // desc: everything the captured launches depend on (kernel, variant, members, strides, grids, slab offsets),
+    // compared on a key hit -- a 64-bit hash alone would replay the wrong graph on a collision
+    struct ZipGraph { uint64_t key; int asked; hipGraphExec_t exec; std::vector<uint64_t> desc; };
     struct ZipContext {
         char* zip_host = nullptr; char* zip_dev = nullptr; size_t zip_cap = 0;
         int* zip_flags_host = nullptr; int* zip_flags_dev = nullptr; size_t zip_flags_cap = 0;
@@ -500,6 +506,24 @@ hipError_t copy_sync(nemgpu_engine* e, void* dst, const void* src, size_t bytes,
     return hipStreamSynchronize(e->stream);
 }
 
+// the iteration flags are on the host: did a kernel report that it could not finish its work?
+int check_fault(nemgpu_engine* e)
+{
+    if (e->h_iter()[FLAG_FAULT] == 0) return NEMGPU_OK;
+    e->fault_seen = true;
+    set_error("internal: a kernel reported a fault (a producer/consumer hand-over of the fuzzy M-step never completed); "
+              "the results of this call are not to be used");
+    return NEMGPU_E_INTERNAL;
+}
+int clear_fault(nemgpu_engine* e)
+{
+    if (!e->fault_seen) return NEMGPU_OK;
+    e->fault_seen = false;
+    e->flags_host[C_WORDS + FLAG_FAULT] = 0;
+    HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_FAULT, 0, sizeof(int), e->stream));
+    return NEMGPU_OK;
+}
+
 FinishArgs finish_args(nemgpu_engine* e, int mode, const int* stats)
 {
     FinishArgs t;
@@ -701,6 +725,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, 
             HIPCHK(hipStreamSynchronize(e->stream));
         }
         flags_ready = false;
+        { const int fr = check_fault(e); if (fr) return fr; }
         if (!c.multi) { done_at = 0; break; }
         bool tab_short = false;
         for (int q = c.checked; q < c.r; q++) {
@@ -769,7 +794,7 @@ int do_mstep(nemgpu_engine* e, const CtrlArgs* prev_ctrl = nullptr)
         launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, e->cbuf[e->cur] + (size_t)e->lo * e->k,
                            e->fuzzy_chains ? e->fz_ct : nullptr, e->nbobs_k,
                            e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, e->stop_ptr, e->stream,
-                           e->fuzzy_chains == 2 ? e->fz_chk : nullptr);
+                           e->fuzzy_chains == 2 ? e->fz_chk : nullptr, e->iter_flags() + FLAG_FAULT, e->fault_inject);
         launch_finish(finish_args(e, 2, nullptr), e->stream);
     }
     HIPCHK(hipGetLastError());
@@ -783,7 +808,7 @@ int read_iter_flags(nemgpu_engine* e)
     HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, (C_WORDS + FLAG_ITER_STRIDE) * sizeof(int),
                           hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    return NEMGPU_OK;
+    return check_fault(e);
 }
 
 int reset_device(nemgpu_engine* e);
@@ -1009,6 +1034,7 @@ int loop_begin(nemgpu_engine* e, LoopCursor& lc, int n_iters, bool with_init)
     if (with_init) {
         if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
         if ((r = ensure_state_buffers(e))) return r;
+        if ((r = clear_fault(e))) return r;
         e->reset_pending = false;                          // (the head of the first batch is the device half of a reset)
         e->run_deep_used = 0; e->run_tracked = true;
         e->cur = 0; e->sweep_counter = 0;
@@ -1071,6 +1097,7 @@ int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
 int batch_finish(nemgpu_engine* e, LoopCursor& lc)
 {
     int r;
+    if ((r = check_fault(e))) return r;
     const int* c = e->h_ctrl();
     const int done = c[C_ITERS], commits = c[C_COMMITS];
     const bool first = lc.batch_first;
@@ -1302,6 +1329,7 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
     std::vector<Launch> launches;
     size_t off = 0;
     uint64_t key = 1469598103934665603ull;                        // FNV-1a over everything a captured sequence depends on
+    std::vector<uint64_t> desc;                                   // ... and the list itself (compared on a key hit)
     auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
     for (const auto& g : groups) {
         const int B = (int)g.size();
@@ -1316,22 +1344,23 @@ int zip_and_launch(nemgpu_engine* lead, const std::vector<Recorder>& recs, const
             for (int b = 0; b < B; b++) { gx[b] = (int)recs[g[b]].ops[t].gx; L.max_gx = std::max(L.max_gx, recs[g[b]].ops[t].gx); }
             off += ((size_t)B * sizeof(int) + 15) & ~(size_t)15;
             launches.push_back(L);
-            mix((uint64_t)L.kind); mix((uint64_t)L.variant); mix((uint64_t)B); mix((uint64_t)stride); mix(L.max_gx); mix(L.gy); mix(L.block);
+            for (uint64_t v : {(uint64_t)L.kind, (uint64_t)L.variant, (uint64_t)B, (uint64_t)stride, (uint64_t)L.max_gx, (uint64_t)L.gy,
+                               (uint64_t)L.block, (uint64_t)L.args_off, (uint64_t)L.gx_off}) { mix(v); desc.push_back(v); }
         }
     }
-    mix(flags_words);
+    mix(flags_words); desc.push_back(flags_words);
     if (off == 0 && flags_words == 0) return NEMGPU_OK;
     if (off) HIPCHK(hipMemcpyAsync(z->zip_dev, z->zip_host, off, hipMemcpyHostToDevice, lead->stream));
     // The launches themselves depend only on the shape (kernels, grids, slab offsets), not on the argument blocks'
     // content: a shape seen before is replayed from its captured graph
     nemgpu_engine::ZipGraph* slot = nullptr;
-    for (auto& g : z->zip_graphs) if (g.key == key) { slot = &g; break; }
+    for (auto& g : z->zip_graphs) if (g.key == key && g.desc == desc) { slot = &g; break; }
     if (slot == nullptr && lead->use_graphs) {
         if (z->zip_graphs.size() >= 64) {
             for (auto& g : z->zip_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
             z->zip_graphs.clear();
         }
-        z->zip_graphs.push_back({key, 0, nullptr});
+        z->zip_graphs.push_back({key, 0, nullptr, desc});
         slot = &z->zip_graphs.back();
     }
     auto issue = [&]() -> int {
@@ -1470,15 +1499,31 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
     int r;
     const int B = (int)E.size();
     nemgpu_engine* lead = E[0];
-    std::vector<hipStream_t> own((size_t)B);
     for (int i = 0; i < B; i++) {
         if (E[i]->device != lead->device) { set_error("a batch lives on one device"); return NEMGPU_E_ARG; }
         if (E[i]->lo != 0 || E[i]->hi != E[i]->n_total) { set_error("sharded engines cannot join a batch"); return NEMGPU_E_ARG; }
-        HIPCHK(hipStreamSynchronize(E[i]->stream));
-        own[i] = E[i]->stream;
-        E[i]->stream = lead->stream;
     }
-    auto restore = [&]() { for (int i = 0; i < B; i++) E[i]->stream = own[i]; };
+    // The members run on the lead's stream for the duration.  Whatever way this function is left, the lead's stream is
+    // waited for BEFORE the members get their own streams back: a later call on a member's stream must not race with
+    // work still queued on the lead's.
+    struct StreamLoan {
+        std::vector<nemgpu_engine*>& E; nemgpu_engine* lead; std::vector<hipStream_t> own; int taken = 0;
+        StreamLoan(std::vector<nemgpu_engine*>& E_, nemgpu_engine* l) : E(E_), lead(l), own(E_.size()) {}
+        void give_back() {
+            if (taken == 0) return;
+            (void)hipStreamSynchronize(lead->stream);
+            for (int i = 0; i < taken; i++) E[i]->stream = own[i];
+            taken = 0;
+        }
+        ~StreamLoan() { give_back(); }
+    } loan(E, lead);
+    for (int i = 0; i < B; i++) {
+        HIPCHK(hipStreamSynchronize(E[i]->stream));            // (an early return gives back what was taken so far)
+        loan.own[i] = E[i]->stream;
+        E[i]->stream = lead->stream;
+        loan.taken = i + 1;
+    }
+    auto restore = [&]() { loan.give_back(); };
     for (int i = 0; i < B; i++) {
         if (crit_test(E[i])) {                                     // (a host round trip per iteration: nothing to share)
             restore();
@@ -1638,7 +1683,7 @@ int reset_device(nemgpu_engine* e)
         HIPCHK(hipMemsetAsync(e->nbobs_k, 0, sizeof(float) * e->k, e->stream));
     }
     HIPCHK(hipMemsetAsync(e->sweep_next, 0, sizeof(int), e->stream));
-    return NEMGPU_OK;
+    return clear_fault(e);
 }
 
 int flush_reset(nemgpu_engine* e)
@@ -1681,11 +1726,56 @@ extern "C" {
 
 const char* nemgpu_last_error(void) { return g_last_error.c_str(); }
 
+static const char kForkedMsg[] =
+    "this process was forked from one that had already used the GPU: HIP is unusable in a forked child "
+    "(start the workers with multiprocessing's 'spawn' or 'forkserver' method)";
+
 int nemgpu_device_count(void)
 {
+    if (g_forked_after_hip.load()) return 0;                       // (no HIP call in such a child)
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
+}
+
+int nemgpu_default_device(int* device)
+{
+    if (!device) return NEMGPU_E_FUNCARG;
+    *device = 0;
+    std::call_once(g_atfork_once, [] { pthread_atfork(nullptr, nullptr, atfork_child); });
+    if (g_forked_after_hip.load()) { set_error(kForkedMsg); return NEMGPU_E_DEVICE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device: this library has no CPU fallback");
+        return NEMGPU_E_DEVICE;
+    }
+    g_hip_used.store(true);
+    const char* s = getenv("NEM_MI355X_DEVICE");
+    if (s == nullptr || s[0] == '\0') {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+        *device = cur;
+        return NEMGPU_OK;
+    }
+    if (!strcmp(s, "auto")) {
+        unsigned long key = (unsigned long)getpid();
+        if (const char* lr = getenv("LOCAL_RANK")) {
+            char* end = nullptr;
+            const long v = strtol(lr, &end, 10);
+            if (end != lr && *end == '\0' && v >= 0) key = (unsigned long)v;
+        }
+        *device = (int)(key % (unsigned long)ndev);
+        return NEMGPU_OK;
+    }
+    char* end = nullptr;
+    const long v = strtol(s, &end, 10);
+    if (end == s || *end != '\0' || v < 0 || v >= ndev) {
+        set_error(std::string("NEM_MI355X_DEVICE=") + s + ": not a device index below " + std::to_string(ndev) + " (or \"auto\")");
+        return NEMGPU_E_ARG;
+    }
+    *device = (int)v;
+    return NEMGPU_OK;
 }
 
 int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, int site_hi, int device,
@@ -1704,11 +1794,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
         return NEMGPU_E_ARG;
     }
     std::call_once(g_atfork_once, [] { pthread_atfork(nullptr, nullptr, atfork_child); });
-    if (g_forked_after_hip.load()) {
-        set_error("this process was forked from one that had already used the GPU: HIP is unusable in a forked child "
-                  "(start the workers with multiprocessing's 'spawn' or 'forkserver' method)");
-        return NEMGPU_E_DEVICE;
-    }
+    if (g_forked_after_hip.load()) { set_error(kForkedMsg); return NEMGPU_E_DEVICE; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         set_error("no usable HIP device: this library has no CPU fallback");
@@ -1733,6 +1819,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_ROUNDS_ITER")) e->rounds_iter = std::max(2, std::min(e->round_batch, atoi(g)));
     e->rounds_iter = std::min(e->rounds_iter, e->round_batch);
     if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = std::max(0, std::min(2, atoi(g)));
+    if (const char* g = getenv("NEM_MI355X_FAULT_INJECT")) e->fault_inject = !strcmp(g, "fuzzy_pc") ? 1 : 0;
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
     if (const char* g = getenv("NEM_MI355X_SORT")) e->use_sort = (g[0] != '0');       // 0: E1 lanes in family order
     if (hip_stream) { e->stream = (hipStream_t)hip_stream; e->own_stream = false; }
@@ -1896,7 +1983,14 @@ int nemgpu_set_matrix_bits(nemgpu_engine* e, const uint32_t* xbits_host)
     if (!e || !xbits_host) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     const size_t words = (size_t)e->n * e->wf;
-    memcpy(host_bits_reserve(e, words), xbits_host, words * sizeof(uint32_t));
+    uint32_t* bits = host_bits_reserve(e, words);
+    memcpy(bits, xbits_host, words * sizeof(uint32_t));
+    // bits above organism d-1 in a row's last word are not data: cleared here, so that a caller's dirty padding can
+    // neither count as organisms in the popcount M-step nor push a row's popcount past d in the lane ordering
+    if (e->d & 31) {
+        const uint32_t keep = (1u << (e->d & 31)) - 1u;
+        for (size_t i = 0; i < (size_t)e->n; i++) bits[i * e->wf + (e->wf - 1)] &= keep;
+    }
     return upload_bits(e, nullptr);
 }
 
@@ -2182,7 +2276,8 @@ int nemgpu_run(nemgpu_engine* e, nemgpu_result* res)
     HIPCHK(hipStreamSynchronize(e->stream));
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (e->iters == 0) {                                           // nem_alg.c:1845-1851
-            if ((r = do_mstep(e))) return r;
+        if ((r = do_mstep(e))) return r;
+        if (!e->ncem() && (r = read_iter_flags(e))) return r;      // (a fuzzy M-step can report a fault)
         if ((r = do_tables(e))) return r;
         if ((r = do_density(e))) return r;
     }
@@ -2389,6 +2484,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
     }
     e->cur = 0; e->masks_valid = false;
     if ((r = do_mstep(e))) return r;
+    if (!e->ncem() && (r = read_iter_flags(e))) return r;         // (a fuzzy M-step can report a fault)
     std::vector<float> dispsam((size_t)d);
     HIPCHK(copy_sync(e, dispsam.data(), e->disp, sizeof(float) * d, hipMemcpyDeviceToHost));
 
@@ -2457,7 +2553,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
         if (e->ncem()) HIPCHK(hipMemcpyAsync(e->lab[e->cur], best_lab, (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
         else HIPCHK(hipMemcpyAsync(e->cbuf[e->cur], best_c, sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
         e->masks_valid = false; e->tables_fresh = false; e->density_fresh = false;
-        if ((r = do_mstep(e))) { cleanup(); return r; }                                                      // :1711
+        if ((r = do_mstep(e)) || (!e->ncem() && (r = read_iter_flags(e)))) { cleanup(); return r; }             // :1711
         e->status = NEMGPU_OK; e->emptyk = 0;
         e->iters = best_res.iters; e->converged = best_res.converged;
         if (res) { *res = best_res; res->status = NEMGPU_OK; res->tie_draws = e->draws; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
@@ -2560,6 +2656,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     }
     e->cur = 0; e->masks_valid = false;
     if ((r = do_mstep(e))) return r;
+    if (!e->ncem() && (r = read_iter_flags(e))) return r;         // (a fuzzy M-step can report a fault)
     std::vector<float> dispsam((size_t)d);
     HIPCHK(copy_sync(e, dispsam.data(), e->disp, sizeof(float) * d, hipMemcpyDeviceToHost));
 
@@ -2675,7 +2772,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
         if (e->ncem()) HIPCHK(hipMemcpyAsync(e->lab[e->cur], e->best_lab, (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
         else HIPCHK(hipMemcpyAsync(e->cbuf[e->cur], e->best_c, sizeof(float) * (size_t)e->n_total * k, hipMemcpyDeviceToDevice, e->stream));
         e->masks_valid = false; e->tables_fresh = false; e->density_fresh = false;
-        if ((r = do_mstep(e))) return r;                                                                      // :1711
+        if ((r = do_mstep(e)) || (!e->ncem() && (r = read_iter_flags(e)))) return r;                              // :1711
         e->status = NEMGPU_OK; e->emptyk = 0;
         e->iters = best_res.iters; e->converged = best_res.converged;
         if (res) { *res = best_res; res->status = NEMGPU_OK; res->tie_draws = e->draws; for (int t = 0; t < 6; t++) res->crit[t] = best_crit[t]; }
@@ -2785,6 +2882,12 @@ int nemgpu_shard_begin(nemgpu_engine* e)
     if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
     if (e->sh_stride == 0) { set_error("nemgpu_shard_layout must be called first"); return NEMGPU_E_FUNCARG; }
     if (e->libc()) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_FUNCARG; }
+    if (crit_test(e)) {
+        // (the criterion is an i-ordered float sum over ALL families: no sharded reduction reproduces it, and the loop
+        //  control of this path only knows the clas test -- a run configured with crit would never converge)
+        set_error("the family-sharded path implements the convergence tests none and clas only");
+        return NEMGPU_E_FUNCARG;
+    }
     HIPCHK(hipSetDevice(e->device));
     { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));

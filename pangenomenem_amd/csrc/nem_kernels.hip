@@ -2480,11 +2480,21 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
     // (workgroup-scope release), bumps s_ready; the consumer reads a buffer once all eight producers of that tenant
     // are in (acquire), and says so in s_done when its last read has come back; a producer does not touch a buffer
     // before the consumer is done with its previous tenant.  The producers run ahead and sleep on s_done; the
-    // consumer's check is one LDS read.  Spins are bounded: a broken hand-over ends the kernel, wrong, not hung.
-    __shared__ int s_ready[2], s_done;
-    if (threadIdx.x == 0) { s_ready[0] = 0; s_ready[1] = 0; s_done = -1; }
+    // consumer's check is one LDS read.  Spins are bounded, and a spin that runs out is a FAULT, not a result: the wave
+    // that sees it raises s_fault (every wave of the block leaves its loop at its next hand-over) and the engine's
+    // FLAG_FAULT word, which the host turns into NEMGPU_E_INTERNAL -- a broken hand-over ends the kernel, reported, not
+    // hung and not silently wrong.
+    __shared__ int s_ready[2], s_done, s_fault;
+    if (threadIdx.x == 0) { s_ready[0] = 0; s_ready[1] = 0; s_done = -1; s_fault = 0; }
     __syncthreads();
     constexpr int kSpinCap = 1 << 22;
+    auto faulted = [&]() { return __hip_atomic_load(&s_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
+    auto raise_fault = [&]() {
+        if (lane == 0) {
+            __hip_atomic_store(&s_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (a.fault != nullptr) atomicOr(a.fault, 1);
+        }
+    };
 #ifdef NEM_PHASE_PROF
     unsigned long long t_work = 0, t_begin = wall_clock64();
 #endif
@@ -2492,8 +2502,14 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
         PcIn cur = fetch(ps), nxt = fetch(4 + ps);
         for (int H = 0; H < nhand; H++) {
             // buffer H & 1 held hand-over H - 2
-            for (int spin = 0; spin < kSpinCap && __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < H - 2; spin++)
+            int spin = 0;
+            for (; spin < kSpinCap && __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < H - 2; spin++) {
+                if ((spin & 255) == 255 && faulted()) break;
                 __builtin_amdgcn_s_sleep(4);
+            }
+            if (faulted()) break;
+            if (spin >= kSpinCap) { raise_fault(); break; }
+            if (a.inject == 1 && wv == 1 && H == 1 && blockIdx.x == 0 && blockIdx.y == 0) continue;   // (test hook: a producer that never delivers)
             produce(H & 1, 4 * H + ps, cur);
             if (lane == 0) __hip_atomic_fetch_add(&s_ready[H & 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             cur = nxt;
@@ -2505,7 +2521,9 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
             const unsigned long long t_a = wall_clock64();
 #endif
             const int need = 8 * ((H >> 1) + 1);         // all eight producers of this tenant of the buffer
-            for (int spin = 0; spin < kSpinCap && __hip_atomic_load(&s_ready[H & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spin++) { }
+            int spin = 0;
+            for (; spin < kSpinCap && __hip_atomic_load(&s_ready[H & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spin++) { }
+            if (spin >= kSpinCap) { raise_fault(); break; }   // (the sums are not to be used: FLAG_FAULT says so)
             // two register sets: the next sub-window's 64 addends are read from LDS while this one's are added
             const float4* r4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sA4[H & 1]) + lane * kPcStride);
             float4 vA[16], vB[16];
@@ -3332,11 +3350,11 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
 
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
                         float* ct, float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
-                        float* iner, const int* stop, hipStream_t s, float* chk)
+                        float* iner, const int* stop, hipStream_t s, float* chk, int* fault, int inject)
 {
     const int DB = (D + 63) / 64;
     const int ctpad = (n + kWin - 1) / kWin * kWin;
-    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct, ctpad, chk};
+    FuzzyArgs a{n, npad, K, D, xw, xt, nw64, c, nbobs_k, in0, in1, inh_k, lastz, any1, center, iner, stop, ct, ctpad, chk, fault, inject};
     if (ct != nullptr && chk != nullptr) {
         // one lane per chain at the chain's own speed: producer waves make the addends (see mstep_fuzzy_pc_body)
         if (!record_op(OP_FUZZY_T, 0, dim3(ctpad / 256), 256, a))

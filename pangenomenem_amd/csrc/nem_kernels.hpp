@@ -18,7 +18,9 @@ enum { FLAG_CHANGED = 0, FLAG_NZERO = 1, FLAG_FIRSTZERO = 2, FLAG_NTIES = 3, FLA
 // per-iteration flag block.  FLAG_EMPTYK is overwritten by every k_mstep_disp; FLAG_MOVED and the
 // relaxation-round window that follows this block are zeroed by k_density, which precedes every
 // sweep of the EM loop (so no memset launches are needed).
-enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 4 };
+// FLAG_FAULT: a kernel could not finish its work (bit 0: a hand-over of k_mstep_fuzzy_pc never completed).  Sticky: only
+// a reset clears it; the host turns it into NEMGPU_E_INTERNAL wherever it reads the flags back.
+enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_FAULT = 2, FLAG_MOVED = 3, FLAG_ITER_STRIDE = 4 };
 
 // device-side loop control block (ints), see k_ctrl
 // C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
@@ -87,7 +89,9 @@ struct CountsArgs { int K, D, nw64; const uint64_t* xt; const uint64_t* mask; in
 struct FuzzyArgs { int n, npad, K, D; const uint32_t* xw; const uint64_t* xt; int nw64; const float* c; float* nbobs_k;
                    float* in0; float* in1; float* inh_k; int* lastz; int* any1; float* center; float* iner; const int* stop;
                    float* ct; int ctpad;      // ct: class-major copy of c, [K][ctpad] (nullptr: the one-lane-per-chain kernels)
-                   float* chk; };             // producer/consumer kernels: the zeros' chains every 64 families, [K][nwin + 1][64 DB]
+                   float* chk;                // producer/consumer kernels: the zeros' chains every 64 families, [K][nwin + 1][64 DB]
+                   int* fault;                // the iteration flags' FLAG_FAULT word (nullptr: faults go unreported)
+                   int inject; };             // test hook (NEM_MI355X_FAULT_INJECT=fuzzy_pc): one producer skips a hand-over
 struct ConvFuzzyArgs { size_t m; const float* c; const float* cold; float thres; int* flags; const int* stop; CtrlArgs ca; };
 struct OnehotArgs { int n, K; const uint8_t* lab; float* c; };
 struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const float* nei_w; int use_nei; float beta;
@@ -160,7 +164,7 @@ void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint6
                          const int* stop, const CtrlArgs* prev_ctrl, hipStream_t s);
 void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const uint64_t* xt, int nw64, const float* c,
                         float* ct, float* nbobs_k, float* in0, float* in1, float* inh_k, int* lastz, int* any1, float* center,
-                        float* iner, const int* stop, hipStream_t s, float* chk = nullptr);
+                        float* iner, const int* stop, hipStream_t s, float* chk = nullptr, int* fault = nullptr, int inject = 0);
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
                        const CtrlArgs* ctrl, hipStream_t s);
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s);

@@ -270,6 +270,9 @@ class ShardedNem:
     PIPE_DEPTH = 6       # whole iterations enqueued between host synchronisations
 
     def __init__(self, stepper, comm, n_total, beta, cvtest="clas", cvthres=1e-8, param_fix=False):
+        if cvtest not in ("none", "clas"):
+            raise ValueError("the sharded path implements the convergence tests 'none' and 'clas' only (got %r): the "
+                             "criterion is an i-ordered float sum over all families" % (cvtest,))
         self.st, self.comm = stepper, comm
         self.n_total = n_total
         self.blk, self.stride = slot_layout(n_total, comm.world, stepper.stats_words())
@@ -453,6 +456,8 @@ class ShardedNem:
 
     # ---- bench helpers
     def set_cvtest(self, name):
+        if name not in ("none", "clas"):
+            raise ValueError("the sharded path implements the convergence tests 'none' and 'clas' only (got %r)" % (name,))
         self.cvtest = name
         self.st.set_cvtest(name)
         self._graphs, self._seen = {}, set()      # kernel arguments are baked into captured batches

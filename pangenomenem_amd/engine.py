@@ -17,7 +17,7 @@ DISP = {"s__": 0, "sk_": 1, "s_d": 2, "skd": 3}
 PROP = {"p_": 0, "pk": 1}
 CVT = {"none": 0, "clas": 1, "crit": 2, "crit_logged": 3}
 TIE = {"libc": 0, "first": 1, "hash": 2}
-STATUS_OK, STATUS_W_EMPTYCLASS, STATUS_E_DEVICE = 0, 2, 9
+STATUS_OK, STATUS_W_EMPTYCLASS, STATUS_E_DEVICE, STATUS_E_INTERNAL = 0, 2, 9, 10
 
 
 class NemGpuError(RuntimeError):
@@ -62,6 +62,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     lib.nemgpu_last_error.restype = C.c_char_p
+    lib.nemgpu_default_device.argtypes = [C.POINTER(C.c_int)]
     lib.nemgpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.nemgpu_destroy.argtypes = [vp]
     lib.nemgpu_destroy.restype = None
@@ -131,6 +132,17 @@ def load_library():
 
 def device_count():
     return int(load_library().nemgpu_device_count())
+
+
+def default_device():
+    """The device a call that was not given one runs on (NEM_MI355X_DEVICE = index | auto, else the current HIP
+    device); raises in a forked child of a GPU-using process and on a malformed NEM_MI355X_DEVICE."""
+    lib = load_library()
+    dev = C.c_int(0)
+    rc = lib.nemgpu_default_device(C.byref(dev))
+    if rc != 0:
+        raise NemGpuError("nemgpu_default_device failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
+    return dev.value
 
 
 def _vp(a):
