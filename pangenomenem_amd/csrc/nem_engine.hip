@@ -679,6 +679,7 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         if (c.post && ncem && r0 == 0 && b == count - 1) {
             // (the sweep's final labels are in buffer Q, the out buffer of even rounds)
             c.a.post_on = 1; c.a.post_from_guess = (r % 2 == 1) ? 1 : 0; c.a.post_moved = c.post_moved ? 1 : 0;
+            c.a.post_skip_guess = c.a.post_from_guess;
             c.a.post_nw64 = e->nw64; c.a.post_mask = e->mask; c.a.post_flags = e->iter_flags(); c.a.post_ctrl = c.post_ctrl;
         }
         launch_sweep(c.a, ncem, e->stream);
@@ -687,12 +688,9 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
     return NEMGPU_OK;
 }
 
-int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false, const CtrlArgs* post_ctrl = nullptr,
-                  bool post_moved = false, int slot_base = 0, int rounds = 0)
+// the arguments every round of one sweep shares (takes the sweep's number)
+int sweep_setup(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value)
 {
-    c = SweepCtx();
-    c.slot_base = slot_base;
-    if (post_ctrl != nullptr && e->ncem()) { c.post = true; c.post_moved = post_moved; c.post_ctrl = *post_ctrl; }
     c.use_nei = e->has_graph && beta != 0.0f;
     c.multi = c.use_nei || e->libc();
     SweepArgs& a = c.a;
@@ -707,6 +705,16 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
         if (e->stop_ptr == nullptr) { int r = ensure_draw_window(e, e->draws, draw_need(e)); if (r) return r; }
         sweep_draw_args(e, a, e->stop_ptr == nullptr);
     }
+    return NEMGPU_OK;
+}
+
+int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = false, const CtrlArgs* post_ctrl = nullptr,
+                  bool post_moved = false, int slot_base = 0, int rounds = 0)
+{
+    c = SweepCtx();
+    c.slot_base = slot_base;
+    if (post_ctrl != nullptr && e->ncem()) { c.post = true; c.post_moved = post_moved; c.post_ctrl = *post_ctrl; }
+    { int r = sweep_setup(e, beta, c, id_by_value); if (r) return r; }
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
     return sweep_launch_rounds(e, c, c.multi ? (rounds > 0 ? rounds : e->round_batch) : 1);

@@ -571,7 +571,8 @@ struct FusedDensityArgs {
     const int* perm;
 };
 
-__device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
+// returns the family tile the block worked on, -1 when it had nothing to do
+__device__ __forceinline__ int density_fused_body(const FusedDensityArgs& a)
 {
     __shared__ float sVal[FD_MAXD];                      // inertia per organism, later epsilon per organism
     __shared__ double2 sT[FD_CH];
@@ -582,9 +583,9 @@ __device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
     __shared__ unsigned long long sTot2;
     __shared__ float sEps, sChain[2];
     __shared__ int sGeneral;
-    if (a.stop != nullptr && *a.stop) return;
+    if (a.stop != nullptr && *a.stop) return -1;
     int k, tile;
-    if (!density_tile(a.K, a.npad >> 8, tile, k)) return;
+    if (!density_tile(a.K, a.npad >> 8, tile, k)) return -1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = tile * 256 + tid;                      // i < npad by construction
     const int npad = a.npad, dpad = a.dpad, D = a.D, K = a.K;
@@ -790,6 +791,7 @@ __device__ __forceinline__ void density_fused_body(const FusedDensityArgs& a)
         }
     }
     density_store(a.perm, tile, tid, a.n, npad, k, dk, nul, pkd, logpk, a.pkfki, a.logpkfki);
+    return tile;
 }
 
 
@@ -871,9 +873,13 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
 __device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0, int* tally_out = nullptr)
 {
     __shared__ int s_last;
+    // What the last block reads of the others are FLAGS, all of them updated by device-scope atomics: every wave waits
+    // until its own are performed (vmcnt(0)), the block meets, one thread adds the arrival.  (A device-scope release
+    // fence here -- `buffer_wbl2`, the whole L2 written back -- cost microseconds per launch once every block did one;
+    // the last block's acquire fence below stays: it reads the flags with plain loads.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
     __syncthreads();
     if (threadIdx.x == 0 && tally_out == nullptr) {                // plain ticket: 32-bit counters
-        __threadfence();
         int last = 0;
         if (nblocks <= 32) {
             const int t = atomicAdd(ticket, 1);
@@ -885,16 +891,14 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0
             const int ng = (nblocks + gsz - 1) / gsz;
             const int members = min(gsz, nblocks - g * gsz);
             int* gc = ticket + 32 * (1 + g);
-            if (atomicAdd(gc, 1) == members - 1) {
+            if (atomicAdd(gc, 1) == members - 1) {                 // (the top arrival is issued once this one has returned)
                 *gc = 0;
-                __threadfence();
                 if (atomicAdd(ticket, 1) == ng - 1) { *ticket = 0; last = 1; }
             }
         }
         if (last) __threadfence();
         s_last = last;
     } else if (threadIdx.x == 0) {
-        __threadfence();
         using u64 = unsigned long long;
         const u64 mine = 1ull | ((u64)(unsigned)tally << 32);
         int last = 0;
@@ -914,7 +918,6 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0
             if ((int)(t & 0xffffffffull) == members - 1) {
                 *gc = 0;
                 const u64 gsum = (t >> 32) + (u64)(unsigned)tally;
-                __threadfence();
                 u64* tc = reinterpret_cast<u64*>(ticket);
                 const u64 tt = atomicAdd(tc, 1ull | (gsum << 32));
                 if ((int)(tt & 0xffffffffull) == ng - 1) { *tc = 0; last = 1; total = (tt >> 32) + gsum; }
@@ -982,7 +985,7 @@ constexpr int kFuzzyWaves = 4;                          // chains (waves) per bl
 constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
 
 template <int KT, bool NCEM, int BS>
-__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, const int nblk)
 {
     int fold_hint = 0;
     if (a.stop != nullptr) {
@@ -998,13 +1001,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
         if (!any) skip = true;
     }
     if (skip && !(NCEM && a.post_on)) {
-        if (a.publish_byte != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *a.publish_byte = 0;
+        if (a.publish_byte != nullptr && bx == 0 && threadIdx.x == 0) *a.publish_byte = 0;
         return;
     }
     __shared__ int s_nzero, s_first;
     __shared__ uint8_t s_lab[NCEM ? BS : 1];             // the block's labels while it iterates
     __shared__ uint64_t s_drew[BS / 64];                 // TIE_LIBC: per wave, which of its sites drew
-    const int i = blockIdx.x * BS + threadIdx.x;
+    const int i = bx * BS + threadIdx.x;
     const bool active = i < a.n_local;
     const int gi = a.lo + (active ? i : 0);
     const int K = KT > 0 ? KT : a.K;
@@ -1030,7 +1033,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
     // rounds: label changes run down the path inside one launch instead of one launch per hop.
     // ------------------------------------------------------------------------------------------
     const bool libc = a.tie_rule == NEMGPU_TIE_LIBC;
-    const int blk_lo = a.lo + blockIdx.x * BS;           // first label slot of this block
+    const int blk_lo = a.lo + bx * BS;           // first label slot of this block
     double pkf[KA];
 #pragma unroll
     for (int k = 0; k < KA; k++) if (k < K) pkf[k] = active && !skip ? a.pkfki[(size_t)k * a.npad + i] : 0.0;
@@ -1124,7 +1127,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
                             //   draws before the sweep + sites below it that drew in this sweep
                             if (lower_draws < 0) {
                                 lower_draws = 0;
-                                for (int b = 0; b < (int)blockIdx.x; b++) lower_draws += a.tie_cnt_guess[b];
+                                for (int b = 0; b < bx; b++) lower_draws += a.tie_cnt_guess[b];
                             }
                             int base = a.draw_base, tab0 = a.draw_tab0;
                             if (a.draw_ctl != nullptr) { base = a.draw_ctl[0]; tab0 = a.draw_ctl[1]; }
@@ -1171,8 +1174,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
         if (threadIdx.x == 0) {
             int cnt = 0;
             for (int w = 0; w < BS / 64; w++) cnt += (int)__popcll(s_drew[w]);
-            if (cnt != a.tie_cnt_guess[blockIdx.x]) changed = true;
-            a.tie_cnt_out[blockIdx.x] = cnt;
+            if (cnt != a.tie_cnt_guess[bx]) changed = true;
+            a.tie_cnt_out[bx] = cnt;
             if (cnt > 0) atomicAdd(&a.flags[FLAG_NTIES], cnt);
         }
     }
@@ -1232,7 +1235,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int nblk)
         if (active) {
             // (a round that skipped its sites and posts its own output reads that output back: not a case the
             //  engine enqueues, the verification round posts its guess)
-            lab = a.post_from_guess ? (my_guess & kLabMask) : (my_new != 255 ? my_new : ((int)a.lab_out[gi] & kLabMask));
+            // (a round that skipped its sites -- a round before it changed nothing -- has no output of its own: the
+            //  partition is in the sweep's first buffer, the guess of odd rounds and the output of even ones)
+            if (skip) lab = (a.post_skip_guess ? my_guess : (int)a.lab_out[gi]) & kLabMask;
+            else lab = a.post_from_guess ? (my_guess & kLabMask) : (my_new != 255 ? my_new : ((int)a.lab_out[gi] & kLabMask));
             if (a.post_moved) moved = (lab != my_old);
         }
         const int wave = i >> 6;
@@ -1319,7 +1325,7 @@ __device__ __forceinline__ void labels_post_body(int n_local, int lo, int K, int
 template <int R>
 __device__ __forceinline__ void mstep_counts_body(int K, int D, int nw64, const uint64_t* __restrict__ xt,
                                                   const uint64_t* __restrict__ mask, int* __restrict__ stats,
-                                                  const int* __restrict__ stop, const CtrlArgs& prev_ctrl, const int nblk)
+                                                  const int* __restrict__ stop, const CtrlArgs& prev_ctrl, const int bx, const int nblk)
 {
     // R organism rows per block (row D = the all-ones row that counts the class sizes): each class-mask word is
     // loaded once for R rows, so the masks' L2 traffic (K * N/8 bytes per block) shrinks by R
@@ -1328,12 +1334,12 @@ __device__ __forceinline__ void mstep_counts_body(int K, int D, int nw64, const 
     // last sweep round left it to us -- there it costs a last-block ticket, two device-wide atomic round trips at the
     // tail of the launch; here it runs beside the counting blocks.  They have read the stop word before it can be
     // raised, so the counts of an iteration that will not happen are computed once for nothing.
-    if (prev_ctrl.ctrl != nullptr && (int)blockIdx.x == nblk - 1) {
+    if (prev_ctrl.ctrl != nullptr && bx == nblk - 1) {
         if (threadIdx.x == 0) ctrl_logic(prev_ctrl);
         return;
     }
     if (stop != nullptr && *stop) return;
-    const int d0 = blockIdx.x * R;
+    const int d0 = bx * R;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t* rows[R];
 #pragma unroll
@@ -3102,12 +3108,12 @@ __global__ __launch_bounds__(1024) void k_finish(FinishArgs a) { finish_body(a, 
 __global__ __launch_bounds__(1024) void k_finish_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FinishArgs) finish_body(a, nblk); }
 __global__ __launch_bounds__(256) void k_density(DensityArgs a) { density_body(a); }
 __global__ __launch_bounds__(256) void k_density_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(DensityArgs) density_body(a); }
-__global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a) { density_fused_body(a); }
-__global__ __launch_bounds__(256) void k_density_fused_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FusedDensityArgs) density_fused_body(a); }
+__global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a) { (void)density_fused_body(a); }
+__global__ __launch_bounds__(256) void k_density_fused_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FusedDensityArgs) (void)density_fused_body(a); }
 template <int KT, bool NCEM, int BS>
-__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS>(a, gridDim.x); }
+__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS>(a, blockIdx.x, gridDim.x); }
 template <int KT, bool NCEM, int BS>
-__global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS>(a, nblk); }
+__global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS>(a, blockIdx.x, nblk); }
 __global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
 __global__ void k_ctrl_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CtrlArgs) ctrl_logic(a); }
 __global__ void k_labels_post(LabelsPostArgs a)
@@ -3122,13 +3128,13 @@ __global__ void k_labels_post_b(const void* arr, int stride, const int* gx)
 template <int R>
 __global__ __launch_bounds__(256) void k_mstep_counts(CountsArgs a)
 {
-    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, gridDim.x);
+    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, blockIdx.x, gridDim.x);
 }
 template <int R>
 __global__ __launch_bounds__(256) void k_mstep_counts_b(const void* arr, int stride, const int* gx)
 {
     NEM_B_HEAD(CountsArgs)
-    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, nblk);
+    mstep_counts_body<R>(a.K, a.D, a.nw64, a.xt, a.mask, a.stats, a.stop, a.prev_ctrl, blockIdx.x, nblk);
 }
 __global__ __launch_bounds__(64) void k_mstep_fuzzy_a(FuzzyArgs a)
 {

@@ -65,7 +65,9 @@ struct SweepArgs {
     // the last block) folded into the last enqueued round.  post_from_guess: the final labels are this round's
     // guess (a verification round: if it changes anything the loop control stops the pipeline and the host redoes
     // the bookkeeping), else this round's output.
-    int post_on, post_from_guess, post_moved, post_nw64;
+    // post_skip_guess: where the partition is when this round skips its sites (a round before it changed nothing):
+    // the sweep's first buffer -- this round's guess if it is an odd round, its output buffer if it is an even one
+    int post_on, post_from_guess, post_moved, post_nw64, post_skip_guess;
     uint64_t* post_mask; int* post_flags;
     CtrlArgs post_ctrl;
     // sharded runs: the last block to finish stores this rank's "some label changed in this round" byte behind
