@@ -13,6 +13,11 @@ and is NOT counted as steps.  The matrix has a U-shaped family-frequency spectru
 the three well-separated latent classes of SURVEY.md 8(d) NEM is at its fixed point after ONE iteration, which
 would time the cheapest path (--spectrum latent3 selects that generator).
 
+Timing: W warm-up steps, then `--repeats` (25) blocks of EXACTLY K steps, each bracketed by a barrier and a device
+synchronisation on both sides, maximum over ranks per block; `ms_per_step` / `value` come from the MEDIAN block,
+`ms_per_step_min` / `_max` give the spread (a block of 20 steps lasts under a millisecond: one scheduler hiccup
+would otherwise move the headline by double digits).
+
 N = 1 (default): BASELINE configs[1], 20 000 families x 500 organisms, K=3, beta=0.5, contiguity graph,
 ncem / sk_ / pk exactly as ppanggolin.py:1769-1826 calls nem().  The JSON line also carries `north_star_target`:
 the 50 000 x 1 000 problem of BASELINE.json's north_star on this GPU next to the compiled reference's own loop on
@@ -20,14 +25,21 @@ one host core, timed in the same run (--no-north-star skips it).
 
 N > 1: one process per GPU (torch.distributed over RCCL).  `python bench.py --gpus N` starts its own ranks
 (a torch.distributed.run child, before this process touches the GPU); under an existing launcher (RANK /
-WORLD_SIZE in the environment) it is one of the ranks.  Default: STRONG scaling of BASELINE configs[2] -- the
-fixed 50 000 x 1 000 problem, families sharded in contiguous blocks; --scaling weak gives every rank a
-configs[1]-sized shard instead.  Per EM iteration two all-gathers of the label blocks (one per relaxation round),
-the second of which also carries every rank's partial integer M-step statistics -- no separate all-reduce
-(pangenomenem_amd/distributed.py).
+WORLD_SIZE in the environment) it is one of the ranks.  --scaling selects what the N GPUs do:
+  strong   (default) BASELINE configs[2]: ONE 50 000 x 1 000 problem (--families / --organisms: any), families
+           sharded in contiguous blocks; per EM iteration two RCCL all-gathers of the label blocks (one per relaxation
+           round), the second also carrying every rank's partial integer M-step statistics -- no separate all-reduce
+           (pangenomenem_amd/distributed.py).  Rank 0 also times the same problem on ONE GPU in the same run
+           (`single_gpu_same_workload`);
+  weak     the same sharded EM with a configs[1]-sized shard per rank (one problem of N x 20 000 families);
+  replicas N independent configs[1]-sized problems, one per GPU, NO collective on the data path -- the reference's own
+           form of parallelism (one NEM problem per organism chunk, ppanggolin.py:1039-1095).
+An N > 1 line also carries `collective` (time of one all-gather, measured on the job's own path) and, unless
+--no-extras, `also`: the replicas figure and the strong-scaling figure of 200 000 x 5 000 (BASELINE configs[3]), the
+shape large enough for sharding to pay, each with its own single-GPU reference.
 
-Before the timed region every batch shape it will enqueue is captured into its hipGraph (independent of
---warmup); `graphs_primed` in the output asserts that nothing was captured or sent as plain launches while timing.
+Before a timed region every batch shape it will enqueue is captured into its hipGraph (independent of --warmup);
+`graphs_primed` in the output asserts that nothing was captured or sent as plain launches while timing.
 
 Rank 0 prints ONE JSON line.
 """
@@ -53,23 +65,26 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=25, help="timed blocks of --steps steps each (median reported)")
     ap.add_argument("--families", type=int, default=None,
-                    help="families: of the problem (1 GPU, strong scaling) or per GPU (weak scaling)")
+                    help="families: of the problem (1 GPU, strong scaling) or per GPU (weak scaling, replicas)")
     ap.add_argument("--organisms", type=int, default=None)
     ap.add_argument("--k", type=int, default=None,
                     help="classes (default 3); given: BASELINE configs[4], the K sweep -- 10-latent-group data, K-class .m, skd")
     ap.add_argument("--algo", default="ncem")
     ap.add_argument("--disper", default=None, help="dispersion model (default sk_, BASELINE's; skd for --k != 3)")
     ap.add_argument("--spectrum", default="ushape", choices=["ushape", "latent3"])
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak", "replicas"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: host-staged collectives, several ranks may share one GPU (rehearsal only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the `also` block (replicas, 200 000 x 5 000)")
+    ap.add_argument("--extras-strong-shape", default="200000x5000", help="families x organisms of the `also` block's strong-scaling problem")
     ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
     ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
-    ap.add_argument("--ns-cpu-iters", type=int, default=2, help="reference iterations timed at 50 000 x 1 000")
-    ap.add_argument("--ns-steps", type=int, default=220, help="GPU iterations timed at 50 000 x 1 000")
+    ap.add_argument("--ns-cpu-iters", type=int, default=4, help="reference iterations timed at 50 000 x 1 000")
+    ap.add_argument("--ns-steps", type=int, default=220, help="GPU iterations per block at 50 000 x 1 000")
     return ap.parse_args(argv)
 
 
@@ -123,6 +138,19 @@ def whole_iteration_bytes(n, d, k, nnz):
     return 2 * ((d + 31) // 32) * 4 * n + 12 * n * k + (8 * nnz + 4 * k * nnz + 4 * (n + 1)) + 16 * k * d
 
 
+def median(v):
+    s = sorted(v)
+    m = len(s) // 2
+    return s[m] if len(s) % 2 else 0.5 * (s[m - 1] + s[m])
+
+
+def timing_fields(blocks, steps):
+    """blocks: seconds of each timed block of `steps` steps (max over ranks already)"""
+    med = median(blocks)
+    return dict(ms_per_step=med * 1e3 / steps, repeats=len(blocks), ms_per_step_min=min(blocks) * 1e3 / steps,
+                ms_per_step_max=max(blocks) * 1e3 / steps, timed_region_s=sum(blocks)), med
+
+
 class EngineRun:
     """One problem resident on one GPU, timed the way the module docstring says."""
 
@@ -152,27 +180,42 @@ class EngineRun:
             done += m
         return rounds
 
-    def timed(self, steps, warmup):
-        eng = self.eng
+    def prime(self, steps, warmup):
         # every batch shape the warm-up and the timed region enqueue gets its hipGraph NOW, whatever --warmup is
         for m in sorted({self.cycle, steps % self.cycle, warmup % self.cycle} - {0}):
-            eng.restart_iterate(m)
+            self.eng.restart_iterate(m)
         self.run_steps(warmup)
-        c0 = eng.graph_counters()
+
+    def block(self, steps):
+        """one timed block: restart_iterate() synchronises the stream before returning"""
         t0 = time.perf_counter()
         rounds = self.run_steps(steps)
-        elapsed = time.perf_counter() - t0          # restart_iterate() synchronises the stream before returning
+        return time.perf_counter() - t0, rounds
+
+    def timed(self, steps, warmup, repeats, sync=None):
+        """sync(seconds) -> seconds: barrier + maximum over ranks around a block (multi-rank callers)"""
+        eng = self.eng
+        self.prime(steps, warmup)
+        c0 = eng.graph_counters()
+        blocks, rounds = [], 0
+        for _ in range(max(1, repeats)):
+            if sync is not None:
+                sync(None)
+            dt, r = self.block(steps)
+            blocks.append(sync(dt) if sync is not None else dt)
+            rounds += r
         c1 = eng.graph_counters()
-        restarts = (steps + self.cycle - 1) // self.cycle
+        total = steps * len(blocks)
+        restarts = len(blocks) * ((steps + self.cycle - 1) // self.cycle)
         info = dict(
             graphs_primed=(c1["captured"] == c0["captured"] and c1["plain"] == c0["plain"]),
             graph_replays_timed=c1["replayed"] - c0["replayed"],
             host_finished_sweeps_timed=c1["host_finished_sweeps"] - c0["host_finished_sweeps"],
             iters_to_converge=int(self.first["iters"]), cycle_iterations=self.cycle, run_status=int(self.first["status"]),
             # two initial sweeps per restart ride in the total; the rest are the iterations' own
-            sweep_rounds_per_iteration=(rounds - 2 * restarts) / max(steps, 1) if rounds else None,
+            sweep_rounds_per_iteration=(rounds - 2 * restarts) / max(total, 1) if rounds else None,
         )
-        return elapsed, info
+        return blocks, info
 
 
 def cpu_baseline(x, nei, k, prop, center, disp, beta, algo, disper, iters):
@@ -181,6 +224,7 @@ def cpu_baseline(x, nei, k, prop, center, disp, beta, algo, disper, iters):
     test off, minus a 0-iteration run (sort index + initial sweeps)."""
     from oracle import pyoracle
     n, d = x.shape
+    extra = {}
     if pyoracle.have_reference():
         ref = pyoracle.Reference()
         kw = dict(algo=algo, beta=beta, disper=disper, cvtest="none")
@@ -188,23 +232,27 @@ def cpu_baseline(x, nei, k, prop, center, disp, beta, algo, disper, iters):
         t1 = ref.classify(x, nei, k, prop, center, disp, it_max=iters, **kw)["seconds"]
         per_it = max(t1 - t0, 1e-9) / iters
         kind = "reference"
+        extra = dict(reference_wall_s_0_iterations=t0, reference_wall_s_n_iterations=t1, reference_iterations=iters)
     else:
         orc = pyoracle.Oracle()
         per_it = orc.run(x, nei, k, prop, center, disp, algo=algo, beta=beta, disper=disper, cvtest="none",
                          it_max=iters, tie="hash")["loop_seconds"] / iters
         kind = "port"
-    return dict(value=n * d / per_it, unit="cells/s", cores=1, kind=kind,
-                sample="%d EM iterations of the same %dx%d workload, convergence test off, loop time only "
-                       "(%.3f s/iteration); host has %d cores" % (iters, n, d, per_it, os.cpu_count() or 0),
-                em_iterations_per_sec=1.0 / per_it, seconds_per_iteration=per_it)
+    out = dict(value=n * d / per_it, unit="cells/s", cores=1, kind=kind,
+               sample="%d EM iterations of the same %dx%d workload, convergence test off, loop time only "
+                      "(%.3f s/iteration = the difference of a %d-iteration and a 0-iteration call of the reference's "
+                      "ClassifyByNem, divided by %d); host has %d cores" % (iters, n, d, per_it, iters, iters, os.cpu_count() or 0),
+               em_iterations_per_sec=1.0 / per_it, seconds_per_iteration=per_it)
+    out.update(extra)
+    return out
 
 
 def pmc_traffic(kernel, n_loc, d):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes
     (profiles/r0N_pmc_density.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this very command,
     FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, checked with a known-size read).  Only valid
     for the workload it was measured on; null otherwise."""
-    for name in ("r02_pmc_density.json", "r01_pmc_density.json"):
+    for name in ("r03_pmc_density.json", "r02_pmc_density.json", "r01_pmc_density.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -216,20 +264,57 @@ def pmc_traffic(kernel, n_loc, d):
     return None
 
 
-def roofline_block(prof, n_loc, d):
-    achieved = prof["algorithmic_bytes_per_launch"] / (prof["density_ms_avg"] * 1e-3) / 1e9 \
-        if prof["density_ms_avg"] > 0 else 0.0
+def rocprof_average_ms(kernel, n_loc, d):
+    """the committed `rocprofv3 --kernel-trace --stats` average of this kernel on this workload (profiles/
+    r03_kernel_averages.json, written by profiles/summarize.py from the kernel-stats CSVs), or null"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_kernel_averages.json")) as f:
+            rec = json.load(f)
+        for w in rec.get("workloads", []):
+            if w.get("families") == n_loc and w.get("organisms") == d:
+                for name, v in w.get("kernels", {}).items():
+                    if name.startswith(kernel):
+                        return v["avg_ms"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def roofline_block(kernels, n_loc, d):
+    """kernels: engine.profile_kernels() -- {E1, one relaxation round, M-step counts}, each timed live with HIP events
+    around a string of back-to-back launches on the engine's stream (no event pair per launch).  The block's own fields
+    are the dominant kernel's (E1, the longest launch of the iteration); `kernels` lists all three."""
+    rows = []
+    for kr in kernels:
+        ach = kr["algorithmic_bytes_per_launch"] / (kr["avg_launch_ms"] * 1e-3) / 1e9 if kr["avg_launch_ms"] > 0 else 0.0
+        rows.append(dict(kernel=kr["kernel"], what=kr["what"], algorithmic_bytes_per_launch=kr["algorithmic_bytes_per_launch"],
+                         avg_launch_ms=kr["avg_launch_ms"], launches_timed=kr["launches_timed"], achieved=ach, unit="GB/s",
+                         frac=ach / HBM_PEAK_GBS, rocprof_avg_launch_ms=rocprof_average_ms(kr["kernel"], n_loc, d),
+                         traffic=pmc_traffic(kr["kernel"], n_loc, d)))
+    e1 = rows[0]
     return {
         "bound": "hbm",
-        "kernel": prof.get("kernel", "k_density") + " (E1 Bernoulli log-density chains)",
-        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic(prof.get("kernel", "k_density"), n_loc, d),
-        "algorithmic_bytes_per_launch": prof["algorithmic_bytes_per_launch"],
-        "avg_launch_ms": prof["density_ms_avg"], "launches_timed": prof["density_launches"],
-        "note": "HBM is the nominal bound (SURVEY.md 8d: bit scans, no dense contraction, no MFMA). The kernel is a "
-                "dependent chain per (family, class) that the reference's float rounding forbids re-associating; "
-                "one launch at configs[1] moves 2 MB (0.26 us at peak) and is latency-bound, see DESIGN.md section 4",
+        "kernel": e1["kernel"] + " (" + e1["what"] + ")",
+        "achieved": e1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e1["frac"],
+        "traffic": e1["traffic"],
+        "algorithmic_bytes_per_launch": e1["algorithmic_bytes_per_launch"],
+        "avg_launch_ms": e1["avg_launch_ms"], "launches_timed": e1["launches_timed"],
+        "kernels": rows,
+        "note": "HBM is the nominal bound (SURVEY.md 8d: bit scans, no dense contraction, no MFMA). E1 is a dependent "
+                "chain per (family, class) that the reference's float rounding forbids re-associating; a launch at "
+                "configs[1] moves 2 MB (0.26 us at peak) and is latency-bound, as are the sweep rounds and the counts "
+                "(DESIGN.md section 4). Durations: HIP events around back-to-back launches; rocprof_avg_launch_ms: the "
+                "committed rocprofv3 kernel-trace average of the same kernel on the same workload",
     }
+
+
+def kernel_probe(eng, reps=50):
+    try:
+        return eng.profile_kernels(reps)
+    except Exception:                                      # fuzzy / sharded engines: E1 alone
+        p = eng.profile_density(reps)
+        return [dict(kernel=p["kernel"], what="E1: Bernoulli log-density chains", avg_launch_ms=p["density_ms_avg"],
+                     algorithmic_bytes_per_launch=p["algorithmic_bytes_per_launch"], launches_timed=p["density_launches"])]
 
 
 def north_star_target(args):
@@ -239,14 +324,17 @@ def north_star_target(args):
     x, nei, prop, center, disp, disper, what = make_workload(n, d, k, args.spectrum, 3)
     run = EngineRun(x, nei, k, prop, center, disp, "ncem", beta, disper)
     steps = max(run.cycle, (args.ns_steps // run.cycle) * run.cycle)
-    elapsed, info = run.timed(steps, run.cycle)
-    prof = run.eng.profile_density(50)
-    ms_it = elapsed * 1e3 / steps
+    blocks, info = run.timed(steps, run.cycle, min(args.repeats, 9))
+    tf, med = timing_fields(blocks, steps)
+    roof = roofline_block(kernel_probe(run.eng), n, d)
+    ms_it = tf["ms_per_step"]
     out = {
         "workload": "50000 families x 1000 organisms, K=3, beta=0.5, contiguity graph, ncem/sk_/pk; " + what,
         "gpu_ms_per_iteration": ms_it, "gpu_em_iterations_per_sec": 1e3 / ms_it,
-        "gpu_cells_per_sec": n * d * 1e3 / ms_it, "gpu_steps_timed": steps,
-        "e1_roofline_frac": roofline_block(prof, n, d)["frac"], "e1_avg_launch_ms": prof["density_ms_avg"],
+        "gpu_cells_per_sec": n * d * 1e3 / ms_it, "gpu_steps_per_block": steps, "gpu_blocks": tf["repeats"],
+        "gpu_ms_per_iteration_min": tf["ms_per_step_min"], "gpu_ms_per_iteration_max": tf["ms_per_step_max"],
+        "e1_roofline_frac": roof["frac"], "e1_avg_launch_ms": roof["avg_launch_ms"],
+        "kernels": [{kk: r[kk] for kk in ("kernel", "avg_launch_ms", "frac")} for r in roof["kernels"]],
         "whole_iteration_algorithmic_GBps": whole_iteration_bytes(n, d, k, int(nei[0][-1])) / (ms_it * 1e-3) / 1e9,
         "target_speedup": 50.0,
     }
@@ -255,12 +343,103 @@ def north_star_target(args):
     try:
         cpu = cpu_baseline(x, nei, k, prop, center, disp, beta, "ncem", disper, args.ns_cpu_iters)
         out["reference_cpu_seconds_per_iteration"] = cpu["seconds_per_iteration"]
-        out["reference_cpu"] = {kk: cpu[kk] for kk in ("kind", "cores", "sample")}
+        out["reference_cpu"] = {kk: cpu[kk] for kk in ("kind", "cores", "sample", "reference_wall_s_0_iterations",
+                                                       "reference_wall_s_n_iterations", "reference_iterations") if kk in cpu}
         out["speedup_vs_reference_cpu"] = cpu["seconds_per_iteration"] * 1e3 / ms_it
         out["meets_target"] = bool(out["speedup_vs_reference_cpu"] >= 50.0)
     except Exception as exc:
         out["reference_cpu"] = {"kind": "unavailable", "sample": "failed: %r" % (exc,)}
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# multi-rank pieces
+# ----------------------------------------------------------------------------------------------------------------
+class Ranks:
+    """barrier + device synchronisation + maximum over ranks, the bracket of every timed block"""
+
+    def __init__(self, args, rank, world, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.on_gpu = args.backend == "nccl"
+
+    def sync(self, seconds):
+        """seconds None: the bracket ahead of a block; else: the bracket behind it, returns the maximum over ranks"""
+        self.torch.cuda.synchronize()
+        if seconds is None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+            return None
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda" if self.on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device="cuda" if self.on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def sharded_run(args, ranks, n_tot, d, k, beta, seed, steps, warmup, repeats, want_solo):
+    """ONE n_tot x d problem sharded over the ranks: timed blocks (max over ranks each), the job's facts, and -- rank 0,
+    want_solo -- the same problem on one GPU in the same run."""
+    from pangenomenem_amd import distributed as nd
+    rank, world, device = ranks.rank, ranks.world, ranks.device
+    job = nd.ShardedNem.synthetic(n_tot, d, k, beta, rank, world, device, algo=args.algo, spectrum=args.spectrum, seed=seed)
+    cycle = job.iters_to_converge()
+    steps = max(steps, 1)
+    # every batch shape of the timed region goes through the driver once or twice before the clock starts
+    # (its graph, where graphs are on, is captured the second time a shape is seen)
+    for m in sorted({cycle, steps % cycle, warmup % cycle} - {0}):
+        job.run_steps(2 * m, m)
+    job.run_steps(warmup, cycle)
+    blocks = []
+    for _ in range(max(1, repeats)):
+        ranks.sync(None)
+        t0 = time.perf_counter()
+        job.run_steps(steps, cycle)
+        ranks.torch.cuda.synchronize()
+        blocks.append(ranks.sync(time.perf_counter() - t0))
+    coll = job.time_collective(100)
+    stride_bytes = int(job.stride)
+    facts = dict(iters_to_converge=cycle, cycle_iterations=cycle, native_rccl=bool(job.native), rccl_ranks=job.eng.rccl_ranks(),
+                 backend=args.backend, batch_graphs=bool(job.use_graphs),
+                 collective=dict(what="in-place all-gather of the ranks' label blocks (labels, flag bytes, int32 M-step statistics)",
+                                 bytes_per_rank=stride_bytes, per_allgather_ms=coll * 1e3, per_iteration=2,
+                                 per_iteration_ms=2 * coll * 1e3, how="100 back-to-back all-gathers between one pair of HIP events"
+                                 if job.native else "100 all-gathers through torch.distributed, wall clock"))
+    kernels = kernel_probe(job.eng)
+    n_loc = job.hi - job.lo
+    solo = None
+    if want_solo and rank == 0:
+        try:
+            x1, nei1, p1, c1, d1, _, _ = make_workload(n_tot, d, k, args.spectrum, seed)
+            one = EngineRun(x1, nei1, k, p1, c1, d1, args.algo, beta, "sk_", device=device)
+            st = max(one.cycle, (min(steps, 220) // one.cycle) * one.cycle)
+            b1, _ = one.timed(st, one.cycle, min(repeats, 9))
+            tf1, med1 = timing_fields(b1, st)
+            solo = dict(ms_per_step=tf1["ms_per_step"], value=n_tot * d * st / med1, em_iterations_per_sec=st / med1, steps=st,
+                        repeats=tf1["repeats"], ms_per_step_min=tf1["ms_per_step_min"], ms_per_step_max=tf1["ms_per_step_max"])
+            one.eng.close()
+            del x1
+        except Exception as exc:
+            solo = {"error": repr(exc)}
+    if want_solo and world > 1:
+        ranks.dist.barrier()
+    return blocks, facts, kernels, n_loc, solo
+
+
+def replicas_run(args, ranks, n, d, k, beta, steps, warmup, repeats):
+    """N independent problems, one per GPU, no collective on the data path (the barrier brackets the timed blocks only):
+    every rank solves its own n x d problem -- another seed, another chunk of organisms."""
+    x, nei, prop, center, disp, disper, what = make_workload(n, d, k, args.spectrum, 2 + ranks.rank)
+    run = EngineRun(x, nei, k, prop, center, disp, args.algo, beta, args.disper or disper, device=ranks.device)
+    blocks, info = run.timed(steps, warmup, repeats, sync=ranks.sync)
+    solves = ranks.sum(steps / run.cycle)                 # whole solves all ranks complete per block
+    kernels = kernel_probe(run.eng)
+    run.eng.close()
+    return blocks, info, kernels, solves, what
 
 
 def main():
@@ -281,25 +460,26 @@ def main():
     from pangenomenem_amd import build as nem_build
     ksweep = args.k is not None
     k, beta = (args.k if ksweep else 3), 0.5
-    sharded = world > 1 or args.dist
+    multi = world > 1 or args.dist
     if args.disper is None:
         args.disper = "skd" if ksweep else "sk_"
-    if sharded and ksweep:
-        raise SystemExit("the sharded path benchmarks K = 3 (BASELINE configs[2])")
+    if multi and ksweep:
+        raise SystemExit("the multi-GPU modes benchmark K = 3")
+    extra, also = {}, None
 
-    if not sharded:
+    if not multi:
         nem_build.build()                          # no-op when the in-tree library is up to date
         n_tot, d = args.families or 20000, args.organisms or 500
         x, nei, prop, center, disp, _, what = make_workload(n_tot, d, k, args.spectrum, 2, ksweep)
         run = EngineRun(x, nei, k, prop, center, disp, args.algo, beta, args.disper)
-        dt_max, extra = run.timed(args.steps, args.warmup)
-        # E1 kernel duration: HIP events on the engine's stream around individual launches, on the state the
-        # timed region just left (the timed region itself replays captured graphs, which carry no events)
-        prof = run.eng.profile_density(100)
+        blocks, extra = run.timed(args.steps, args.warmup, args.repeats)
+        # kernel durations: HIP events on the engine's stream around strings of launches, on the state the timed region
+        # just left (the timed region itself replays captured graphs, which carry no events)
+        kernels = kernel_probe(run.eng)
         n_loc, nnz = n_tot, int(nei[0][-1])
         scaling, parallelism = "weak", "1 GPU"
+        steps_total = args.steps
     else:
-        from pangenomenem_amd import distributed as nd
         import torch
         import torch.distributed as dist
         ndev = torch.cuda.device_count()
@@ -314,72 +494,84 @@ def main():
         if rank == 0:                             # one rank checks / rebuilds the library, the others wait for it
             nem_build.build()
         dist.barrier()
-        if args.scaling == "strong":
-            n_tot, d = args.families or 50000, args.organisms or 1000
-            seed = 3 if (n_tot, d) == (50000, 1000) else 2
-        else:
-            d = args.organisms or 500
-            n_tot, seed = (args.families or 20000) * world, 2
+        ranks = Ranks(args, rank, world, device)
         what = make_workload(64, 32, 3, args.spectrum, 1)[6]
-        job = nd.ShardedNem.synthetic(n_tot, d, k, beta, rank, world, device, algo=args.algo,
-                                      spectrum=args.spectrum, seed=seed)
-        cycle = job.iters_to_converge()
-        # every batch shape of the timed region goes through the driver once or twice before the clock starts
-        # (its graph, where graphs are on, is captured the second time a shape is seen)
-        for m in sorted({cycle, args.steps % cycle, args.warmup % cycle} - {0}):
-            job.run_steps(2 * m, m)
-        job.run_steps(args.warmup, cycle)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        job.run_steps(args.steps, cycle)
-        torch.cuda.synchronize()
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
-        prof = job.eng.profile_density(100)
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        n_loc = job.hi - job.lo
-        nnz = int(2.1 * n_tot)
-        scaling = args.scaling if world > 1 else "weak"
-        extra = dict(iters_to_converge=cycle, cycle_iterations=cycle, native_rccl=bool(job.native),
-                     rccl_ranks=job.eng.rccl_ranks(), backend=args.backend,
-                     batch_graphs=bool(job.use_graphs))
-        if world > 1 and args.scaling == "strong" and rank == 0:
-            # the same problem on ONE GPU, same run: what the strong-scaling values are to be compared with (the
-            # N = 1 default of this script is configs[1], another problem)
-            try:
-                x1, nei1, p1, c1, d1, _, _ = make_workload(n_tot, d, k, args.spectrum, seed)
-                solo = EngineRun(x1, nei1, k, p1, c1, d1, args.algo, beta, "sk_", device=device)
-                st = max(solo.cycle, (min(args.steps, 220) // solo.cycle) * solo.cycle)
-                t1, _ = solo.timed(st, solo.cycle)
-                extra["single_gpu_same_workload"] = dict(ms_per_step=t1 * 1e3 / st, value=n_tot * d * st / t1,
-                                                         em_iterations_per_sec=st / t1, steps=st)
-                extra["speedup_vs_single_gpu_same_workload"] = (t1 / st) / (dt_max / args.steps)
-                solo.eng.close()
-            except Exception as exc:
-                extra["single_gpu_same_workload"] = {"error": repr(exc)}
-        if world > 1:
-            dist.barrier()
-        parallelism = ("families sharded over %d GPUs in contiguous blocks (%s scaling); per EM iteration two RCCL "
-                       "all-gathers of the label blocks, the second also carrying the ranks' int32 M-step statistics"
-                       % (world, scaling)) if world > 1 else "1 GPU through the sharded driver"
+        if args.scaling == "replicas":
+            n_loc, d = args.families or 20000, args.organisms or 500
+            n_tot = n_loc * world
+            blocks, extra, kernels, solves, what = replicas_run(args, ranks, n_loc, d, k, beta, args.steps, args.warmup, args.repeats)
+            nnz = int(2.1 * n_tot)
+            extra.update(whole_solves_per_block=solves, rccl_ranks=0, backend=args.backend,
+                         collective=dict(what="none on the data path (independent problems); a barrier brackets each timed block",
+                                         per_iteration=0, per_iteration_ms=0.0))
+            scaling = "weak"
+            parallelism = ("%d independent %d x %d problems, one per GPU, no collective on the data path (the reference's own "
+                           "parallel form: one NEM problem per organism chunk, ppanggolin.py:1039-1095)" % (world, n_loc, d))
+        else:
+            if args.scaling == "strong":
+                n_tot, d = args.families or 50000, args.organisms or 1000
+                seed = 3 if (n_tot, d) == (50000, 1000) else 2
+            else:
+                d = args.organisms or 500
+                n_tot, seed = (args.families or 20000) * world, 2
+            blocks, extra, kernels, n_loc, solo = sharded_run(args, ranks, n_tot, d, k, beta, seed, args.steps, args.warmup,
+                                                              args.repeats, want_solo=(world > 1 and args.scaling == "strong"))
+            nnz = int(2.1 * n_tot)
+            scaling = args.scaling if world > 1 else "weak"
+            if solo is not None:
+                extra["single_gpu_same_workload"] = solo
+                if "ms_per_step" in solo:
+                    extra["speedup_vs_single_gpu_same_workload"] = solo["ms_per_step"] / (median(blocks) * 1e3 / args.steps)
+            parallelism = ("families sharded over %d GPUs in contiguous blocks (%s scaling); per EM iteration two RCCL "
+                           "all-gathers of the label blocks, the second also carrying the ranks' int32 M-step statistics"
+                           % (world, scaling)) if world > 1 else "1 GPU through the sharded driver"
+            # ---- what else N GPUs can do with this path, in the same run
+            if world > 1 and not args.no_extras:
+                also = {}
+                try:
+                    b2, i2, _, solves, _ = replicas_run(args, ranks, 20000, 500, k, beta, max(args.steps, 140), 14, min(args.repeats, 9))
+                    st2 = max(args.steps, 140)
+                    tf2, med2 = timing_fields(b2, st2)
+                    also["replicas_20000x500_per_gpu"] = dict(
+                        value=world * 20000 * 500 * st2 / med2, unit="cells/s", ms_per_step=tf2["ms_per_step"],
+                        whole_solves_per_sec=solves / med2, scaling="weak", collectives_per_iteration=0,
+                        repeats=tf2["repeats"], ms_per_step_min=tf2["ms_per_step_min"], ms_per_step_max=tf2["ms_per_step_max"],
+                        note="N independent configs[1]-sized problems, one per GPU; the N = 1 default line of this script is the one-GPU figure")
+                except Exception as exc:
+                    also["replicas_20000x500_per_gpu"] = {"error": repr(exc)}
+                n3, d3 = (int(v) for v in args.extras_strong_shape.lower().split("x"))
+                if (n_tot, d) != (n3, d3):
+                    try:
+                        st3 = 60
+                        b3, f3, _, _, solo3 = sharded_run(args, ranks, n3, d3, k, beta, 2, st3, 6, min(args.repeats, 7), want_solo=True)
+                        tf3, med3 = timing_fields(b3, st3)
+                        rec = dict(value=float(n3) * d3 * st3 / med3, unit="cells/s", ms_per_step=tf3["ms_per_step"], scaling="strong",
+                                   families=n3, organisms=d3,
+                                   repeats=tf3["repeats"], ms_per_step_min=tf3["ms_per_step_min"], ms_per_step_max=tf3["ms_per_step_max"],
+                                   collective=f3["collective"], rccl_ranks=f3["rccl_ranks"], single_gpu_same_workload=solo3)
+                        if solo3 and "ms_per_step" in solo3:
+                            rec["speedup_vs_single_gpu_same_workload"] = solo3["ms_per_step"] / tf3["ms_per_step"]
+                        also["strong_%dx%d" % (n3, d3)] = rec
+                    except Exception as exc:
+                        also["strong_%dx%d" % (n3, d3)] = {"error": repr(exc)}
+        steps_total = args.steps
 
     if rank == 0:
-        ms_per_step = dt_max * 1e3 / args.steps
-        cells_per_s = n_tot * d * args.steps / dt_max
+        tf, med = timing_fields(blocks, steps_total)
+        cells_per_s = n_tot * d * steps_total / med
         shape = ("BASELINE configs[4] (K sweep)" if (n_tot, d) == (20000, 500) and args.disper == "skd" else "custom model") \
             if ksweep else (SHAPES.get((n_tot, d), "custom shape") if args.disper == "sk_" else "custom model")
         out = {
             "metric": "em_family_x_organism_cells_per_sec",
             "value": cells_per_s,
             "unit": "cells/s",
-            "em_iterations_per_sec": args.steps / dt_max,
+            "em_iterations_per_sec": steps_total / med,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": tf["ms_per_step"],
+            "repeats": tf["repeats"], "ms_per_step_min": tf["ms_per_step_min"], "ms_per_step_max": tf["ms_per_step_max"],
+            "timed_region_s": tf["timed_region_s"],
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -392,12 +584,13 @@ def main():
                 "cycle_iterations": extra["cycle_iterations"],
                 "parallelism": parallelism,
             },
-            "roofline": roofline_block(prof, n_loc, d),
+            "roofline": roofline_block(kernels, n_loc, d),
         }
-        out["roofline"]["whole_iteration_algorithmic_GBps"] = \
-            whole_iteration_bytes(n_tot, d, k, nnz) * args.steps / dt_max / 1e9
+        out["roofline"]["whole_iteration_algorithmic_GBps"] = whole_iteration_bytes(n_tot, d, k, nnz) * steps_total / med / 1e9
         out.update(extra)
-        if not sharded and not args.no_cpu_baseline:
+        if also is not None:
+            out["also"] = also
+        if not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(x, nei, k, prop, center, disp, beta, args.algo, args.disper,
                                                    args.cpu_iters)
@@ -405,7 +598,7 @@ def main():
             except Exception as exc:   # the checker is optional on the box; the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 1, "kind": "unavailable",
                                        "sample": "failed: %r" % (exc,)}
-        if not sharded and not args.no_north_star and not ksweep:
+        if not multi and not args.no_north_star and not ksweep:
             try:
                 run.eng.close()
                 out["north_star_target"] = north_star_target(args)
@@ -414,7 +607,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if sharded:
+    if multi:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -217,7 +217,9 @@ int nemgpu_criteria_previous(nemgpu_engine* e, float crit6[6]);
    nemgpu_shard_end the loop tests run on the device, as in the single-GPU pipelined loop.
 
    Label arrays are uint8[world * stride]: rank r owns slots [r*stride, r*stride + blk) (its families,
-   in order); the byte at r*stride + blk carries its "a label changed in this round" flag and, further
+   in order); the byte at r*stride + blk carries its "a label changed in this round" flag, the byte behind it "one
+   of my labels moved in this sweep" (the verifying round's, or round 0's when there are no neighbours to verify
+   against: every rank then runs the convergence test on the gathered bytes) and, further
    behind (4-byte aligned, the driver picks the offset), its partial M-step statistics, so ONE
    all-gather per relaxation round moves labels, flags and statistics together -- there is no separate
    all-reduce.  The engine is created with n_total = world*stride, site_lo = rank*stride,
@@ -238,6 +240,13 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
                               const uint8_t* labels_old_dev, uint8_t* labels_out_dev);
 int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
                               const uint8_t* labels_guess_dev, uint8_t* labels_out_dev);
+/* round 1 and nemgpu_shard_counts(stats_dev) together: one launch where the shape has a kernel for it (the two do not
+   depend on each other), else the two launches */
+int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                                     const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* stats_dev);
+/* nemgpu_shard_begin for a batch that starts the run over: nemgpu_reset, the cleared loop control and the density
+   tables in one launch */
+int nemgpu_shard_begin_restart(nemgpu_engine* e);
 int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, const uint8_t* labels_old_dev,
                                   const uint8_t* labels_q_dev, const uint8_t* labels_r_dev);
 int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
@@ -305,6 +314,14 @@ int nemio_write_mf(const char* path, const float crit6[6], float beta, int d, in
    algorithmic bytes one launch moves. */
 int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* algorithmic_bytes_per_launch,
                            int* used_fused_kernel);
+/* The same for the three kernels of a solo NCEM iteration -- {E1, one relaxation round of the E-step sweep, the M-step
+   counts} -- each launched `reps` times back to back between ONE pair of HIP events (an event pair per launch costs as
+   much as the shorter kernels).  avg_ms[3], bytes[3]; which[0] = 1 when E1 is the fused kernel.  The engine's partition
+   is not advanced. */
+int nemgpu_profile_kernels(nemgpu_engine* e, int reps, double avg_ms[3], double bytes[3], int which[1]);
+/* `reps` in-place all-gathers of the sharded EM's label blocks through the engine's own communicator between one pair
+   of HIP events: the cost of ONE of an iteration's two collectives.  Collective over the job's ranks. */
+int nemgpu_rccl_time_allgather(nemgpu_engine* e, uint8_t* buf_dev, int reps, double* avg_ms);
 /* FETCH_SIZE calibration helper: `reps` launches reading `bytes` of device memory 16 bytes per lane (E1's
    pattern); run under `rocprofv3 --pmc FETCH_SIZE` and compare with the known byte count (profiles/README.md). */
 int nemgpu_calibrate_fetch(size_t bytes, int reps);

@@ -2882,9 +2882,23 @@ void shard_sweep_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id)
     a.fold_ticket = e->sweep_next + 32;
 }
 uint8_t* own_flag_byte(nemgpu_engine* e, uint8_t* labels) { return labels + (size_t)e->sh_rank * e->sh_stride + e->sh_blk; }
+void shard_round1_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                       const uint8_t* labels_guess_dev, uint8_t* labels_out_dev)
+{
+    shard_sweep_args(e, a, beta, sweep_id);
+    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
+    a.flags = e->round_flags(1);
+    a.flags_in = labels_guess_dev + e->sh_blk;                     // rank 0's flag byte; stride = slot_stride
+    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
+    // the verifying round also says whether one of THIS rank's labels moved in the sweep (its guess against the old
+    // partition): the byte behind its flag byte, gathered with it -- the convergence test then needs no pass over the
+    // whole label array on every rank
+    a.post_on = 1; a.post_from_guess = 1; a.post_skip_guess = 1; a.post_moved = 1; a.post_no_masks = 1;
+    a.post_nw64 = e->nw64; a.post_mask = e->mask; a.post_flags = e->iter_flags();
+}
 }  // namespace
 
-int nemgpu_shard_begin(nemgpu_engine* e)
+static int shard_check(nemgpu_engine* e)
 {
     if (!e) return NEMGPU_E_FUNCARG;
     if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
@@ -2896,9 +2910,37 @@ int nemgpu_shard_begin(nemgpu_engine* e)
         set_error("the family-sharded path implements the convergence tests none and clas only");
         return NEMGPU_E_FUNCARG;
     }
+    return NEMGPU_OK;
+}
+
+int nemgpu_shard_begin(nemgpu_engine* e)
+{
+    { const int cr = shard_check(e); if (cr) return cr; }
     HIPCHK(hipSetDevice(e->device));
     { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
+    e->stop_ptr = e->ctrl() + C_STOP;
+    return NEMGPU_OK;
+}
+
+// nemgpu_shard_begin for a batch that starts a run over: the reset (initial parameters back in place), the clearing of
+// the loop control and the density tables in ONE launch (the head of the single engine's restart batches, enqueue_init)
+// instead of a device-to-device copy, three fills and a tables launch
+int nemgpu_shard_begin_restart(nemgpu_engine* e)
+{
+    { const int cr = shard_check(e); if (cr) return cr; }
+    if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    if ((r = reset_state(e, true))) return r;                      // host half; the device half is the launch below
+    e->reset_pending = false;
+    if ((r = clear_fault(e))) return r;
+    FinishArgs t = finish_args(e, 0, nullptr);
+    t.reset_prop = e->prop0; t.reset_center = e->center0; t.reset_disp = e->disp0;
+    t.reset_ctrl = e->ctrl(); t.reset_ctrl_words = C_WORDS; t.reset_sweep_next = e->sweep_next;
+    launch_finish(t, e->stream);
+    HIPCHK(hipGetLastError());
+    e->tables_fresh = true; e->density_fresh = false;
     e->stop_ptr = e->ctrl() + C_STOP;
     return NEMGPU_OK;
 }
@@ -2958,20 +3000,23 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
             e->tables_fresh = true;
             e->density_fresh = false;
         } else if ((r = do_tables(e))) return r;
-        if (e->density_fresh) { if ((r = clear_sweep_flags(e))) return r; }   // same parameters as the last E1: keep pkfki
+        if (e->density_fresh) { if (!e->flags_clean && (r = clear_sweep_flags(e))) return r; }   // same parameters as the last E1: keep pkfki
         else if ((r = do_density(e))) return r;                    // also clears MOVED + the round flag window
     }
+    // the blind sweep of a start (beta = 0, sweep 0, the parameters as given): a flag slot of its own and no "moved"
+    // flag, so that the sweep behind it -- same densities -- needs no clearing of the flags in between
+    const bool blind = stats_dev == nullptr && sweep_id == 0 && beta == 0.0f;
     SweepArgs a;
     shard_sweep_args(e, a, beta, sweep_id);
     a.lab_old = labels_old_dev; a.lab_guess = labels_old_dev; a.lab_out = labels_out_dev;
-    a.flags = e->round_flags(0);
+    a.flags = e->round_flags(blind ? kRoundCap - 1 : 0);
     // the same launch builds the class masks of its output (for nemgpu_shard_counts) and publishes the flag byte
-    a.post_on = 1; a.post_from_guess = 0; a.post_moved = 0; a.post_nw64 = e->nw64; a.post_mask = e->mask;
-    a.post_flags = e->iter_flags();
+    a.post_on = 1; a.post_from_guess = 0; a.post_moved = blind ? 0 : 1; a.post_nw64 = e->nw64; a.post_mask = e->mask;
+    a.post_flags = e->iter_flags();                                // ("moved" byte: final when this is the sweep's only round)
     a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
-    e->flags_clean = false;
+    e->flags_clean = blind && e->flags_clean;
     return NEMGPU_OK;
 }
 
@@ -2983,12 +3028,25 @@ int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const 
     if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     SweepArgs a;
-    shard_sweep_args(e, a, beta, sweep_id);
-    a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
-    a.flags = e->round_flags(1);
-    a.flags_in = labels_guess_dev + e->sh_blk;                     // rank 0's flag byte; stride = slot_stride
-    a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
+    shard_round1_args(e, a, beta, sweep_id, labels_old_dev, labels_guess_dev, labels_out_dev);
     launch_sweep(a, true, e->stream);
+    HIPCHK(hipGetLastError());
+    return NEMGPU_OK;
+}
+
+// relaxation round 1 and this rank's partial counts of round 0's labels (nemgpu_shard_counts) in ONE launch where the
+// shape has such a kernel (k_sweep_counts), else one after the other: the two do not depend on each other
+int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
+                                     const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* stats_dev)
+{
+    if (!e || !labels_old_dev || !labels_guess_dev || !labels_out_dev || !stats_dev) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    SweepArgs a;
+    shard_round1_args(e, a, beta, sweep_id, labels_old_dev, labels_guess_dev, labels_out_dev);
+    if (!launch_sweep_counts(a, e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream)) {
+        launch_sweep(a, true, e->stream);
+        launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
+    }
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -3005,8 +3063,11 @@ int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, con
     ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.q_flags = labels_q_dev + e->sh_blk; ca.r_flags = labels_r_dev + e->sh_blk;
     ca.n_ranks = e->sh_world; ca.flag_stride = e->sh_stride; ca.is_init = is_init;
-    launch_moved_global(e->n_true, e->sh_blk, e->sh_stride, labels_q_dev, labels_old_dev, e->iter_flags(), e->stop_ptr,
-                        &ca, e->stream);
+    if (is_init) ca.blind = e->round_flags(kRoundCap - 1);         // (the blind sweep's zero-density tally)
+    // every rank's "one of my labels moved" byte came with the gather of the sweep's last round: round 1's, or -- no
+    // neighbours to verify against (beta = 0) -- round 0's
+    ca.moved_bytes = is_init ? 0 : (beta != 0.0f ? 1 : 2);
+    launch_ctrl(ca, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
 }
@@ -3155,6 +3216,7 @@ int nemgpu_rccl_ranks(const nemgpu_engine* e)
 namespace {
 int rccl_allgather_blocks(nemgpu_engine* e, uint8_t* buf)
 {
+    if (e->sh_world == 1) return NEMGPU_OK;                        // (a rank alone holds every block already)
     const size_t stride = (size_t)e->sh_stride;
     int rc = g_rccl.all_gather(buf + (size_t)e->sh_rank * stride, buf, stride, /*ncclUint8*/ 1, e->rccl_comm, e->stream);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
@@ -3203,7 +3265,7 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
     auto all_stats = [&](uint8_t* buf) { return (const int32_t*)(buf + stats_off); };
     int r;
 #define NEM_TRY(call) do { if ((r = (call)) != NEMGPU_OK) return r; } while (0)
-    NEM_TRY(nemgpu_shard_begin(e));
+    NEM_TRY(with_init ? nemgpu_shard_begin_restart(e) : nemgpu_shard_begin(e));
     if (with_init) {
         NEM_TRY(nemgpu_shard_estep_round0(e, nullptr, 0.0f, 0, L[0], L[1]));       // blind sweep
         NEM_TRY(rccl_allgather_blocks(e, L[1]));
@@ -3211,8 +3273,8 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
         if (want_stats && !use_nei) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[2])));
         NEM_TRY(rccl_allgather_blocks(e, L[2]));
         if (use_nei) {
-            NEM_TRY(nemgpu_shard_estep_round1(e, beta, 1, L[1], L[2], L[0]));
-            if (want_stats) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[0])));
+            if (want_stats) NEM_TRY(nemgpu_shard_estep_round1_counts(e, beta, 1, L[1], L[2], L[0], own_stats(L[0])));
+            else NEM_TRY(nemgpu_shard_estep_round1(e, beta, 1, L[1], L[2], L[0]));
             NEM_TRY(rccl_allgather_blocks(e, L[0]));
         }
         NEM_TRY(nemgpu_shard_finish_iteration(e, beta, 1, L[1], L[2], L[0]));
@@ -3224,8 +3286,8 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
         if (want_stats && !use_nei) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[Q])));
         NEM_TRY(rccl_allgather_blocks(e, L[Q]));
         if (use_nei) {
-            NEM_TRY(nemgpu_shard_estep_round1(e, beta, -1, L[P], L[Q], L[R]));
-            if (want_stats) NEM_TRY(nemgpu_shard_counts(e, own_stats(L[R])));
+            if (want_stats) NEM_TRY(nemgpu_shard_estep_round1_counts(e, beta, -1, L[P], L[Q], L[R], own_stats(L[R])));
+            else NEM_TRY(nemgpu_shard_estep_round1(e, beta, -1, L[P], L[Q], L[R]));
             NEM_TRY(rccl_allgather_blocks(e, L[R]));
         }
         NEM_TRY(nemgpu_shard_finish_iteration(e, beta, 0, L[P], L[Q], L[R]));
@@ -3404,6 +3466,88 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
         *algorithmic_bytes_per_launch = (double)e->n * e->wf * 4.0 + (double)e->k * e->d * 24.0 +
                                         (double)e->n * e->k * 12.0;
     }
+    return NEMGPU_OK;
+}
+
+// Kernel-duration probe for bench.py's roofline.kernels[]: the three kernels of a solo NCEM iteration -- E1 (with the
+// parameter update when the loop launches it that way), one relaxation round of the E-step sweep, the M-step counts --
+// each launched `reps` times back to back between ONE pair of HIP events on the engine's stream (an event pair per
+// launch costs ~3 us, as much as the shorter kernels), on the state the engine is in (the launches are idempotent: same
+// inputs, same outputs; the partition is not advanced).  avg_ms[3], bytes[3]: average duration and algorithmic bytes
+// per launch of {E1, sweep round, counts}; which[0]: 1 when E1 is the fused kernel.
+int nemgpu_profile_kernels(nemgpu_engine* e, int reps, double avg_ms[3], double bytes[3], int which[1])
+{
+    if (!e || reps <= 0 || !avg_ms || !bytes) return NEMGPU_E_FUNCARG;
+    if (!e->ncem() || e->lo != 0 || e->hi != e->n_total) { set_error("the kernel probe times a whole NCEM problem on one engine"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    if ((r = do_tables(e))) return r;
+    if (!e->masks_valid) { if ((r = do_labels_post(e, e->cur, -1))) return r; }
+    if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }
+    const bool fused = !e->cfg.param_fix && e->fused_update() && e->iters > 0;
+    auto timed = [&](auto&& launch, double* out) -> int {
+        launch();                                                  // (one untimed launch: code object, caches)
+        HIPCHK(hipEventRecord(e->ev0, e->stream));
+        for (int i = 0; i < reps; i++) launch();
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e->ev1, e->stream));
+        HIPCHK(hipEventSynchronize(e->ev1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        *out = (double)ms / reps;
+        return NEMGPU_OK;
+    };
+    // M-step counts first: they leave the statistics the fused E1 derives its parameters from
+    if ((r = timed([&] { launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, nullptr, nullptr, e->stream); }, &avg_ms[2]))) return r;
+    if ((r = timed([&] {
+            if (fused) launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
+                                            e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+            else launch_density(finish_args(e, 0, nullptr), e->xws, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
+                                1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+        }, &avg_ms[0]))) return r;
+    e->density_fresh = true; e->flags_clean = true;
+    if (fused) e->tables_fresh = false;
+    // one relaxation round: round 0 of a sweep from the current partition (guess = old), into the next buffer
+    {
+        SweepCtx c;
+        const uint32_t keep = e->sweep_counter;
+        if ((r = sweep_setup(e, e->cfg.beta, c, true))) return r;
+        e->sweep_counter = keep;
+        const int P = e->cur, Q = (e->cur + 1) % 3;
+        c.a.lab_old = e->lab[P]; c.a.lab_guess = e->lab[P]; c.a.lab_out = e->lab[Q];
+        c.a.tie_cnt_guess = e->tie_cnt[P]; c.a.tie_cnt_out = e->tie_cnt[Q];
+        c.a.flags = e->round_flags(0); c.a.fold_ticket = e->sweep_next + 32;
+        if ((r = timed([&] { launch_sweep(c.a, true, e->stream); }, &avg_ms[1]))) return r;
+        e->flags_clean = false;
+    }
+    const double n = e->n, d = e->d, k = e->k, nnz = e->nnz;
+    bytes[0] = n * e->wf * 4.0 + k * d * 24.0 + n * k * 12.0;             // bit matrix once, (k,d) tables, pk*fk f64 + log f32 out
+    bytes[1] = 8.0 * nnz + 4.0 * (n + 1) + nnz + 8.0 * n * k + 2.0 * n;   // CSR idx + w, row pointers, neighbour labels, densities, labels in/out
+    bytes[2] = d * e->nw64 * 8.0 + k * e->nw64 * 8.0 + 4.0 * (k + k * d); // organism bit rows once, class masks once, counts out
+    if (which) which[0] = fused ? 1 : 0;
+    return NEMGPU_OK;
+}
+
+// `reps` in-place all-gathers of the sharded EM's label blocks (stride bytes per rank) back to back through the engine's
+// own communicator, between one pair of HIP events: what ONE of the iteration's two collectives costs.  Collective.
+int nemgpu_rccl_time_allgather(nemgpu_engine* e, uint8_t* buf_dev, int reps, double* avg_ms)
+{
+    if (!e || !buf_dev || reps <= 0 || !avg_ms) return NEMGPU_E_FUNCARG;
+    if (!e->rccl_comm) { set_error("nemgpu_rccl_attach first"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->ev0) { HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1)); }
+    const size_t stride = (size_t)e->sh_stride;
+    auto gather = [&]() { return g_rccl.all_gather(buf_dev + (size_t)e->sh_rank * stride, buf_dev, stride, /*ncclUint8*/ 1, e->rccl_comm, e->stream); };
+    for (int i = 0; i < 3; i++) { const int rc = gather(); if (rc != 0) return rccl_fail("ncclAllGather", rc); }
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < reps; i++) { const int rc = gather(); if (rc != 0) return rccl_fail("ncclAllGather", rc); }
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *avg_ms = (double)ms / reps;
     return NEMGPU_OK;
 }
 

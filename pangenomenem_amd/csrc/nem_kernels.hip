@@ -806,36 +806,69 @@ __device__ __forceinline__ int density_fused_body(const FusedDensityArgs& a)
 __device__ inline void ctrl_logic(const CtrlArgs& a)
 {
     int* c = a.ctrl;
-    if (c[C_STOP]) return;
-    if (a.is_init) *a.sweep_next = 2;                             // sweeps 0 and 1 are the two initial ones
-    else { c[C_ITERS] += 1; *a.sweep_next += 1; }                 // the tie-break hash is keyed by the sweep number
+    // One thread runs this at the tail of a launch (or as a launch of its own): a string of dependent read-modify-writes
+    // of device memory would BE that tail (each ~0.1-0.4 us).  So everything the decision reads is requested up front
+    // -- independent loads, one memory latency -- the tests run on registers, and what changed is stored at the end.
+    constexpr int kMaxRounds = 4;                                 // (kRoundBatchMax in nem_engine.hip)
+    const int nr = a.n_rounds > 0 ? (a.n_rounds < kMaxRounds ? a.n_rounds : kMaxRounds) : 2;
+    const int stop = c[C_STOP];
+    int iters = c[C_ITERS], commits = c[C_COMMITS], sweep_rounds = c[C_SWEEP_ROUNDS], nzero = c[C_NZERO], firstzero = c[C_FIRSTZERO];
+    int draws = c[C_DRAWS];
+    const int sweep_next = *a.sweep_next;
     const int emptyk = a.iter_flags[FLAG_EMPTYK];
+    int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    static_assert(FLAG_ROUND_STRIDE == 4 && FLAG_CHANGED == 0 && FLAG_NZERO == 1 && FLAG_FIRSTZERO == 2 && FLAG_NTIES == 3, "a round's slot is one int4");
+    int4 rf[kMaxRounds];
+#pragma unroll
+    for (int r = 0; r < kMaxRounds; r++) rf[r] = r < nr ? reinterpret_cast<const int4*>(a.round0)[r] : make_int4(1, 0, 0, 0);
+    int4 bf = make_int4(0, 0, 0, 0);
+    if (a.is_init && a.blind != nullptr) bf = *reinterpret_cast<const int4*>(a.blind);
+    int draw0 = 0;
+    if (a.draw_ctl != nullptr) draw0 = a.draw_ctl[0];
+    int ch0 = 0, ch1 = 0, mv = 0;
+    if (a.q_flags != nullptr) {                                   // sharded: every rank's flag bytes (all-gathered)
+        for (int r = 0; r < a.n_ranks; r++) {
+            const size_t o = (size_t)r * a.flag_stride;
+            ch0 |= a.q_flags[o];
+            ch1 |= a.r_flags[o];
+            // every rank's 'one of MY labels moved' byte, next to its flag byte of the sweep's last round (1: round 1's,
+            // 2: round 0's): every rank takes the same decision without another collective, and without a pass over
+            // the other ranks' labels
+            if (a.moved_bytes) mv |= (a.moved_bytes == 2 ? a.q_flags : a.r_flags)[o + 1];
+        }
+        if (a.moved_bytes) moved = mv;
+    }
+    if (stop) return;
+
     // which of the enqueued relaxation rounds changed nothing (= the sweep's fixed point)?  -1: none of them
-    const int nr = a.n_rounds > 0 ? a.n_rounds : 2;
     int last = -1;
     if (!a.use_nei) last = 0;                                     // one round, nothing to verify
-    else if (a.q_flags != nullptr) {                              // sharded: any rank's flag byte, two rounds
-        int ch0 = 0, ch1 = 0;
-        for (int r = 0; r < a.n_ranks; r++) ch0 |= a.q_flags[(size_t)r * a.flag_stride];
-        if (ch0) for (int r = 0; r < a.n_ranks; r++) ch1 |= a.r_flags[(size_t)r * a.flag_stride];
-        last = !ch0 ? 0 : (!ch1 ? 1 : -1);
-    } else {
-        for (int r = 0; r < nr; r++)
-            if (a.round0[r * FLAG_ROUND_STRIDE + FLAG_CHANGED] == 0) { last = r; break; }
+    else if (a.q_flags != nullptr) last = !ch0 ? 0 : (!ch1 ? 1 : -1);   // sharded: two rounds
+    else {
+#pragma unroll
+        for (int r = kMaxRounds - 1; r >= 0; r--) if (r < nr && rf[r].x == 0) last = r;
     }
-    const int* f = a.round0 + (last > 0 ? last : 0) * FLAG_ROUND_STRIDE;
+    int4 f = rf[0];
+#pragma unroll
+    for (int r = 1; r < kMaxRounds; r++) if (last == r) f = rf[r];
+    // the tie-break hash is keyed by the sweep number; sweeps 0 and 1 are the two initial ones
+    if (a.is_init) *a.sweep_next = 2;
+    else { iters += 1; c[C_ITERS] = iters; *a.sweep_next = sweep_next + 1; }
     if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
-        if (a.blind != nullptr && a.blind[FLAG_NZERO] > 0) {      // the blind sweep's zero-density sites come first
-            c[C_NZERO] += a.blind[FLAG_NZERO];
-            if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = a.blind[FLAG_FIRSTZERO];
+        if (bf.y > 0) {                                           // the blind sweep's zero-density sites come first
+            nzero += bf.y;
+            if (firstzero == 0) firstzero = bf.z;
         }
-        if (last < 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; return; }
-        c[C_SWEEP_ROUNDS] += last + 2;                            // blind sweep + this one
-        if (f[FLAG_NZERO] > 0) { c[C_NZERO] += f[FLAG_NZERO]; if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO]; }
-        c[C_FOLD] = f[FLAG_NZERO] > 0;                            // how the next sweeps tally such sites, see k_sweep
+        if (last >= 0) {
+            sweep_rounds += last + 2;                             // blind sweep + this one
+            if (f.y > 0) { nzero += f.y; if (firstzero == 0) firstzero = f.z; }
+            c[C_FOLD] = f.y > 0;                                  // how the next sweeps tally such sites, see k_sweep
+            c[C_SWEEP_ROUNDS] = sweep_rounds;
+        }
+        c[C_NZERO] = nzero; c[C_FIRSTZERO] = firstzero;
+        if (last < 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; }
         return;
     }
-    const int moved = __hip_atomic_load(&a.iter_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!a.param_fix && emptyk != 0) {                            // nem_alg.c:1831-1838: E-step "not run"
         c[C_STATUS] = NEMGPU_W_EMPTYCLASS;
         c[C_EMPTYK] = emptyk;
@@ -843,19 +876,19 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
         return;
     }
     if (last < 0) { c[C_NEED_ROUNDS] = 1; c[C_STOP] = 1; return; }
-    c[C_SWEEP_ROUNDS] += last + 1;
-    if (last >= 2) c[C_DEEP] = c[C_ITERS];
-    if (f[FLAG_NZERO] > 0) {
-        c[C_NZERO] += f[FLAG_NZERO];
-        if (c[C_FIRSTZERO] == 0) c[C_FIRSTZERO] = f[FLAG_FIRSTZERO];
+    c[C_SWEEP_ROUNDS] = sweep_rounds + last + 1;
+    if (last >= 2) c[C_DEEP] = iters;
+    if (f.y > 0) {
+        c[C_NZERO] = nzero + f.y;
+        if (firstzero == 0) c[C_FIRSTZERO] = f.z;
     }
-    c[C_FOLD] = f[FLAG_NZERO] > 0;
+    c[C_FOLD] = f.y > 0;
     if (a.draw_ctl != nullptr) {                                  // TIE_LIBC: the sweep's draws move the stream on
-        const int nt = f[FLAG_NTIES] & ((1 << 30) - 1);
-        a.draw_ctl[0] += nt;
-        c[C_DRAWS] += nt;
+        const int nt = f.w & ((1 << 30) - 1);
+        a.draw_ctl[0] = draw0 + nt;
+        c[C_DRAWS] = draws + nt;
     }
-    c[C_COMMITS] += 1;
+    c[C_COMMITS] = commits + 1;
     if (a.cvtest == NEMGPU_CV_CLAS) {                             // HasConverged, nem_alg.c:2075-2089
         const int conv = a.ncem ? (moved ? (1.0f < a.cvthres) : (0.0f < a.cvthres)) : !moved;
         if (conv) { c[C_CONVERGED] = 1; c[C_STOP] = 1; }
@@ -1242,7 +1275,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
             if (a.post_moved) moved = (lab != my_old);
         }
         const int wave = i >> 6;
-        if (wave < a.post_nw64) {
+        if (wave < a.post_nw64 && !a.post_no_masks) {
             for (int k = 0; k < K; k++) {
                 const uint64_t m = __ballot(lab == k);
                 if ((threadIdx.x & 63) == 0) a.post_mask[(size_t)k * a.post_nw64 + wave] = m;
@@ -1254,40 +1287,16 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     if (a.publish_byte != nullptr || post_ctrl || fold) {
         int* ticket = a.publish_byte != nullptr ? a.publish_ticket : (post_ctrl ? a.post_ctrl.ticket : a.fold_ticket);
         if (last_block_ticket(ticket, nblk, fold ? s_nzero : 0, fold ? &a.flags[FLAG_NZERO] : nullptr)) {
-            if (a.publish_byte != nullptr)
+            if (a.publish_byte != nullptr) {
                 *a.publish_byte = (uint8_t)(__hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+                if (NCEM && a.post_on && a.post_moved)          // (sharded: this rank's 'a label moved' byte rides next to it)
+                    a.publish_byte[1] = (uint8_t)(__hip_atomic_load(&a.post_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+            }
             if (post_ctrl) ctrl_logic(a.post_ctrl);
         }
     }
 }
 
-
-
-// sharded runs: CVTEST_CLAS over the WHOLE (all-gathered) label array, so every rank takes the same decision
-// without another collective; slot t of true family f: (f / blk) * stride + f % blk
-__global__ void k_moved_global(int n_true, int blk, int stride, const uint8_t* __restrict__ lab_new,
-                               const uint8_t* __restrict__ lab_old, int* __restrict__ flags,
-                               const int* __restrict__ stop, CtrlArgs ca)
-{
-    if (stop != nullptr && *stop) return;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    int moved = 0;
-    if (f < n_true) {
-        const size_t slot = (size_t)(f / blk) * stride + (f % blk);
-        moved = (lab_new[slot] & 0x7F) != (lab_old[slot] & 0x7F);
-    }
-    if (__any(moved) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
-    if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, gridDim.x)) ctrl_logic(ca);
-}
-
-void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
-                         const int* stop, const CtrlArgs* ctrl, hipStream_t s)
-{
-    CtrlArgs ca{};
-    if (ctrl != nullptr) ca = *ctrl;
-    hipLaunchKernelGGL(k_moved_global, dim3((n_true + 255) / 256), dim3(256), 0, s, n_true, blk, stride, lab_new,
-                       lab_old, flags, stop, ca);
-}
 
 
 // ------------------------------------------------------------------------------------------
@@ -3114,6 +3123,18 @@ template <int KT, bool NCEM, int BS>
 __global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS>(a, blockIdx.x, gridDim.x); }
 template <int KT, bool NCEM, int BS>
 __global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS>(a, blockIdx.x, nblk); }
+// One relaxation round (blocks [0, nsweep)) and the M-step counts of the partition it verifies (the other blocks: its
+// class masks were made by the round before) side by side in ONE launch -- the sharded iteration's second half, where
+// the counts are taken from round 0's labels while round 1, the verifying round, runs.  The two do not depend on each
+// other; as two launches the second waited for the first.  (The round's last-block ticket -- it publishes the rank's
+// flag bytes -- is among the round's blocks only.)
+template <int KT, int R>
+__global__ __launch_bounds__(256) void k_sweep_counts(SweepArgs s, CountsArgs c, int nsweep)
+{
+    if ((int)blockIdx.x < nsweep) { sweep_body<KT, true, 256>(s, blockIdx.x, nsweep); return; }
+    mstep_counts_body<R>(c.K, c.D, c.nw64, c.xt, c.mask, c.stats, c.stop, CtrlArgs{}, (int)blockIdx.x - nsweep, (int)gridDim.x - nsweep);
+}
+
 __global__ void k_ctrl(CtrlArgs a) { ctrl_logic(a); }
 __global__ void k_ctrl_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CtrlArgs) ctrl_logic(a); }
 __global__ void k_labels_post(LabelsPostArgs a)
@@ -3327,6 +3348,25 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
     const dim3 grid(((npad / 256 + 7) / 8) * 8 * t.K);
     if (record_op(OP_DENSITY_FUSED, 0, grid, 256, a)) return;
     hipLaunchKernelGGL(k_density_fused, grid, dim3(256), 0, s, a);
+}
+
+// an NCEM relaxation round and M-step counts in one launch (k_sweep_counts); false: not for this shape (the caller
+// launches the two separately)
+bool launch_sweep_counts(const SweepArgs& sw, int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
+                         const int* stop, hipStream_t s)
+{
+    if (current_recorder() != nullptr || sw.n_local >= 65536 || K < 2 || K > 5) return false;
+    CountsArgs c{K, D, nw64, xt, mask, stats, stop, CtrlArgs{}};
+    const int nsweep = (sw.n_local + 255) / 256;
+    const bool wide = D + 1 >= 1024;
+    const dim3 grid(nsweep + (wide ? (D + 1 + 3) / 4 : D + 1));
+#define NEM_SC(KT_) case KT_:                                                                                        \
+        if (wide) hipLaunchKernelGGL((k_sweep_counts<KT_, 4>), grid, dim3(256), 0, s, sw, c, nsweep);                \
+        else hipLaunchKernelGGL((k_sweep_counts<KT_, 1>), grid, dim3(256), 0, s, sw, c, nsweep);                     \
+        break;
+    switch (K) { NEM_SC(2) NEM_SC(3) NEM_SC(4) NEM_SC(5) default: return false; }
+#undef NEM_SC
+    return true;
 }
 
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,

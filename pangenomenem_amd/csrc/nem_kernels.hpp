@@ -38,6 +38,7 @@ struct CtrlArgs {
     // sharded runs: every rank's "some label changed" byte for round 0 / round 1, as all-gathered at the tail
     // of each rank's block of the label arrays (nullptr on a single GPU: the int flags above are used)
     const uint8_t* q_flags; const uint8_t* r_flags; int n_ranks, flag_stride;
+    int moved_bytes;               // sharded: the byte behind a rank's flag byte says 'one of its labels moved' (1: in r_flags, 2: in q_flags)
     int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
     const int* blind;              // is_init: flag slot of the blind beta = 0 sweep (its zero-density tally), or nullptr
     int* draw_ctl;                 // TIE_LIBC: {draws made so far, first draw of the table} (device), else nullptr
@@ -68,6 +69,7 @@ struct SweepArgs {
     // post_skip_guess: where the partition is when this round skips its sites (a round before it changed nothing):
     // the sweep's first buffer -- this round's guess if it is an odd round, its output buffer if it is an even one
     int post_on, post_from_guess, post_moved, post_nw64, post_skip_guess;
+    int post_no_masks;             // the bookkeeping without the class masks (a verifying round whose guess has them already)
     uint64_t* post_mask; int* post_flags;
     CtrlArgs post_ctrl;
     // sharded runs: the last block to finish stores this rank's "some label changed in this round" byte behind
@@ -127,9 +129,6 @@ void launch_zipped(int kind, int variant, int B, const void* dev_args, int strid
 void launch_fill(int* ptr, int words, int value, hipStream_t s);   // recordable memset of 32-bit words
 void launch_copy_words(const int* src, int* dst, int words, hipStream_t s);   // recordable device-to-device copy
 
-void launch_moved_global(int n_true, int blk, int stride, const uint8_t* lab_new, const uint8_t* lab_old, int* flags,
-                         const int* stop, const CtrlArgs* ctrl, hipStream_t s);
-
 
 void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
                    const int* perm, uint32_t* xws, hipStream_t s);
@@ -160,6 +159,10 @@ constexpr int kFusedMaxD = 1024;   // beyond this the per-block parameter deriva
 void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                           int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
+// one NCEM relaxation round and the M-step counts (of the partition whose class masks exist already) in ONE launch;
+// returns false when the shape has no such kernel (2 <= K <= 5, fewer than 65 536 families, not recordable)
+bool launch_sweep_counts(const SweepArgs& sw, int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
+                         const int* stop, hipStream_t s);
 void launch_labels_post(int n_local, int lo, int K, int nw64, const uint8_t* lab_new, const uint8_t* lab_old,
                         uint64_t* mask, int* flags, const int* stop, const CtrlArgs* ctrl, hipStream_t s);
 void launch_mstep_counts(int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,

@@ -92,6 +92,8 @@ class Comm:
 
     def allgather_blocks_(self, buf, stride):
         """In-place all-gather: rank r owns buf[r*stride:(r+1)*stride]; afterwards every rank holds all blocks."""
+        if self.world == 1:
+            return                    # (a rank alone holds every block already)
         mine = buf[self.rank * stride:(self.rank + 1) * stride]
         if self.backend == "gloo":
             h = mine.cpu() if mine.is_cuda else mine.clone()
@@ -198,10 +200,10 @@ class GpuStepper:
         return self.eng.stats_words()
 
     def reset(self):
-        self.eng.reset()
+        pass        # (a run starts with begin(restart=True): the reset is the head launch of its first batch)
 
-    def begin(self):
-        self.eng.shard_begin()
+    def begin(self, restart=False):
+        self.eng.shard_begin(restart)
 
     def _own_stats_ptr(self, buf):
         return buf.data_ptr() + self.rank * self.stride + stats_offset(self.blk)
@@ -221,6 +223,11 @@ class GpuStepper:
 
     def estep_round1(self, beta, sweep_id, old, guess, out):
         self.eng.shard_estep_round1(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr())
+
+    def estep_round1_counts(self, beta, sweep_id, old, guess, out):
+        """round 1 and counts(out) in one launch where the shape has a kernel for it"""
+        self.eng.shard_estep_round1_counts(beta, sweep_id, old.data_ptr(), guess.data_ptr(), out.data_ptr(),
+                                           self._own_stats_ptr(out))
 
     def finish_iteration(self, beta, is_init, old, q, r):
         self.eng.shard_finish_iteration(beta, is_init, old.data_ptr(), q.data_ptr(), r.data_ptr())
@@ -299,9 +306,7 @@ class ShardedNem:
         return self.st.eng
 
     def reset(self):
-        self.st.reset()
-        with self.st.on_stream():
-            self.labels[0].zero_()
+        self.st.reset()               # (buffer 0 needs no clearing: the blind sweep of a start never reads a partition)
         self.cur = 0
         self.sweep_id = 0
         self.iters, self.converged, self.status, self.emptyk, self.sweep_rounds = 0, False, STATUS_OK, 0, 0
@@ -324,9 +329,7 @@ class ShardedNem:
             self.st.counts(L[2])
         self.comm.allgather_blocks_(L[2], self.stride)
         if use_nei:
-            self.st.estep_round1(self.beta, 1, L[1], L[2], L[0])
-            if want_stats:
-                self.st.counts(L[0])                                      # statistics of L[2], riding with L[0]
+            self._round1(1, L[1], L[2], L[0], want_stats)                 # (+ the statistics of L[2], riding with L[0])
             self.comm.allgather_blocks_(L[0], self.stride)
         self.st.finish_iteration(self.beta, 1, L[1], L[2], L[0])
 
@@ -338,11 +341,18 @@ class ShardedNem:
             self.st.counts(L[Q])
         self.comm.allgather_blocks_(L[Q], self.stride)
         if use_nei:
-            self.st.estep_round1(self.beta, -1, L[P], L[Q], L[R])
-            if want_stats:
-                self.st.counts(L[R])                                      # statistics of L[Q], riding with L[R]
+            self._round1(-1, L[P], L[Q], L[R], want_stats)                # (+ the statistics of L[Q], riding with L[R])
             self.comm.allgather_blocks_(L[R], self.stride)
         self.st.finish_iteration(self.beta, 0, L[P], L[Q], L[R])
+
+    def _round1(self, sweep_id, old, guess, out, want_stats):
+        """the verifying round and, beside it, this rank's partial counts of the labels it verifies"""
+        if want_stats and hasattr(self.st, "estep_round1_counts"):
+            self.st.estep_round1_counts(self.beta, sweep_id, old, guess, out)
+            return
+        self.st.estep_round1(self.beta, sweep_id, old, guess, out)
+        if want_stats:
+            self.st.counts(out)
 
     def _publish_stats(self, cur):
         """Statistics of the partition in buffer `cur`, recomputed and gathered explicitly (after the host had
@@ -373,7 +383,10 @@ class ShardedNem:
         if self.native:
             self.st.enqueue_batch_native(with_init, g, base, self.beta, not self.param_fix, self.labels)
             return
-        self.st.begin()
+        if with_init and isinstance(self.st, GpuStepper):
+            self.st.begin(restart=True)
+        else:
+            self.st.begin()
         if with_init:
             self._enqueue_init()
         for j in range(g):
@@ -470,6 +483,25 @@ class ShardedNem:
         self.set_cvtest(keep)
         return max(1, int(res["iters"]))
 
+    def time_collective(self, reps=100):
+        """Seconds per all-gather of one label array (an iteration issues two), on this job's own path; collective."""
+        import time
+        if self.comm.world == 1:
+            return 0.0
+        if self.native:
+            return self.eng.rccl_time_allgather(self.labels[(self.cur + 2) % 3].data_ptr(), reps) * 1e-3
+        buf = self.labels[(self.cur + 2) % 3]
+        torch = self.st.torch
+        with self.st.on_stream():
+            for _ in range(3):
+                self.comm.allgather_blocks_(buf, self.stride)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.comm.allgather_blocks_(buf, self.stride)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
     def run_steps(self, count, cycle):
         done = 0
         while done < count:
@@ -488,10 +520,12 @@ class ShardedNem:
             raise ValueError("the sharded path is NCEM-only (fuzzy sums are order-dependent, SURVEY.md §8e)")
         lo, hi, _ = shard_bounds(n_total, world, rank)
         blk, stride = slot_layout(n_total, world, k + k * d)
-        gen = synth.ushaped_pa_matrix if spectrum == "ushape" else synth.bernoulli_pa_matrix
-        x, _ = gen(n_total, d, seed)
-        x_local = np.ascontiguousarray(x[lo:hi])
-        del x
+        if spectrum == "ushape":
+            x_local, _ = synth.ushaped_pa_matrix(n_total, d, seed, rows=(lo, hi))    # (the shard of the same matrix)
+        else:
+            x, _ = synth.bernoulli_pa_matrix(n_total, d, seed)
+            x_local = np.ascontiguousarray(x[lo:hi])
+            del x
         nei = slice_graph(synth.contiguity_graph(n_total, seed), lo, hi, blk, stride)
         prop, center, disp = synth.default_init(d)
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)

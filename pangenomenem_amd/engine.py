@@ -92,6 +92,8 @@ def load_library():
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
     lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), ip]
     lib.nemgpu_calibrate_fetch.argtypes = [C.c_size_t, C.c_int]
+    lib.nemgpu_profile_kernels.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), ip]
+    lib.nemgpu_rccl_time_allgather.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double)]
     lib.nemgpu_set_stream.argtypes = [vp, vp]
     lib.nemgpu_set_fast_forward.argtypes = [vp, C.c_int]
     lib.nemgpu_set_graph_policy.argtypes = [vp, C.c_int]
@@ -103,6 +105,8 @@ def load_library():
     lib.nemgpu_stats_words.argtypes = [vp]
     lib.nemgpu_shard_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.nemgpu_shard_begin.argtypes = [vp]
+    lib.nemgpu_shard_begin_restart.argtypes = [vp]
+    lib.nemgpu_shard_estep_round1_counts.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp, vp]
     lib.nemgpu_shard_mstep_partial.argtypes = [vp, vp, vp]
     lib.nemgpu_shard_counts.argtypes = [vp, vp]
     lib.nemgpu_rccl_open.argtypes = [C.c_char_p]
@@ -315,8 +319,12 @@ class NemEngine:
     def shard_layout(self, world, rank, blk, stride, n_true):
         self._chk(self.lib.nemgpu_shard_layout(self._h, world, rank, blk, stride, n_true))
 
-    def shard_begin(self):
-        self._chk(self.lib.nemgpu_shard_begin(self._h))
+    def shard_begin(self, restart=False):
+        self._chk((self.lib.nemgpu_shard_begin_restart if restart else self.lib.nemgpu_shard_begin)(self._h))
+
+    def shard_estep_round1_counts(self, beta, sweep_id, old_ptr, guess_ptr, out_ptr, stats_ptr):
+        self._chk(self.lib.nemgpu_shard_estep_round1_counts(self._h, C.c_float(beta), int(sweep_id), C.c_void_p(old_ptr),
+                                                            C.c_void_p(guess_ptr), C.c_void_p(out_ptr), C.c_void_p(stats_ptr)))
 
     def shard_mstep_partial(self, labels_ptr, stats_ptr):
         self._chk(self.lib.nemgpu_shard_mstep_partial(self._h, C.c_void_p(labels_ptr), C.c_void_p(stats_ptr)))
@@ -366,6 +374,22 @@ class NemEngine:
         self._chk(self.lib.nemgpu_profile_density(self._h, int(reps), C.byref(ms), C.byref(b), C.byref(fused)))
         return dict(density_ms_avg=ms.value, density_launches=int(reps), algorithmic_bytes_per_launch=b.value,
                     kernel="k_density_fused" if fused.value else "k_density")
+
+    def profile_kernels(self, reps=50):
+        """Average duration (HIP events around `reps` back-to-back launches) and algorithmic bytes per launch of the
+        three kernels of a solo NCEM iteration: E1, one relaxation round, the M-step counts."""
+        ms, by, which = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+        self._chk(self.lib.nemgpu_profile_kernels(self._h, int(reps), ms, by, C.byref(which)))
+        names = ("k_density_fused" if which.value else "k_density", "k_sweep", "k_mstep_counts")
+        what = ("E1: Bernoulli log-density chains" + (" + NCEM parameter update" if which.value else ""),
+                "E2: one relaxation round of the Gauss-Seidel site sweep", "M: integer popcount statistics")
+        return [dict(kernel=names[i], what=what[i], avg_launch_ms=ms[i], algorithmic_bytes_per_launch=by[i], launches_timed=int(reps))
+                for i in range(3)]
+
+    def rccl_time_allgather(self, buf_ptr, reps=100):
+        ms = C.c_double(0)
+        self._chk(self.lib.nemgpu_rccl_time_allgather(self._h, C.c_void_p(buf_ptr), int(reps), C.byref(ms)))
+        return ms.value
 
     def set_fast_forward(self, mode):
         """E1 binade fast-forward: 1 always, 0 never, -1 automatic (default); results are bit-identical."""

@@ -30,21 +30,31 @@ def bernoulli_pa_matrix(n, d, seed, mix=(0.30, 0.20, 0.50), p=(0.97, 0.5, 0.03))
     return x, z
 
 
-def ushaped_pa_matrix(n, d, seed, a=0.3, b=0.3):
+def ushaped_pa_matrix(n, d, seed, a=0.3, b=0.3, rows=None):
     """Family-frequency spectrum of a real pangenome: U-shaped (many rare families, many near-universal ones, a
     broad shell in between).  Family i is present in each organism with its own probability p_i ~ Beta(a, b).
     Unlike the three well-separated latent classes of bernoulli_pa_matrix -- on which NEM is at its fixed point
     after ONE iteration from PPanGGOLiN's default .m -- the shell boundaries move for several EM iterations
-    (7 at 20 000 x 500 with the reference), so an EM benchmark on it times real pre-convergence iterations."""
+    (7 at 20 000 x 500 with the reference), so an EM benchmark on it times real pre-convergence iterations.
+    rows = (lo, hi): only those rows of the SAME matrix are kept (a rank's shard of a problem too large to hold
+    whole on every rank: the generator's stream is consumed in full, the memory is the shard's)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     pz = rng.beta(a, b, size=n).astype(np.float32)
-    x = np.empty((n, d), np.uint8)
+    lo, hi = (0, n) if rows is None else (max(0, int(rows[0])), min(n, int(rows[1])))
+    x = np.empty((max(hi - lo, 0), d), np.uint8)
     step = max(1, (1 << 26) // max(d, 1))
+    empties = []
     for r0 in range(0, n, step):
         r1 = min(n, r0 + step)
-        x[r0:r1] = rng.random((r1 - r0, d), dtype=np.float32) < pz[r0:r1, None]
-    empty = np.flatnonzero(x.sum(axis=1) == 0)
-    x[empty, rng.integers(0, d, size=len(empty))] = 1
+        chunk = rng.random((r1 - r0, d), dtype=np.float32) < pz[r0:r1, None]
+        empties.append(np.flatnonzero(~chunk.any(axis=1)) + r0)
+        a0, a1 = max(r0, lo), min(r1, hi)
+        if a0 < a1:
+            x[a0 - lo:a1 - lo] = chunk[a0 - r0:a1 - r0]
+    empty = np.concatenate(empties) if empties else np.zeros(0, np.int64)
+    cols = rng.integers(0, d, size=len(empty))
+    mine = (empty >= lo) & (empty < hi)
+    x[empty[mine] - lo, cols[mine]] = 1
     return x, pz
 
 

@@ -86,15 +86,39 @@ def test_bench_starts_its_own_ranks(gpu_lib):
     GPU of the box, host-staged gloo collectives) and prints the one JSON line; the default multi-GPU workload is
     the strong-scaling split of ONE problem."""
     rec = _bench("--gpus", "2", "--backend", "gloo", "--steps", "12", "--warmup", "3", "--families", "6000",
-                 "--organisms", "200")
+                 "--organisms", "200", "--repeats", "3", "--extras-strong-shape", "9000x300")
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 12 and rec["warmup"] == 3
     assert rec["config"]["families_total"] == 6000 and rec["config"]["families_per_gpu"] == 3000
-    assert rec["value"] > 0 and rec["iters_to_converge"] >= 1
+    assert rec["value"] > 0 and rec["iters_to_converge"] >= 1 and rec["repeats"] == 3
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= rec["ms_per_step_max"]
+    # an N-rank line says what its collectives cost, what one GPU does with the same problem, and what else N GPUs can
+    # do with this path: independent problems (no collective) and the strong scaling of a larger problem
+    assert rec["collective"]["per_iteration"] == 2 and rec["collective"]["per_iteration_ms"] > 0
+    assert rec["single_gpu_same_workload"]["ms_per_step"] > 0 and rec["speedup_vs_single_gpu_same_workload"] > 0
+    also = rec["also"]
+    assert also["replicas_20000x500_per_gpu"]["value"] > 0 and also["replicas_20000x500_per_gpu"]["collectives_per_iteration"] == 0
+    big = also["strong_9000x300"]
+    assert big["value"] > 0 and big["single_gpu_same_workload"]["ms_per_step"] > 0 and big["collective"]["per_iteration"] == 2
+
+
+@pytest.mark.parametrize("scaling", ["replicas", "weak"])
+def test_bench_other_multi_gpu_modes(gpu_lib, scaling):
+    """--scaling replicas: N independent problems, one per rank, no collective on the data path (the reference's own
+    parallel form); --scaling weak: one problem of N x --families families, sharded.  Two ranks on the one GPU, gloo."""
+    rec = _bench("--gpus", "2", "--backend", "gloo", "--scaling", scaling, "--steps", "14", "--warmup", "7",
+                 "--families", "5000", "--organisms", "150", "--repeats", "3", "--no-extras")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["families_total"] == 10000 and rec["config"]["families_per_gpu"] == 5000
+    if scaling == "replicas":
+        assert rec["collective"]["per_iteration"] == 0 and rec["whole_solves_per_block"] > 0 and rec["graphs_primed"]
+        assert "no collective" in rec["config"]["parallelism"]
+    else:
+        assert rec["collective"]["per_iteration"] == 2 and "sharded" in rec["config"]["parallelism"]
 
 
 def test_bench_sharded_driver_agrees_with_single_engine(gpu_lib):
     """N = 1 through the sharded driver (--dist, RCCL group of one rank) against the single engine on the same
-    workload: within 2.6x of each other; and a short run (--steps 20 --warmup 5) reports the same ms_per_step as a
+    workload: within 1.5x of each other; and a short run (--steps 20 --warmup 5) reports the same ms_per_step as a
     long one -- every batch shape is captured before the clock starts."""
     common = ["--families", "20000", "--organisms", "500", "--no-cpu-baseline", "--no-north-star"]
     short = _bench("--steps", "20", "--warmup", "5", *common)
@@ -103,5 +127,6 @@ def test_bench_sharded_driver_agrees_with_single_engine(gpu_lib):
     assert short["graphs_primed"] and long_["graphs_primed"]
     assert short["iters_to_converge"] == long_["iters_to_converge"] == dist1["iters_to_converge"] >= 5
     assert short["ms_per_step"] < 1.6 * long_["ms_per_step"], (short["ms_per_step"], long_["ms_per_step"])
-    # (the sharded driver pays two RCCL all-gathers and one launch more per iteration: ~2x the single engine at this size)
-    assert 0.5 < dist1["ms_per_step"] / long_["ms_per_step"] < 2.6, (dist1["ms_per_step"], long_["ms_per_step"])
+    # (a rank alone skips the all-gathers; the sharded iteration keeps one launch more than the single engine's, its
+    #  loop control: round 3 brought the ratio from 1.5-1.6 to under 1.2 at 50 000 x 1 000)
+    assert 0.5 < dist1["ms_per_step"] / long_["ms_per_step"] < 1.5, (dist1["ms_per_step"], long_["ms_per_step"])
