@@ -404,11 +404,12 @@ def sharded_run(args, ranks, n_tot, d, k, beta, seed, steps, warmup, repeats, wa
     coll = job.time_collective(100)
     stride_bytes = int(job.stride)
     facts = dict(iters_to_converge=cycle, cycle_iterations=cycle, native_rccl=bool(job.native), rccl_ranks=job.eng.rccl_ranks(),
-                 backend=args.backend, batch_graphs=bool(job.use_graphs),
+                 backend=args.backend, batch_graphs=bool(job.use_graphs or job.library_graphs),
                  collective=dict(what="in-place all-gather of the ranks' label blocks (labels, flag bytes, int32 M-step statistics)",
                                  bytes_per_rank=stride_bytes, per_allgather_ms=coll * 1e3, per_iteration=2,
                                  per_iteration_ms=2 * coll * 1e3, how="100 back-to-back all-gathers between one pair of HIP events"
                                  if job.native else "100 all-gathers through torch.distributed, wall clock"))
+    facts["library_graph_counters"] = job.eng.graph_counters()
     kernels = kernel_probe(job.eng)
     n_loc = job.hi - job.lo
     solo = None

@@ -182,6 +182,16 @@ typedef struct {
 } nemgpu_problem;
 int nemgpu_solve_many(nemgpu_problem* problems, int count, const nemgpu_config* cfg, int device, int workers, int group);
 
+/* The same over several devices of this process -- independent chunk problems side by side, the reference's own form of
+   parallelism (multiprocessing.Pool over 500-organism chunks, ppanggolin.py:1039-1095) with the devices in the role of
+   the pool's workers: the lock-step groups are dealt round-robin over `devices` (nemgpu_deal_groups; an entry may
+   repeat), every device runs its share on a thread of its own with its own worker threads (workers / n_devices each),
+   streams, lock-step contexts and resource pool.  Every problem's result equals its own nemgpu_run. */
+int nemgpu_solve_many_devices(nemgpu_problem* problems, int count, const nemgpu_config* cfg, const int* devices, int n_devices,
+                              int workers, int group);
+/* slot_of_problem[i] = index into the device list of the device that solves problem i (host arithmetic only) */
+int nemgpu_deal_groups(int count, int group, int n_devices, int* slot_of_problem);
+
 /* Whole run from random starts (the reference's init_mode = INIT_RANDOM, RandNemAlgo nem_alg.c:1574-1742): n_starts
    starts (the reference uses 50), centres drawn from the data with the reference's generator -- glibc random()
    after srandom(seed), restated in csrc/nem_rng.hpp -- best start by criterion M, EstimPara on the best partition.

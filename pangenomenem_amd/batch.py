@@ -29,13 +29,25 @@ def nem_many(calls, workers=8):
         return list(pool.map(lambda kw: nem(**kw), calls))
 
 
+def deal_groups(count, group, n_devices):
+    """index into the device list of the device that solves each of `count` problems (nemgpu_deal_groups): lock-step
+    group g goes to slot g % n_devices"""
+    out = (C.c_int * max(count, 1))()
+    rc = load_library().nemgpu_deal_groups(int(count), int(group), int(n_devices), out)
+    if rc != 0:
+        raise NemGpuError("nemgpu_deal_groups failed (status %d)" % rc)
+    return [int(out[i]) for i in range(count)]
+
+
 def solve_many(problems, workers=8, group=32, device=0, algo="ncem", beta=0.5, disper="sk_", propor="pk", cvtest="clas",
-               cvthres=1e-8, it_max=100, param_fix=False, tie="hash", seed=0):
+               cvthres=1e-8, it_max=100, param_fix=False, tie="hash", seed=0, devices=None):
     """problems = [(x, nei, k, prop, center, disp), ...]; returns their solve() results, each bit-identical to the
     problem solved alone.  ONE library call (nemgpu_solve_many, include/nem_mi355x.h): `workers` threads of the library
     build the engines (bit packing, uploads) and fetch the results, every `group` of problems runs in lock step, and
     while one group runs the next ones are being built.  x: uint8 [n][d] of 0/1, or uint32 bit rows [n][ceil(d/32)]
-    (then d is taken from the shape of `center`)."""
+    (then d is taken from the shape of `center`).  devices=[...]: the groups are dealt round-robin over several devices
+    of this process (nemgpu_solve_many_devices; an entry may repeat), each running its share with workers / len(devices)
+    library threads -- PPanGGOLiN's pool of chunk workers, with GPUs as the workers."""
     if not problems:
         return []
     lib = load_library()
@@ -69,7 +81,11 @@ def solve_many(problems, workers=8, group=32, device=0, algo="ncem", beta=0.5, d
                  nbobs_k=np.zeros(k, np.float32), c=np.zeros((n, k), np.float32))
         q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c = (addr(o[f]) for f in ("prop", "center", "disp", "nbobs_k", "c"))
         outs.append(o)
-    rc = lib.nemgpu_solve_many(arr, len(problems), C.byref(cfg), int(device), int(workers), int(group))
+    if devices is None:
+        rc = lib.nemgpu_solve_many(arr, len(problems), C.byref(cfg), int(device), int(workers), int(group))
+    else:
+        dl = (C.c_int * len(devices))(*[int(v) for v in devices])
+        rc = lib.nemgpu_solve_many_devices(arr, len(problems), C.byref(cfg), dl, len(devices), int(workers), int(group))
     if rc not in (STATUS_OK,):
         raise NemGpuError("nemgpu_solve_many failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
     res = []

@@ -217,6 +217,10 @@ struct nemgpu_engine {
         std::vector<ZipGraph> zip_graphs;
     };
     ZipContext* zc = nullptr;
+    // a rank alone in the sharded EM (no collective inside a batch): its batches as hipGraphs of the library's own,
+    // captured the second time a shape is enqueued (nemgpu_shard_enqueue_batch)
+    struct ShardGraph { uint64_t key; std::vector<uint64_t> desc; int asked; hipGraphExec_t exec; };
+    std::vector<ShardGraph> shard_graphs;
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
     int* ctrl() const { return flags_dev; }
@@ -1570,6 +1574,8 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
 
 void drop_graphs(nemgpu_engine* e)
 {
+    for (auto& g : e->shard_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->shard_graphs.clear();
     for (auto& plane : e->graphs)
         for (auto& row : plane)
             for (auto& col : row)
@@ -2463,6 +2469,59 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     return rc;
 }
 
+// Which device solves which problem when nemgpu_solve_many_devices deals the lock-step groups: group g (problems
+// g*group .. g*group + group - 1) goes to slot g % n_devices of the device list.  Host arithmetic only.
+int nemgpu_deal_groups(int count, int group, int n_devices, int* slot_of_problem)
+{
+    if (count < 0 || n_devices <= 0 || !slot_of_problem) return NEMGPU_E_FUNCARG;
+    group = std::max(1, std::min(group, 256));
+    for (int i = 0; i < count; i++) slot_of_problem[i] = (i / group) % n_devices;
+    return NEMGPU_OK;
+}
+
+// nemgpu_solve_many over SEVERAL devices of this process: the reference's own form of parallelism -- independent chunk
+// problems side by side (multiprocessing.Pool over 500-organism chunks, ppanggolin.py:1039-1095) -- with the devices in
+// the role of the pool's workers.  The lock-step groups are dealt round-robin over `devices` (an entry may repeat: two
+// pipelines on one device); every device runs its share through nemgpu_solve_many on a thread of its own, with its own
+// worker threads, streams, lock-step contexts and resource pool; no device waits for another.  Every problem's result
+// equals its own nemgpu_run.  Returns the first failure (each problem's own status is in its rc).
+int nemgpu_solve_many_devices(nemgpu_problem* P, int count, const nemgpu_config* cfg, const int* devices, int n_devices,
+                              int workers, int group)
+{
+    if (!P || count <= 0 || !cfg || !devices || n_devices <= 0) return NEMGPU_E_FUNCARG;
+    if (n_devices == 1) return nemgpu_solve_many(P, count, cfg, devices[0], workers, group);
+    const int ndev = nemgpu_device_count();
+    for (int s = 0; s < n_devices; s++)
+        if (devices[s] < 0 || devices[s] >= ndev) { set_error("nemgpu_solve_many_devices: bad device index in the list"); return NEMGPU_E_ARG; }
+    group = std::max(1, std::min(group, 256));
+    std::vector<int> slot((size_t)count);
+    (void)nemgpu_deal_groups(count, group, n_devices, slot.data());
+    std::vector<std::vector<nemgpu_problem>> sub((size_t)n_devices);
+    std::vector<std::vector<int>> who((size_t)n_devices);
+    for (int i = 0; i < count; i++) { sub[(size_t)slot[i]].push_back(P[i]); who[(size_t)slot[i]].push_back(i); }
+    std::vector<int> rcs((size_t)n_devices, NEMGPU_OK);
+    std::vector<std::string> errs((size_t)n_devices);
+    const int wk = std::max(1, workers / n_devices);
+    std::vector<std::thread> th;
+    for (int s = 0; s < n_devices; s++) {
+        if (sub[(size_t)s].empty()) continue;
+        th.emplace_back([&, s] {
+            rcs[(size_t)s] = nemgpu_solve_many(sub[(size_t)s].data(), (int)sub[(size_t)s].size(), cfg, devices[s], wk, group);
+            if (rcs[(size_t)s] != NEMGPU_OK) errs[(size_t)s] = g_last_error;       // (the error text is per thread)
+        });
+    }
+    for (std::thread& t : th) t.join();
+    int rc = NEMGPU_OK;
+    for (int s = 0; s < n_devices; s++) {
+        for (size_t j = 0; j < sub[(size_t)s].size(); j++) {
+            P[who[(size_t)s][j]].result = sub[(size_t)s][j].result;
+            P[who[(size_t)s][j]].rc = sub[(size_t)s][j].rc;
+        }
+        if (rcs[(size_t)s] != NEMGPU_OK && rc == NEMGPU_OK) { rc = rcs[(size_t)s]; set_error(errs[(size_t)s]); }
+    }
+    return rc;
+}
+
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
 {
     if (!e || n_starts <= 0) return NEMGPU_E_FUNCARG;
@@ -2683,7 +2742,14 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     if (e->ncem()) { if (!e->best_lab && (r = dev_alloc(&e->best_lab, (size_t)e->n_total))) return r; }
     else { if (!e->best_c && (r = dev_alloc(&e->best_c, (size_t)e->n_total * k))) return r; }
     const int group = std::min(n_starts, 64);
-    int width = group;                                            // starts per round (TIE_LIBC: follows how far the guesses hold)
+    // Starts per round.  TIE_LIBC: the starts' centre draws and the sweeps' tie draws are ONE stream, so a round's starts
+    // are drawn as if none of them tied and everything behind the first that did is thrown away.  Whether the data tie
+    // at all is not known ahead: start 0 runs ALONE, on this engine's own pipelined path (what the sequential form
+    // does); a start that ran alone without a tie opens a full-width round; a voided round is followed by a start
+    // alone again, and after two voided rounds in a row every remaining start runs alone -- data whose every start ties
+    // cost what the sequential form costs, never more.
+    int width = e->libc() ? 1 : group;
+    int voided_in_a_row = 0; bool alone_for_good = false;
     if ((r = ensure_clones(e, group))) return r;
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
 
@@ -2720,6 +2786,31 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 for (int t = 0; t < d; t++) center[(size_t)h * d + t] = bit(ipt, t);                             // :1457
             }
             start_pos[j] = e->draws;                                 // where this start's sweeps begin to draw
+        }
+        if (e->libc() && M == 1) {
+            // ---- one start alone: this engine's own run (nemgpu_run_random's sequential body)
+            const float* prop = host_par.data(); const float* center = prop + k; const float* disp = center + kd;
+            HIPCHK(copy_sync(e, e->prop0, prop, sizeof(float) * k, hipMemcpyHostToDevice));
+            HIPCHK(copy_sync(e, e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
+            HIPCHK(copy_sync(e, e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+            if ((r = iterate(e, e->cfg.it_max, true))) return r;
+            if (e->iters == 0) { if ((r = do_mstep(e)) || (r = do_tables(e)) || (r = do_density(e))) return r; }
+            float crit[6];
+            if ((r = criteria(e, crit))) return r;
+            const bool tied = e->draws != start_pos[0];
+            last_status = e->status;
+            if (e->status == NEMGPU_OK) {
+                nbsucc++;
+                if (nbsucc == 1 || crit[3] > best_crit[3]) {                                                     // :1676-1697
+                    HIPCHK(hipMemcpyAsync(e->best_lab, e->lab[e->cur], (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+                    for (int t = 0; t < 6; t++) best_crit[t] = crit[t];
+                    best = next;
+                    fill_result(e, &best_res);
+                }
+            }
+            next += 1;
+            width = (alone_for_good || tied) ? 1 : group;
+            continue;
         }
         HIPCHK(copy_sync(e, e->clone_par0, host_par.data(), host_par.size() * sizeof(float), hipMemcpyHostToDevice));
         if (e->libc()) {
@@ -2772,8 +2863,10 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
             set_error("internal: lock-step starts out of order"); return NEMGPU_E_FUNCARG;
         }
         next += valid;
-        // data whose starts tie are run a few starts at a time (everything behind the first tie is thrown away)
-        width = (valid == M) ? std::min(group, 2 * M) : std::max(1, std::min(group, valid == 1 ? 1 : 2 * valid));
+        if (e->libc()) {
+            if (valid < M) { voided_in_a_row++; if (voided_in_a_row >= 2) alone_for_good = true; width = 1; }
+            else { voided_in_a_row = 0; width = group; }
+        }
     }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (nbsucc > 0) {
@@ -3043,7 +3136,8 @@ int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id,
     HIPCHK(hipSetDevice(e->device));
     SweepArgs a;
     shard_round1_args(e, a, beta, sweep_id, labels_old_dev, labels_guess_dev, labels_out_dev);
-    if (!launch_sweep_counts(a, e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream)) {
+    static const bool merge = !(getenv("NEM_DIST_MERGE") && getenv("NEM_DIST_MERGE")[0] == '0');
+    if (!merge || !launch_sweep_counts(a, e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream)) {
         launch_sweep(a, true, e->stream);
         launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, nullptr, e->stream);
     }
@@ -3254,11 +3348,9 @@ int nemgpu_rccl_selftest(nemgpu_engine* e, uint8_t* buf_dev, int stride, int tim
 // enqueued on the engine's stream without returning to the caller in between (what ShardedNem._enqueue_batch
 // does through torch.distributed).  lab[3]: the all-gathered label arrays; stats_off: byte offset of a rank's
 // statistics inside its block; base: buffer of the current partition (2 after an init).
-int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
-                               uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off)
+static int shard_batch_body(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
+                            uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off)
 {
-    if (!e || !lab0 || !lab1 || !lab2 || n_iters < 0 || base < 0 || base > 2) return NEMGPU_E_FUNCARG;
-    if (!e->rccl_comm) { set_error("nemgpu_rccl_attach first"); return NEMGPU_E_FUNCARG; }
     uint8_t* L[3] = {lab0, lab1, lab2};
     const bool use_nei = beta != 0.0f;
     auto own_stats = [&](uint8_t* buf) { return (int32_t*)(buf + (size_t)e->sh_rank * e->sh_stride + stats_off); };
@@ -3294,6 +3386,62 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
     }
 #undef NEM_TRY
     return nemgpu_shard_end_enqueue(e);
+}
+
+int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int base, float beta, int want_stats,
+                               uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off)
+{
+    if (!e || !lab0 || !lab1 || !lab2 || n_iters < 0 || base < 0 || base > 2) return NEMGPU_E_FUNCARG;
+    if (!e->rccl_comm) { set_error("nemgpu_rccl_attach first"); return NEMGPU_E_FUNCARG; }
+    // A rank alone has no collective inside its batches: they go out as hipGraphs of the library's own, captured the
+    // second time a shape is enqueued (as the single engine's batches are).  With more ranks the batch holds RCCL
+    // calls and is issued launch by launch -- one C call either way.
+    nemgpu_engine::ShardGraph* slot = nullptr;
+    if (e->sh_world == 1 && e->use_graphs) {
+        uint32_t bb; memcpy(&bb, &beta, 4);
+        const std::vector<uint64_t> desc = {(uint64_t)with_init, (uint64_t)n_iters, (uint64_t)base, (uint64_t)bb, (uint64_t)want_stats,
+                                            (uint64_t)(uintptr_t)lab0, (uint64_t)(uintptr_t)lab1, (uint64_t)(uintptr_t)lab2, (uint64_t)stats_off};
+        uint64_t key = 1469598103934665603ull;
+        for (uint64_t v : desc) key = (key ^ v) * 1099511628211ull;
+        for (auto& g : e->shard_graphs) if (g.key == key && g.desc == desc) { slot = &g; break; }
+        if (slot == nullptr) {
+            if (e->shard_graphs.size() >= 64) drop_graphs(e);
+            e->shard_graphs.push_back({key, desc, 0, nullptr});
+            slot = &e->shard_graphs.back();
+        }
+        if (slot->exec != nullptr) {
+            { const int cr = shard_check(e); if (cr) return cr; }
+            HIPCHK(hipSetDevice(e->device));
+            HIPCHK(hipGraphLaunch(slot->exec, e->stream));
+            e->n_replayed++;
+            e->stop_ptr = nullptr;
+            return NEMGPU_OK;
+        }
+        if (slot->asked++ >= 1 || e->capture_first) {
+            HIPCHK(hipSetDevice(e->device));
+            if (with_init == 0) { const int fr = flush_reset(e); if (fr) return fr; }      // (nothing pending may be captured)
+            HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            const int r = shard_batch_body(e, with_init, n_iters, base, beta, want_stats, lab0, lab1, lab2, stats_off);
+            hipGraph_t graph = nullptr;
+            const hipError_t cerr = hipStreamEndCapture(e->stream, &graph);
+            hipGraphExec_t exec = nullptr;
+            if (r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                slot->exec = exec;
+                e->n_captured++;
+                HIPCHK(hipGraphLaunch(exec, e->stream));
+                return NEMGPU_OK;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (getenv("NEM_MI355X_DEBUG"))
+                fprintf(stderr, "[nem] sharded batch capture failed: body rc %d (%s), end-capture %s\n", r, g_last_error.c_str(), hipGetErrorString(cerr));
+            (void)hipGetLastError();
+            e->use_graphs = false;                                 // plain launches from now on
+            if (r != NEMGPU_OK) return r;
+        }
+    }
+    e->n_plain++;
+    return shard_batch_body(e, with_init, n_iters, base, beta, want_stats, lab0, lab1, lab2, stats_off);
 }
 
 // host-side completion of an iteration whose sweep needed extra rounds: count it like k_ctrl would have

@@ -287,11 +287,13 @@ class ShardedNem:
         self.beta, self.cvtest, self.cvthres, self.param_fix = float(beta), cvtest, float(cvthres), param_fix
         self.labels = [stepper.alloc(self.stride * comm.world, "uint8") for _ in range(3)]
         import os
-        # whole-batch graph capture (kernels + collectives): on by default for a 1-rank group; with more ranks it
-        # is opt-in (NEM_DIST_GRAPHS=1) because captured RCCL collectives could not be rehearsed on the one-GPU
-        # development box and a wedged replay would cost the whole job, while eager launches are only ~1.7x slower
-        default = "1" if comm.world == 1 else "0"
-        self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", default) != "0"
+        # Whole batches as graphs.  A rank alone (no collective inside a batch) gets them from the LIBRARY
+        # (nemgpu_shard_enqueue_batch captures a batch shape into a hipGraph of its own the second time it is enqueued,
+        # as the single engine does).  Capturing kernels AND collectives through torch (torch.cuda.CUDAGraph) is opt-in
+        # (NEM_DIST_GRAPHS=1): with more ranks captured RCCL collectives could not be rehearsed on the one-GPU
+        # development box and a wedged replay would cost the whole job; with one rank, round 3 saw replays of such a
+        # graph block in hipGraphLaunch for good in two runs out of four once nothing else was enqueued between them.
+        self.use_graphs = os.environ.get("NEM_DIST_GRAPHS", "0") != "0"
         # RCCL straight from the library: a whole batch (kernels + all-gathers) per C call.  On by default over the
         # nccl backend; NEM_DIST_NATIVE=0 keeps every collective in torch.distributed.
         self.native = False
@@ -299,6 +301,8 @@ class ShardedNem:
                 and os.environ.get("NEM_DIST_NATIVE", "1") != "0"):
             self.native = bool(stepper.enable_native(comm))
         self._graphs, self._seen = {}, set()
+        self.library_graphs = bool(self.native and comm.world == 1)
+        self.first_sweep_is_long, self._last_need_rounds = False, False
         self.reset()
 
     @property
@@ -416,6 +420,7 @@ class ShardedNem:
             else:
                 self._enqueue_batch(with_init, g, base)
         res = self.st.end()
+        self._last_need_rounds = res["need_rounds"] == 1
         self.sweep_rounds += res["sweep_rounds"]
         if with_init and res["need_rounds"] == 2:
             # the initial beta sweep was not at its fixed point after two rounds: finish it from the host;
@@ -451,7 +456,15 @@ class ShardedNem:
     def iterate(self, n_iters, with_init=False):
         first, remaining = with_init, int(n_iters)
         while True:
-            done = self._run_batch(first, min(remaining, self.PIPE_DEPTH))
+            # The sweep of the first iteration after a start moves many labels and may need a third relaxation round,
+            # which this pipeline does not enqueue: the iterations behind it in the batch then all return at the stop
+            # word (four launches each, for nothing) and the host finishes the sweep.  A job whose start did that once
+            # sends ONE iteration with its next starts (kept across restarts, like the single engine's deep_iters).
+            depth = 1 if (first and self.first_sweep_is_long) else self.PIPE_DEPTH
+            before = self.iters
+            done = self._run_batch(first, min(remaining, depth))
+            if first and depth > 1 and done >= 1 and self.iters == before + 1 and self._last_need_rounds:
+                self.first_sweep_is_long = True
             first = False
             remaining -= done
             if self.converged or self.status != STATUS_OK or remaining <= 0:

@@ -89,6 +89,8 @@ def load_library():
     lib.nemgpu_get_params.argtypes = [vp, vp, vp, vp, vp]
     lib.nemgpu_get_results.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.nemgpu_solve_many.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    lib.nemgpu_solve_many_devices.argtypes = [vp, C.c_int, vp, ip, C.c_int, C.c_int, C.c_int]
+    lib.nemgpu_deal_groups.argtypes = [C.c_int, C.c_int, C.c_int, ip]
     lib.nemgpu_get_density.argtypes = [vp, vp, vp]
     lib.nemgpu_profile_density.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), ip]
     lib.nemgpu_calibrate_fetch.argtypes = [C.c_size_t, C.c_int]

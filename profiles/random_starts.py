@@ -4,10 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pangenomenem_amd import synth
 from pangenomenem_amd.engine import NemEngine, Result
 rec = []
-for (n, d, tie) in [(5000, 500, "hash"), (20000, 500, "hash"), (20000, 500, "libc")]:
-    x, _ = synth.ushaped_pa_matrix(n, d, 9)
+for (n, d, tie, gen) in [(5000, 500, "hash", "ushape"), (20000, 500, "hash", "ushape"), (20000, 500, "libc", "ushape"),
+                         (20000, 500, "libc", "latent3")]:
+    # (ushape under libc: every start's sweeps draw tie-breaks -- the data hold identical rows; latent3: hardly any do)
+    x, _ = (synth.ushaped_pa_matrix if gen == "ushape" else synth.bernoulli_pa_matrix)(n, d, 9)
     nei = synth.contiguity_graph(n, 9)
-    row = dict(n=n, d=d, tie=tie)
+    row = dict(n=n, d=d, tie=tie, data=gen)
     for mode in ("0", "1"):
         os.environ["NEM_MI355X_BATCH_STARTS"] = mode
         eng = NemEngine(n, d, 3)
@@ -27,6 +29,7 @@ for (n, d, tie) in [(5000, 500, "hash"), (20000, 500, "hash"), (20000, 500, "lib
             go(50); go(50)
             row["fifty_lockstep_replayed_s"] = min(go(50) for _ in range(3))
         row["best_%s" % mode] = best.value
+        row["tie_draws_%s" % mode] = int(r.tie_draws)
         eng.close()
     row["lockstep_over_one_start"] = row["fifty_lockstep_s"] / row["one_start_s"]
     row["speedup"] = row["fifty_sequential_s"] / row["fifty_lockstep_s"]

@@ -319,3 +319,20 @@ def test_tokeniser_numbers_equal_strtof_and_strtol(lib, tmp_path):
     want = np.array([libc.strtof(w.encode(), None) for w in words], np.float32)
     bad = [(w, a, b) for w, a, b in zip(words, wts, want) if np.float32(a).tobytes() != np.float32(b).tobytes()]
     assert not bad, bad[:5]
+
+
+def test_groups_are_dealt_round_robin_over_the_device_list(lib):
+    """nemgpu_solve_many_devices' scheduling (host arithmetic, no GPU): lock-step group g -- problems g*group ..
+    g*group + group - 1 -- goes to slot g % n_devices of the device list; every slot's share is whole groups but the
+    tail; one device takes everything."""
+    from pangenomenem_amd.batch import deal_groups
+    assert deal_groups(10, 3, 2) == [0, 0, 0, 1, 1, 1, 0, 0, 0, 1]
+    assert deal_groups(5, 1, 3) == [0, 1, 2, 0, 1]
+    assert deal_groups(7, 32, 4) == [0] * 7
+    assert deal_groups(6, 2, 1) == [0] * 6
+    assert deal_groups(0, 4, 2) == []
+    for count, group, ndev in ((1000, 32, 8), (333, 7, 5)):
+        slots = deal_groups(count, group, ndev)
+        assert all(slots[i] == (i // group) % ndev for i in range(count))
+        sizes = [slots.count(s) for s in range(ndev)]
+        assert max(sizes) - min(sizes) <= group

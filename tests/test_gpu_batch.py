@@ -207,3 +207,26 @@ def test_lockstep_batch_with_members_that_stop_early(gpu_lib):
             assert np.array_equal(a[key], b[key]), key
     for e in engines:
         e.close()
+
+
+def test_solve_many_over_a_device_list_equals_one_device(gpu_lib):
+    """nemgpu_solve_many_devices: the lock-step groups dealt round-robin over a device list (here twice the one GPU of
+    the box: two pipelines, each with its own worker threads, streams and lock-step contexts) -- every problem's
+    result is bit-identical to the single-device call and to the problem solved alone."""
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import solve
+    probs = _problems(13)
+    probs[6] = (probs[6][0], None) + probs[6][2:]
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", tie="hash", seed=5)
+    one = solve_many(probs, workers=4, group=3, **cfg)
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        many = solve_many(probs, workers=6, group=3, devices=devices, **cfg)
+        for a, b in zip(one, many):
+            assert a["iters"] == b["iters"] and a["status"] == b["status"] and a["converged"] == b["converged"]
+            for f in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+                assert np.array_equal(a[f], b[f]), (devices, f)
+    alone = solve(*probs[9], **cfg)
+    assert np.array_equal(one[9]["c"], alone["c"]) and one[9]["iters"] == alone["iters"]
+    from pangenomenem_amd.engine import NemGpuError
+    with pytest.raises(NemGpuError, match="device"):
+        solve_many(probs[:2], devices=[0, 99], **cfg)
