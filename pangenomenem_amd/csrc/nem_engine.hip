@@ -2745,11 +2745,12 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     // Starts per round.  TIE_LIBC: the starts' centre draws and the sweeps' tie draws are ONE stream, so a round's starts
     // are drawn as if none of them tied and everything behind the first that did is thrown away.  Whether the data tie
     // at all is not known ahead: start 0 runs ALONE, on this engine's own pipelined path (what the sequential form
-    // does); a start that ran alone without a tie opens a full-width round; a voided round is followed by a start
-    // alone again, and after two voided rounds in a row every remaining start runs alone -- data whose every start ties
-    // cost what the sequential form costs, never more.
+    // does); the width of a round follows the starts seen so far -- four times the run of tie-free starts behind it
+    // (1, 4, 20, the rest on tie-free data), one start alone after a start that tied or a round that was voided, and
+    // after two voided rounds in a row every remaining start alone: data whose every start ties cost what the
+    // sequential form costs, data that tie now and then waste a few lock-step starts, never whole rounds of fifty.
     int width = e->libc() ? 1 : group;
-    int voided_in_a_row = 0; bool alone_for_good = false;
+    int voided_in_a_row = 0, clean_run = 0; bool alone_for_good = false;
     if ((r = ensure_clones(e, group))) return r;
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
 
@@ -2809,7 +2810,8 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 }
             }
             next += 1;
-            width = (alone_for_good || tied) ? 1 : group;
+            clean_run = tied ? 0 : clean_run + 1;
+            width = (alone_for_good || clean_run == 0) ? 1 : std::min(group, 4 * clean_run);
             continue;
         }
         HIPCHK(copy_sync(e, e->clone_par0, host_par.data(), host_par.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -2864,8 +2866,8 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
         }
         next += valid;
         if (e->libc()) {
-            if (valid < M) { voided_in_a_row++; if (voided_in_a_row >= 2) alone_for_good = true; width = 1; }
-            else { voided_in_a_row = 0; width = group; }
+            if (valid < M) { voided_in_a_row++; clean_run = 0; if (voided_in_a_row >= 2) alone_for_good = true; width = 1; }
+            else { voided_in_a_row = 0; clean_run += M; width = std::min(group, 4 * clean_run); }
         }
     }
     HIPCHK(hipStreamSynchronize(e->stream));

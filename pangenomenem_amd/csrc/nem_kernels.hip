@@ -75,6 +75,21 @@ __device__ inline long long wave_reduce_add_ll(long long v)
     return ((long long)hi << 20) + (long long)lo;
 }
 
+// s + x0 + x1 + ... + x15, left to right, as sixteen v_add_f32 back to back: a d-ordered float chain on one lane is bound
+// by what stands between two dependent adds, and left to itself the compiler puts a register copy there (it moves every
+// loaded value out of the way of the next load: 1.5 instructions per add, 4.8 ns per organism)
+__device__ __forceinline__ float chain_add16(float s, const float4& a, const float4& b, const float4& c, const float4& d)
+{
+    asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                 "v_add_f32 %0, %0, %5\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\t"
+                 "v_add_f32 %0, %0, %9\n\tv_add_f32 %0, %0, %10\n\tv_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\t"
+                 "v_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\tv_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16"
+                 : "+v"(s)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w),
+                   "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // layout kernels (one-off, at upload time)
 //   xf  [n][W]      family-major bit rows (host layout)
@@ -574,7 +589,7 @@ struct FusedDensityArgs {
 // returns the family tile the block worked on, -1 when it had nothing to do
 __device__ __forceinline__ int density_fused_body(const FusedDensityArgs& a)
 {
-    __shared__ float sVal[FD_MAXD];                      // inertia per organism, later epsilon per organism
+    __shared__ __align__(16) float sVal[FD_MAXD];        // inertia per organism, later epsilon per organism
     __shared__ double2 sT[FD_CH];
     __shared__ double sL[FD_CH];
     __shared__ uint2 sAm[FD_MAXD / 32];                   // {am0, am1} per word
@@ -656,14 +671,9 @@ __device__ __forceinline__ int density_fused_body(const FusedDensityArgs& a)
                 // inertia values sixteen at a time from LDS ahead of the dependent adds, the N_KD chain from a register
                 if (tid == 0) {
                     float si = 0.0f;
+                    const float4* v4 = reinterpret_cast<const float4*>(sVal);
                     int d = 0;
-                    for (; d + 16 <= D; d += 16) {
-                        float v[16];
-#pragma unroll
-                        for (int t = 0; t < 16; t++) v[t] = sVal[d + t];
-#pragma unroll
-                        for (int t = 0; t < 16; t++) si += v[t];
-                    }
+                    for (; d + 16 <= D; d += 16) si = chain_add16(si, v4[d >> 2], v4[(d >> 2) + 1], v4[(d >> 2) + 2], v4[(d >> 2) + 3]);
                     for (; d < D; d++) si += sVal[d];
                     sChain[0] = si;
                 } else if (tid == 64) {
@@ -1714,6 +1724,8 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                 if (tid == 0) {
                     float si = 0.0f;
                     // groups of 32 values, two register sets: one is loaded from LDS while the other is added
+                    // (measured and dropped, round 3: the chain as a block-wide scan of parity maps, binade by binade
+                    //  -- nem_halfchain.hpp, exact, tested -- 42 us against 33.5: seven passes of ~5 us each)
                     const int ng = (D + 31) >> 5, last = CAP / 32 - 1;
                     float4 A[8], B[8];
 #pragma unroll
@@ -1722,13 +1734,13 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                         const int g1 = min(g + 1, last), g2 = min(g + 2, last);
 #pragma unroll
                         for (int j = 0; j < 8; j++) B[j] = s_in4[g1 * 8 + j];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) si = (((si + A[j].x) + A[j].y) + A[j].z) + A[j].w;
+                        si = chain_add16(si, A[0], A[1], A[2], A[3]);
+                        si = chain_add16(si, A[4], A[5], A[6], A[7]);
 #pragma unroll
                         for (int j = 0; j < 8; j++) A[j] = s_in4[g2 * 8 + j];
                         if (g + 1 < ng) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) si = (((si + B[j].x) + B[j].y) + B[j].z) + B[j].w;
+                            si = chain_add16(si, B[0], B[1], B[2], B[3]);
+                            si = chain_add16(si, B[4], B[5], B[6], B[7]);
                         }
                     }
                     s_si = si;
