@@ -813,6 +813,8 @@ __device__ __forceinline__ int density_fused_body(const FusedDensityArgs& a)
 // Runs in the last block to finish of the iteration's bookkeeping kernel (k_labels_post /
 // k_conv_fuzzy), or as its own tiny launch when there is no such kernel.
 // ------------------------------------------------------------------------------------------
+// (measured, round 3: out of line -- __noinline__, the block passed by value -- the kernels that call it need a private
+//  segment, 176 bytes per lane, and every launch of theirs got 3-4 us longer; it stays inline)
 __device__ inline void ctrl_logic(const CtrlArgs& a)
 {
     int* c = a.ctrl;
@@ -989,15 +991,31 @@ __device__ inline bool last_block_ticket(int* ticket, int nblocks, int tally = 0
 // One site's row: ComputeLocalProba (nem_alg.c:2576-2613) from the class contexts.  cf = the normalised row;
 // returns true when the site hit the "density = 0" branch.
 template <int KA>
-__device__ __forceinline__ bool local_proba(const SweepArgs& a, int K, const double* pkf, const float* ctx, float* cf)
+__device__ __forceinline__ bool local_proba(const SweepArgs& a, int K, const double* pkf, const float* ctx, float* cf,
+                                            const double* exp_tab = nullptr, int exp_tab_len = 0)
 {
     double cinum[KA];
     double cum = 0.0;
+    // (exp_tab[m] = exp((double)beta * (double)(float)m) from the same device exp: a context that is such an integer
+    //  takes its factor from the table, every other one runs exp -- decided for the whole row, so that a row costs
+    //  either K table reads or K calls)
+    bool tab = exp_tab != nullptr;
+    int mi[KA];
+    if (tab) {
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+            if (k < K) {
+                const float c = ctx[k];
+                mi[k] = (int)c;
+                tab = tab && c >= 0.0f && c < (float)exp_tab_len && (float)mi[k] == c;
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < KA; k++) {
         if (k < K) {                                     // nem_alg.c:2581-2584
             double v = pkf[k];
-            if (a.use_nei) v = v * exp((double)a.beta * (double)ctx[k]);
+            if (a.use_nei) v = v * (tab ? exp_tab[mi[k]] : exp((double)a.beta * (double)ctx[k]));
             cinum[k] = v;
             cum = cum + v;
         }
@@ -1027,7 +1045,9 @@ constexpr int kTabShort = 1 << 30;                       // in a round's FLAG_NT
 constexpr int kFuzzyWaves = 4;                          // chains (waves) per block of the fuzzy M-step's chain kernels
 constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
 
-template <int KT, bool NCEM, int BS>
+// LIBC: the reference's tie stream (TIE_LIBC) -- its bookkeeping (who drew, per wave and block, at every block-local
+// step) is compiled into the instances that need it only
+template <int KT, bool NCEM, int BS, bool LIBC = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, const int nblk)
 {
     int fold_hint = 0;
@@ -1048,6 +1068,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         return;
     }
     __shared__ int s_nzero, s_first;
+    // NCEM: the MRF factor exp(beta * context) takes few distinct arguments -- the context of a class is a sum of edge
+    // weights, small integers in PPanGGOLiN's graphs (numbers of organisms sharing an adjacency): the block fills a table
+    // exp((double)beta * (double)(float)m), m = 0 .. kExpTab - 1, with the SAME device exp on the same argument the site
+    // would pass (bit-identical by construction), one entry per thread, and a site whose context is such an integer
+    // reads it instead of running three double-precision exp (a third of the round's vector instructions)
+    constexpr int kExpTab = 64;
+    __shared__ double s_exp[NCEM ? kExpTab : 1];
     __shared__ uint8_t s_lab[NCEM ? BS : 1];             // the block's labels while it iterates
     __shared__ uint64_t s_drew[BS / 64];                 // TIE_LIBC: per wave, which of its sites drew
     const int i = bx * BS + threadIdx.x;
@@ -1063,6 +1090,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi] & kLabMask; }
     if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
     if (NCEM) s_lab[threadIdx.x] = (uint8_t)my_guess;
+    if (NCEM && a.use_nei && !skip && threadIdx.x < kExpTab) s_exp[threadIdx.x] = exp((double)a.beta * (double)(float)threadIdx.x);
     __syncthreads();
 
     if (NCEM) {
@@ -1075,7 +1103,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     // the plain round would, and the sweep still ends with a round that changes nothing anywhere.  What it buys is
     // rounds: label changes run down the path inside one launch instead of one launch per hop.
     // ------------------------------------------------------------------------------------------
-    const bool libc = a.tie_rule == NEMGPU_TIE_LIBC;
+    constexpr bool libc = LIBC;
     const int blk_lo = a.lo + bx * BS;           // first label slot of this block
     double pkf[KA];
 #pragma unroll
@@ -1153,7 +1181,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
                         if (k < K) ctx[k] = ctx[k] + ((l == k) ? wt : -0.0f);
                 }
                 float cf[KA];
-                zero_density = local_proba<KA>(a, K, pkf, ctx, cf);
+                zero_density = local_proba<KA>(a, K, pkf, ctx, cf, s_exp, kExpTab);
                 // ComputeMAP, nem_alg.c:603-640
                 int kmax = 0; float ukmax = cf[0];
 #pragma unroll
@@ -3131,10 +3159,10 @@ __global__ __launch_bounds__(256) void k_density(DensityArgs a) { density_body(a
 __global__ __launch_bounds__(256) void k_density_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(DensityArgs) density_body(a); }
 __global__ __launch_bounds__(256) void k_density_fused(FusedDensityArgs a) { (void)density_fused_body(a); }
 __global__ __launch_bounds__(256) void k_density_fused_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FusedDensityArgs) (void)density_fused_body(a); }
-template <int KT, bool NCEM, int BS>
-__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS>(a, blockIdx.x, gridDim.x); }
-template <int KT, bool NCEM, int BS>
-__global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS>(a, blockIdx.x, nblk); }
+template <int KT, bool NCEM, int BS, bool LIBC = false>
+__global__ __launch_bounds__(BS) void k_sweep(SweepArgs a) { sweep_body<KT, NCEM, BS, LIBC>(a, blockIdx.x, gridDim.x); }
+template <int KT, bool NCEM, int BS, bool LIBC = false>
+__global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(SweepArgs) sweep_body<KT, NCEM, BS, LIBC>(a, blockIdx.x, nblk); }
 // One relaxation round (blocks [0, nsweep)) and the M-step counts of the partition it verifies (the other blocks: its
 // class masks were made by the round before) side by side in ONE launch -- the sharded iteration's second half, where
 // the counts are taken from round 0's labels while round 1, the verifying round, runs.  The two do not depend on each
@@ -3143,7 +3171,7 @@ __global__ __launch_bounds__(BS) void k_sweep_b(const void* arr, int stride, con
 template <int KT, int R>
 __global__ __launch_bounds__(256) void k_sweep_counts(SweepArgs s, CountsArgs c, int nsweep)
 {
-    if ((int)blockIdx.x < nsweep) { sweep_body<KT, true, 256>(s, blockIdx.x, nsweep); return; }
+    if ((int)blockIdx.x < nsweep) { sweep_body<KT, true, 256, false>(s, blockIdx.x, nsweep); return; }   // (the sharded path has no TIE_LIBC)
     mstep_counts_body<R>(c.K, c.D, c.nw64, c.xt, c.mask, c.stats, c.stop, CtrlArgs{}, (int)blockIdx.x - nsweep, (int)gridDim.x - nsweep);
 }
 
@@ -3265,27 +3293,27 @@ static bool record_op(int kind, int variant, dim3 grid, unsigned block, const Ar
     return true;
 }
 
-static int sweep_variant(int K, bool ncem, bool big) { return (K >= 1 && K <= 10 ? K : 0) | (ncem ? 16 : 0) | (big ? 32 : 0); }
+static int sweep_variant(int K, bool ncem, bool big, bool libc) { return (K >= 1 && K <= 10 ? K : 0) | (ncem ? 16 : 0) | (big ? 32 : 0) | (libc && ncem ? 64 : 0); }
 
 template <bool BATCHED>
 static void sweep_dispatch(int variant, dim3 grid, hipStream_t s, const SweepArgs* a, const void* arr, int stride, const int* gx)
 {
-    const int kt = variant & 15; const bool ncem = (variant & 16) != 0, big = (variant & 32) != 0;
+    const int kt = variant & 15; const bool ncem = (variant & 16) != 0, big = (variant & 32) != 0, libc = (variant & 64) != 0;
     dim3 block(big ? 1024 : 256);
-#define NEM_SW2(KT_, NC_, BS_)                                                                                     \
+#define NEM_SW2(KT_, NC_, BS_, LC_)                                                                                \
     do {                                                                                                           \
-        if (BATCHED) hipLaunchKernelGGL((k_sweep_b<KT_, NC_, BS_>), grid, block, 0, s, arr, stride, gx);          \
-        else hipLaunchKernelGGL((k_sweep<KT_, NC_, BS_>), grid, block, 0, s, *a);                                  \
+        if (BATCHED) hipLaunchKernelGGL((k_sweep_b<KT_, NC_, BS_, LC_>), grid, block, 0, s, arr, stride, gx);     \
+        else hipLaunchKernelGGL((k_sweep<KT_, NC_, BS_, LC_>), grid, block, 0, s, *a);                             \
     } while (0)
 #define NEM_SW(KT_)                                                                                                \
     case KT_:                                                                                                      \
-        if (big) { if (ncem) NEM_SW2(KT_, true, 1024); else NEM_SW2(KT_, false, 1024); }                           \
-        else { if (ncem) NEM_SW2(KT_, true, 256); else NEM_SW2(KT_, false, 256); }                                 \
+        if (big) { if (!ncem) NEM_SW2(KT_, false, 1024, false); else if (libc) NEM_SW2(KT_, true, 1024, true); else NEM_SW2(KT_, true, 1024, false); } \
+        else { if (!ncem) NEM_SW2(KT_, false, 256, false); else if (libc) NEM_SW2(KT_, true, 256, true); else NEM_SW2(KT_, true, 256, false); }       \
         break;
     switch (kt) {
         NEM_SW(1) NEM_SW(2) NEM_SW(3) NEM_SW(4) NEM_SW(5) NEM_SW(6) NEM_SW(7) NEM_SW(8) NEM_SW(9) NEM_SW(10)
     default:
-        if (ncem) NEM_SW2(0, true, 256); else NEM_SW2(0, false, 256);
+        if (!ncem) NEM_SW2(0, false, 256, false); else if (libc) NEM_SW2(0, true, 256, true); else NEM_SW2(0, true, 256, false);
     }
 #undef NEM_SW
 #undef NEM_SW2
@@ -3299,7 +3327,7 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
     const bool big = a.n_local >= 65536 && !generic;
     const int bs = big ? 1024 : 256;
     dim3 grid((a.n_local + bs - 1) / bs);
-    const int variant = sweep_variant(a.K, ncem, big);
+    const int variant = sweep_variant(a.K, ncem, big, a.tie_rule == NEMGPU_TIE_LIBC);
     if (record_op(OP_SWEEP, variant, grid, (unsigned)bs, a)) return;
     sweep_dispatch<false>(variant, grid, s, &a, nullptr, 0, nullptr);
 }
@@ -3367,7 +3395,7 @@ void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int np
 bool launch_sweep_counts(const SweepArgs& sw, int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
                          const int* stop, hipStream_t s)
 {
-    if (current_recorder() != nullptr || sw.n_local >= 65536 || K < 2 || K > 5) return false;
+    if (current_recorder() != nullptr || sw.n_local >= 65536 || K < 2 || K > 5 || sw.tie_rule == NEMGPU_TIE_LIBC) return false;
     CountsArgs c{K, D, nw64, xt, mask, stats, stop, CtrlArgs{}};
     const int nsweep = (sw.n_local + 255) / 256;
     const bool wide = D + 1 >= 1024;

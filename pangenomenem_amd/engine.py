@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnem_mi355x.so")
+# (NEM_MI355X_LIB: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("NEM_MI355X_LIB") or os.path.join(_HERE, "lib", "libnem_mi355x.so")
 
 ALGO = {"nem": 0, "ncem": 1}
 DISP = {"s__": 0, "sk_": 1, "s_d": 2, "skd": 3}
