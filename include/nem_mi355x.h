@@ -261,6 +261,19 @@ int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, con
                                   const uint8_t* labels_q_dev, const uint8_t* labels_r_dev);
 int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
                             const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int* changed);
+/* NEMGPU_TIE_LIBC in the sharded path (nem_alg.c:617-637 -> nem_rnd.c:53-61): a tied site draws random() number
+   `draws before the sweep + sites below it that drew in this sweep`, and the sites of the ranks below come first.  Every
+   rank's draws of the round that produced a label array ride in its block's tail (an int32, nemgpu_shard_layout's
+   blk rounded up to 4, + 4), all-gathered with the labels; every rank holds the same window of the same stream.
+   nemgpu_shard_set_labels: the driver's three label arrays (the engine keeps each one's per-block draw counts).
+   A start under this rule is completed from the host, sweep by sweep (the blind sweep's ties come first in the
+   stream): nemgpu_shard_round_sync rounds until no rank changes anything, nemgpu_shard_round_draws after each (this
+   rank's draws; table_short: a draw fell outside the table -- the round is void everywhere: nemgpu_shard_grow_draws on
+   every rank, then the round again), nemgpu_shard_book_draws(sum over the ranks of the final round's draws). */
+int nemgpu_shard_set_labels(nemgpu_engine* e, const uint8_t* lab0, const uint8_t* lab1, const uint8_t* lab2);
+int nemgpu_shard_round_draws(nemgpu_engine* e, int* draws, int* table_short);
+int nemgpu_shard_grow_draws(nemgpu_engine* e);
+int nemgpu_shard_book_draws(nemgpu_engine* e, int n);
 int nemgpu_shard_end_enqueue(nemgpu_engine* e);   /* async copy of the control block; last call of a batch */
 int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* need_rounds);   /* sync + report */
 int nemgpu_shard_set_sweep_number(nemgpu_engine* e, int next_sweep);

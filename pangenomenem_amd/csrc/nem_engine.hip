@@ -57,6 +57,8 @@ struct nemgpu_engine {
     int n_true = 0;               // families of the whole problem (= n_total unless label slots carry padding)
     void* rccl_comm = nullptr;           // native RCCL communicator of a sharded engine (nemgpu_rccl_attach)
     int sh_world = 1, sh_rank = 0, sh_blk = 0, sh_stride = 0;   // sharded label-slot layout (stride 0 = plain)
+    const uint8_t* shard_lab[3] = {nullptr, nullptr, nullptr};   // the driver's three all-gathered label arrays (TIE_LIBC: tie_cnt[b] goes with shard_lab[b])
+    int sh_tot_off() const { return ((sh_blk + 3) & ~3) + 4; }   // a rank's int32 draw total inside its block (behind the flag bytes)
     int npad = 0, dpad = 0, W = 0, wf = 0, nw64 = 0, device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -2142,7 +2144,6 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     if (cfg->cvtest != NEMGPU_CV_NONE && !(cfg->cvthres > 0)) { set_error("convergence threshold must be > 0"); return NEMGPU_E_ARG; }
     if (cfg->it_max < 0) { set_error("it_max must be >= 0"); return NEMGPU_E_ARG; }
     if (cfg->tie_rule != NEMGPU_TIE_FIRST && cfg->tie_rule != NEMGPU_TIE_HASH && cfg->tie_rule != NEMGPU_TIE_LIBC) { set_error("bad tie rule"); return NEMGPU_E_ARG; }
-    if (cfg->tie_rule == NEMGPU_TIE_LIBC && e->sh_stride != 0) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_ARG; }
     if (cfg->tie_seed != e->cfg.tie_seed || cfg->tie_rule != e->cfg.tie_rule) e->draw_valid = false;
     e->cfg = *cfg;
     HIPCHK(hipSetDevice(e->device));
@@ -2975,8 +2976,22 @@ void shard_sweep_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id)
     a.stop = e->stop_ptr;
     a.n_ranks = e->sh_world; a.slot_stride = e->sh_stride; a.slot_pad = e->sh_stride - e->sh_blk;
     a.fold_ticket = e->sweep_next + 32;
+    if (e->libc()) { sweep_draw_args(e, a, e->stop_ptr == nullptr); a.rank_index = e->sh_rank; }
 }
 uint8_t* own_flag_byte(nemgpu_engine* e, uint8_t* labels) { return labels + (size_t)e->sh_rank * e->sh_stride + e->sh_blk; }
+int shard_buf(const nemgpu_engine* e, const uint8_t* p) { for (int b = 0; b < 3; b++) if (e->shard_lab[b] == p) return b; return -1; }
+// TIE_LIBC: the draw counts that go with a round's guess and output buffers -- per block (the engine's, by buffer) and
+// per rank (in the buffers' block tails, all-gathered with the labels)
+int shard_tie_args(nemgpu_engine* e, SweepArgs& a, const uint8_t* guess, uint8_t* out)
+{
+    if (!e->libc()) return NEMGPU_OK;
+    const int g = shard_buf(e, guess), o = shard_buf(e, out);
+    if (g < 0 || o < 0) { set_error("TIE_LIBC in the sharded path: a label array that nemgpu_shard_set_labels was not told about"); return NEMGPU_E_FUNCARG; }
+    a.tie_cnt_guess = e->tie_cnt[g]; a.tie_cnt_out = e->tie_cnt[o];
+    a.rank_tot_in = guess + e->sh_tot_off();
+    a.rank_tot_out = out + (size_t)e->sh_rank * e->sh_stride + e->sh_tot_off();
+    return NEMGPU_OK;
+}
 void shard_round1_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id, const uint8_t* labels_old_dev,
                        const uint8_t* labels_guess_dev, uint8_t* labels_out_dev)
 {
@@ -2998,7 +3013,10 @@ static int shard_check(nemgpu_engine* e)
     if (!e) return NEMGPU_E_FUNCARG;
     if (!e->ncem()) { set_error("the sharded path is NCEM-only (SURVEY.md 8e)"); return NEMGPU_E_FUNCARG; }
     if (e->sh_stride == 0) { set_error("nemgpu_shard_layout must be called first"); return NEMGPU_E_FUNCARG; }
-    if (e->libc()) { set_error("the family-sharded path has no shared draw stream: use the hash tie rule"); return NEMGPU_E_FUNCARG; }
+    if (e->libc() && (e->shard_lab[0] == nullptr || e->sh_tot_off() + 4 > e->sh_stride)) {
+        set_error("TIE_LIBC in the sharded path: nemgpu_shard_set_labels first (and a block tail of at least 12 bytes)");
+        return NEMGPU_E_FUNCARG;
+    }
     if (crit_test(e)) {
         // (the criterion is an i-ordered float sum over ALL families: no sharded reduction reproduces it, and the loop
         //  control of this path only knows the clas test -- a run configured with crit would never converge)
@@ -3014,6 +3032,11 @@ int nemgpu_shard_begin(nemgpu_engine* e)
     HIPCHK(hipSetDevice(e->device));
     { const int fr = flush_reset(e); if (fr) return fr; }
     HIPCHK(hipMemsetAsync(e->ctrl(), 0, C_WORDS * sizeof(int), e->stream));
+    if (e->libc()) {                                               // the stream's window and position, as every rank has them
+        int r;
+        if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+        if ((r = publish_draw_ctl(e))) return r;
+    }
     e->stop_ptr = e->ctrl() + C_STOP;
     return NEMGPU_OK;
 }
@@ -3036,6 +3059,10 @@ int nemgpu_shard_begin_restart(nemgpu_engine* e)
     launch_finish(t, e->stream);
     HIPCHK(hipGetLastError());
     e->tables_fresh = true; e->density_fresh = false;
+    if (e->libc()) {                                               // (srandom(seed): the stream starts over)
+        if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+        if ((r = publish_draw_ctl(e))) return r;
+    }
     e->stop_ptr = e->ctrl() + C_STOP;
     return NEMGPU_OK;
 }
@@ -3109,6 +3136,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
     a.post_on = 1; a.post_from_guess = 0; a.post_moved = blind ? 0 : 1; a.post_nw64 = e->nw64; a.post_mask = e->mask;
     a.post_flags = e->iter_flags();                                // ("moved" byte: final when this is the sweep's only round)
     a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
+    if ((r = shard_tie_args(e, a, labels_old_dev, labels_out_dev))) return r;
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = blind && e->flags_clean;
@@ -3124,6 +3152,7 @@ int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const 
     HIPCHK(hipSetDevice(e->device));
     SweepArgs a;
     shard_round1_args(e, a, beta, sweep_id, labels_old_dev, labels_guess_dev, labels_out_dev);
+    { const int tr = shard_tie_args(e, a, labels_guess_dev, labels_out_dev); if (tr) return tr; }
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
@@ -3138,6 +3167,7 @@ int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id,
     HIPCHK(hipSetDevice(e->device));
     SweepArgs a;
     shard_round1_args(e, a, beta, sweep_id, labels_old_dev, labels_guess_dev, labels_out_dev);
+    { const int tr = shard_tie_args(e, a, labels_guess_dev, labels_out_dev); if (tr) return tr; }
     static const bool merge = !(getenv("NEM_DIST_MERGE") && getenv("NEM_DIST_MERGE")[0] == '0');
     if (!merge || !launch_sweep_counts(a, e->k, e->d, e->nw64, e->xt, e->mask, stats_dev, e->stop_ptr, e->stream)) {
         launch_sweep(a, true, e->stream);
@@ -3162,7 +3192,10 @@ int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, con
     if (is_init) ca.blind = e->round_flags(kRoundCap - 1);         // (the blind sweep's zero-density tally)
     // every rank's "one of my labels moved" byte came with the gather of the sweep's last round: round 1's, or -- no
     // neighbours to verify against (beta = 0) -- round 0's
-    ca.moved_bytes = is_init ? 0 : (beta != 0.0f ? 1 : 2);
+    const bool two_rounds = beta != 0.0f || e->libc();             // (the reference's tie stream couples the sites of a sweep without neighbours too)
+    ca.use_nei = two_rounds ? 1 : 0;
+    ca.moved_bytes = is_init ? 0 : (two_rounds ? 1 : 2);
+    if (e->libc()) { ca.draw_ctl = e->draw_ctl; ca.q_tot = labels_q_dev + e->sh_tot_off(); }
     launch_ctrl(ca, e->stream);
     HIPCHK(hipGetLastError());
     return NEMGPU_OK;
@@ -3182,6 +3215,15 @@ int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const ui
     e->stop_ptr = saved;
     a.lab_old = labels_old_dev; a.lab_guess = labels_guess_dev; a.lab_out = labels_out_dev;
     a.flags = e->round_flags(2);
+    if (e->libc()) {
+        // (the window of the stream at the host's position; the rank's draws of this round go to its block's tail:
+        //  the last block of the round writes them with the flag byte)
+        int r;
+        if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+        sweep_draw_args(e, a, true);
+        a.publish_byte = own_flag_byte(e, labels_out_dev); a.publish_ticket = e->sweep_next + 32;
+        if ((r = shard_tie_args(e, a, labels_guess_dev, labels_out_dev))) return r;
+    }
     HIPCHK(hipMemsetAsync(e->round_flags(2), 0, FLAG_ROUND_STRIDE * sizeof(int), e->stream));
     launch_sweep(a, true, e->stream);
     HIPCHK(hipGetLastError());
@@ -3190,6 +3232,33 @@ int nemgpu_shard_round_sync(nemgpu_engine* e, float beta, int sweep_id, const ui
     *changed = e->h_round(2)[FLAG_CHANGED] != 0;
     return NEMGPU_OK;
 }
+
+// TIE_LIBC in the sharded path, host side.  nemgpu_shard_set_labels: the driver's three all-gathered label arrays (the
+// engine keeps each one's per-block draw counts).  nemgpu_shard_round_draws: after nemgpu_shard_round_sync -- this
+// rank's draws in that round, and whether one of them fell outside the draw table (then the round is void on every
+// rank: nemgpu_shard_grow_draws on all of them and the round again).  nemgpu_shard_book_draws: a sweep the host
+// completed drew n numbers (the sum of the ranks' draws of its final round): the stream moves on.
+int nemgpu_shard_set_labels(nemgpu_engine* e, const uint8_t* lab0, const uint8_t* lab1, const uint8_t* lab2)
+{
+    if (!e || !lab0 || !lab1 || !lab2) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    e->shard_lab[0] = lab0; e->shard_lab[1] = lab1; e->shard_lab[2] = lab2;
+    alloc_for(e);
+    for (int b = 0; b < 3; b++)
+        if (!e->tie_cnt[b]) { const int r = dev_alloc(&e->tie_cnt[b], (size_t)e->n / 256 + 2); if (r) return r; }
+    drop_graphs(e);
+    return NEMGPU_OK;
+}
+int nemgpu_shard_round_draws(nemgpu_engine* e, int* draws, int* table_short)
+{
+    if (!e) return NEMGPU_E_FUNCARG;
+    const int v = e->h_round(2)[FLAG_NTIES];
+    if (draws) *draws = v & ((1 << 30) - 1);
+    if (table_short) *table_short = (v >> 30) & 1;
+    return NEMGPU_OK;
+}
+int nemgpu_shard_grow_draws(nemgpu_engine* e) { if (!e) return NEMGPU_E_FUNCARG; e->tie_heavy = true; return NEMGPU_OK; }
+int nemgpu_shard_book_draws(nemgpu_engine* e, int n) { if (!e || n < 0) return NEMGPU_E_FUNCARG; e->draws += n; return NEMGPU_OK; }
 
 // end of a batch: read the loop-control block back (one sync).  res->iters etc. are the batch's increments.
 int nemgpu_shard_end_enqueue(nemgpu_engine* e)
@@ -3218,6 +3287,10 @@ int nemgpu_shard_end(nemgpu_engine* e, nemgpu_result* res, int* commits, int* ne
     }
     if (commits) *commits = c[C_COMMITS];
     if (need_rounds) *need_rounds = c[C_NEED_ROUNDS];
+    if (e->libc()) {
+        e->draws += c[C_DRAWS];                                    // (the committed sweeps' draws: where the next one starts)
+        for (int q = 0; q < 2; q++) if (e->h_round(q)[FLAG_NTIES] & (1 << 30)) e->tie_heavy = true;
+    }
     e->flags_clean = false;
     return NEMGPU_OK;
 }
@@ -3354,7 +3427,7 @@ static int shard_batch_body(nemgpu_engine* e, int with_init, int n_iters, int ba
                             uint8_t* lab0, uint8_t* lab1, uint8_t* lab2, int stats_off)
 {
     uint8_t* L[3] = {lab0, lab1, lab2};
-    const bool use_nei = beta != 0.0f;
+    const bool use_nei = beta != 0.0f || e->libc();                // two rounds: neighbours to verify against, or the shared draw stream
     auto own_stats = [&](uint8_t* buf) { return (int32_t*)(buf + (size_t)e->sh_rank * e->sh_stride + stats_off); };
     auto all_stats = [&](uint8_t* buf) { return (const int32_t*)(buf + stats_off); };
     int r;
@@ -3399,7 +3472,7 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
     // second time a shape is enqueued (as the single engine's batches are).  With more ranks the batch holds RCCL
     // calls and is issued launch by launch -- one C call either way.
     nemgpu_engine::ShardGraph* slot = nullptr;
-    if (e->sh_world == 1 && e->use_graphs) {
+    if (e->sh_world == 1 && e->use_graphs && !e->libc()) {        // (TIE_LIBC: the stream's position is a launch argument)
         uint32_t bb; memcpy(&bb, &beta, 4);
         const std::vector<uint64_t> desc = {(uint64_t)with_init, (uint64_t)n_iters, (uint64_t)base, (uint64_t)bb, (uint64_t)want_stats,
                                             (uint64_t)(uintptr_t)lab0, (uint64_t)(uintptr_t)lab1, (uint64_t)(uintptr_t)lab2, (uint64_t)stats_off};

@@ -835,8 +835,12 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     for (int r = 0; r < kMaxRounds; r++) rf[r] = r < nr ? reinterpret_cast<const int4*>(a.round0)[r] : make_int4(1, 0, 0, 0);
     int4 bf = make_int4(0, 0, 0, 0);
     if (a.is_init && a.blind != nullptr) bf = *reinterpret_cast<const int4*>(a.blind);
-    int draw0 = 0;
-    if (a.draw_ctl != nullptr) draw0 = a.draw_ctl[0];
+    int draw0 = 0, rank_draws = 0;
+    if (a.draw_ctl != nullptr) {
+        draw0 = a.draw_ctl[0];
+        if (a.q_tot != nullptr)                                   // sharded: every rank's draws of the sweep's final round
+            for (int r = 0; r < a.n_ranks; r++) rank_draws += *reinterpret_cast<const int*>(a.q_tot + (size_t)r * a.flag_stride);
+    }
     int ch0 = 0, ch1 = 0, mv = 0;
     if (a.q_flags != nullptr) {                                   // sharded: every rank's flag bytes (all-gathered)
         for (int r = 0; r < a.n_ranks; r++) {
@@ -896,7 +900,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     }
     c[C_FOLD] = f.y > 0;
     if (a.draw_ctl != nullptr) {                                  // TIE_LIBC: the sweep's draws move the stream on
-        const int nt = f.w & ((1 << 30) - 1);
+        const int nt = a.q_tot != nullptr ? rank_draws : (f.w & ((1 << 30) - 1));
         a.draw_ctl[0] = draw0 + nt;
         c[C_DRAWS] = draws + nt;
     }
@@ -1199,6 +1203,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
                             if (lower_draws < 0) {
                                 lower_draws = 0;
                                 for (int b = 0; b < bx; b++) lower_draws += a.tie_cnt_guess[b];
+                                if (a.rank_tot_in != nullptr)    // sharded: the ranks below, as the guess has them
+                                    for (int r = 0; r < a.rank_index; r++)
+                                        lower_draws += *reinterpret_cast<const int*>(a.rank_tot_in + (size_t)r * a.slot_stride);
                             }
                             int base = a.draw_base, tab0 = a.draw_tab0;
                             if (a.draw_ctl != nullptr) { base = a.draw_ctl[0]; tab0 = a.draw_ctl[1]; }
@@ -1329,6 +1336,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
                 *a.publish_byte = (uint8_t)(__hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
                 if (NCEM && a.post_on && a.post_moved)          // (sharded: this rank's 'a label moved' byte rides next to it)
                     a.publish_byte[1] = (uint8_t)(__hip_atomic_load(&a.post_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+                if (LIBC && a.rank_tot_out != nullptr)           // (... and its draws of this round)
+                    *reinterpret_cast<int*>(a.rank_tot_out) =
+                        __hip_atomic_load(&a.flags[FLAG_NTIES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (kTabShort - 1);
             }
             if (post_ctrl) ctrl_logic(a.post_ctrl);
         }

@@ -42,6 +42,7 @@ struct CtrlArgs {
     int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
     const int* blind;              // is_init: flag slot of the blind beta = 0 sweep (its zero-density tally), or nullptr
     int* draw_ctl;                 // TIE_LIBC: {draws made so far, first draw of the table} (device), else nullptr
+    const uint8_t* q_tot;          // TIE_LIBC, sharded: rank 0's draw total in the tail of the sweep's first buffer (flag_stride apart)
 };
 void launch_ctrl(const CtrlArgs& a, hipStream_t s);
 
@@ -85,6 +86,11 @@ struct SweepArgs {
     const uint32_t* draw_tab; int draw_tab_len, draw_base, draw_tab0;
     const int* draw_ctl; const int* draw_extra;
     const int* tie_cnt_guess; int* tie_cnt_out;
+    // ... sharded: the sites of the ranks below come first in the draw order.  Every rank's draws of the round that
+    // produced a label buffer ride in its block's tail (an int32), all-gathered with the labels: rank_tot_in = rank 0's
+    // in the GUESS buffer (the others slot_stride bytes apart), rank_index = this rank, rank_tot_out = this rank's slot
+    // in the output buffer (written by the last block of the round)
+    const uint8_t* rank_tot_in; int rank_index; uint8_t* rank_tot_out;
 };
 // argument blocks of the kernels whose launch wrappers take scalars (the batched launches need them as structs)
 struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const uint8_t* lab_old; uint64_t* mask; int* flags;

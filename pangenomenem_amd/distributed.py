@@ -83,6 +83,13 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
 
+    def allreduce_sum_int(self, v):
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64)
+        if self.backend != "gloo":
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
     def allreduce_max_int(self, v):
         t = self.torch.tensor([int(v)], dtype=self.torch.int32)
         if self.backend != "gloo":
@@ -127,6 +134,7 @@ class GpuStepper:
         self.eng.set_params(prop, center, disp)
         self.eng.configure(**cfg)
         self.eng.shard_layout(world, rank, blk, stride, n_total)
+        self.libc = cfg.get("tie", "hash") == "libc" and cfg.get("algo", "ncem") == "ncem"
 
     def alloc(self, n, dtype):
         return self.torch.zeros(n, dtype=getattr(self.torch, dtype), device=self.device)
@@ -198,6 +206,25 @@ class GpuStepper:
 
     def stats_words(self):
         return self.eng.stats_words()
+
+    # ---- TIE_LIBC (the reference's tie stream): see nemgpu_shard_set_labels in include/nem_mi355x.h
+    def set_labels(self, labels):
+        self.eng.shard_set_labels([t.data_ptr() for t in labels])
+
+    def reset_now(self):
+        self.eng.reset()
+
+    def density(self):
+        self.eng.lib.nemgpu_density(self.eng._h)
+
+    def round_draws(self):
+        return self.eng.shard_round_draws()
+
+    def grow_draws(self):
+        self.eng.shard_grow_draws()
+
+    def book_draws(self, n):
+        self.eng.shard_book_draws(n)
 
     def reset(self):
         pass        # (a run starts with begin(restart=True): the reset is the head launch of its first batch)
@@ -286,6 +313,11 @@ class ShardedNem:
         self.lo, self.hi, _ = shard_bounds(n_total, comm.world, comm.rank)
         self.beta, self.cvtest, self.cvthres, self.param_fix = float(beta), cvtest, float(cvthres), param_fix
         self.labels = [stepper.alloc(self.stride * comm.world, "uint8") for _ in range(3)]
+        # the reference's tie stream (TIE_LIBC): the sites of a sweep are coupled through the stream's position even
+        # without neighbours (two rounds always), and a start is completed from the host, sweep by sweep
+        self.libc = bool(getattr(stepper, "libc", False))
+        if self.libc:
+            stepper.set_labels(self.labels)
         import os
         # Whole batches as graphs.  A rank alone (no collective inside a batch) gets them from the LIBRARY
         # (nemgpu_shard_enqueue_batch captures a batch shape into a hipGraph of its own the second time it is enqueued,
@@ -316,16 +348,20 @@ class ShardedNem:
         self.iters, self.converged, self.status, self.emptyk, self.sweep_rounds = 0, False, STATUS_OK, 0, 0
 
     def _block_view(self, t):
-        return t.reshape(self.comm.world, self.stride)[:, :self.blk]
+        return t.reshape(self.comm.world, self.stride)[:, :self.blk] & 0x7F      # (bit 7: the site drew, TIE_LIBC)
+
+    @property
+    def two_rounds(self):
+        return self.beta != 0.0 or self.libc
 
     # ---- enqueue helpers (no host synchronisation)
     def _stats_buf(self, cur):
         """Which label array's tails hold the statistics of the partition in buffer `cur`: the array gathered
         last in the iteration that produced it (its R buffer with a graph, the partition's own buffer without)."""
-        return (cur + 1) % 3 if self.beta != 0.0 else cur
+        return (cur + 1) % 3 if self.two_rounds else cur
 
     def _enqueue_init(self):
-        L, use_nei, want_stats = self.labels, self.beta != 0.0, not self.param_fix
+        L, use_nei, want_stats = self.labels, self.two_rounds, not self.param_fix
         self.st.estep_round0(None, 0.0, 0, L[0], L[1])                    # blind beta = 0 sweep (nem_alg.c:1972-1976)
         self.comm.allgather_blocks_(L[1], self.stride)
         self.st.estep_round0(None, self.beta, 1, L[1], L[2])              # the sweep with the real beta (:1980)
@@ -339,7 +375,7 @@ class ShardedNem:
 
     def _enqueue_iteration(self, P):
         L, Q, R = self.labels, (P + 1) % 3, (P + 2) % 3
-        use_nei, want_stats = self.beta != 0.0, not self.param_fix        # (parameters fixed: nem_alg.c:1806)
+        use_nei, want_stats = self.two_rounds, not self.param_fix         # (parameters fixed: nem_alg.c:1806)
         self.st.estep_round0(L[self._stats_buf(P)] if want_stats else None, self.beta, -1, L[P], L[Q])
         if want_stats and not use_nei:
             self.st.counts(L[Q])
@@ -368,20 +404,45 @@ class ShardedNem:
             self.st.mstep_partial(self.labels[cur], dst)
             self.comm.allgather_blocks_(dst, self.stride)
 
-    def _finish_sweep_on_host(self, P, sweep_id):
-        """A sweep that needed more than two relaxation rounds: continue them with a host check per round."""
+    def _finish_sweep_on_host(self, P, sweep_id, first_round=2, beta=None):
+        """A sweep whose rounds the host checks one by one: from round 2 on when the two enqueued rounds of a pipelined
+        sweep did not reach the fixed point, from round 0 on for the sweeps of a start under TIE_LIBC (whose draws come
+        one sweep after the other in the stream).  TIE_LIBC: a round one of whose draws fell outside the draw table is
+        void on every rank (the tables grow, the round runs again); the stream moves on by the ranks' draws of the
+        final round."""
         L, Q, R = self.labels, (P + 1) % 3, (P + 2) % 3
-        r = 2
+        beta = self.beta if beta is None else beta
+        r, draws = first_round, 0
         while True:
-            guess, out = (R, Q) if r % 2 == 0 else (Q, R)
+            guess, out = (P, Q) if r == 0 else ((R, Q) if r % 2 == 0 else (Q, R))
             with self.st.on_stream():
-                changed = self.st.round_sync(self.beta, sweep_id, L[P], L[guess], L[out])
+                changed = self.st.round_sync(beta, sweep_id, L[P], L[guess], L[out])
+                if self.libc:
+                    draws, short = self.st.round_draws()
+                    if self.comm.allreduce_max_int(short) != 0:
+                        self.st.grow_draws()
+                        continue
                 self.comm.allgather_blocks_(L[out], self.stride)
                 r += 1
                 if self.comm.allreduce_max_int(changed) == 0:
                     break
-        self.sweep_rounds += r            # out == guess now, so L[Q] holds the result whichever buffer was last
+        if self.libc:
+            self.st.book_draws(self.comm.allreduce_sum_int(draws))
+        self.sweep_rounds += r - first_round if first_round == 0 else r   # out == guess now, so L[Q] holds the result whichever buffer was last
         return Q
+
+    def _host_start(self):
+        """ComputePartitionFromPara(Needinit=1) under TIE_LIBC: the blind sweep and the sweep with the real beta, each
+        completed (its rounds verified, its draws booked) before the next begins -- in the reference's stream the blind
+        sweep's ties come first (nem_alg.c:1972-1980)."""
+        self.st.reset_now()
+        with self.st.on_stream():
+            self.st.density()
+        self._finish_sweep_on_host(0, 0, first_round=0, beta=0.0)         # 0 -> 1
+        self._finish_sweep_on_host(1, 1, first_round=0)                   # 1 -> 2
+        self.cur, self.sweep_id = 2, 2
+        self.st.set_sweep_number(2)
+        self._publish_stats(2)
 
     def _enqueue_batch(self, with_init, g, base):
         if self.native:
@@ -400,6 +461,10 @@ class ShardedNem:
     def _run_batch(self, with_init, g):
         """Enqueue [the two initial sweeps +] g whole iterations, synchronise once, account for what ran.
         The second time a batch shape is seen it is captured (kernels + collectives) into one graph."""
+        if with_init and self.libc:
+            self._host_start()
+            self._last_need_rounds = False
+            return self._run_batch(False, g) if g > 0 else 0
         base = 2 if with_init else self.cur
         s0 = 2 if with_init else self.sweep_id
         key = (with_init, g, base)
@@ -478,7 +543,7 @@ class ShardedNem:
 
     def global_labels(self):
         with self.st.on_stream():
-            return self._block_view(self.labels[self.cur]).reshape(-1)[:self.n_total].cpu().numpy()
+            return self._block_view(self.labels[self.cur]).reshape(-1)[:self.n_total].cpu().numpy()   # (bit 7 masked)
 
     # ---- bench helpers
     def set_cvtest(self, name):

@@ -121,6 +121,10 @@ def load_library():
     lib.nemgpu_shard_finish_iteration.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp]
     lib.nemgpu_shard_round_sync.argtypes = [vp, C.c_float, C.c_int, vp, vp, vp, ip]
     lib.nemgpu_shard_end.argtypes = [vp, C.POINTER(Result), ip, ip]
+    lib.nemgpu_shard_set_labels.argtypes = [vp, vp, vp, vp]
+    lib.nemgpu_shard_round_draws.argtypes = [vp, ip, ip]
+    lib.nemgpu_shard_grow_draws.argtypes = [vp]
+    lib.nemgpu_shard_book_draws.argtypes = [vp, C.c_int]
     lib.nemgpu_shard_set_sweep_number.argtypes = [vp, C.c_int]
     lib.nemio_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.nemio_free.argtypes = [vp]
@@ -367,6 +371,20 @@ class NemEngine:
         self._chk(self.lib.nemgpu_shard_end(self._h, C.byref(r), C.byref(commits), C.byref(need)))
         return dict(status=r.status, iters=r.iters, converged=bool(r.converged), emptyk=r.emptyk,
                     sweep_rounds=r.sweep_rounds, commits=commits.value, need_rounds=need.value)
+
+    def shard_set_labels(self, ptrs):
+        self._chk(self.lib.nemgpu_shard_set_labels(self._h, C.c_void_p(ptrs[0]), C.c_void_p(ptrs[1]), C.c_void_p(ptrs[2])))
+
+    def shard_round_draws(self):
+        d, short = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.nemgpu_shard_round_draws(self._h, C.byref(d), C.byref(short)))
+        return d.value, short.value
+
+    def shard_grow_draws(self):
+        self._chk(self.lib.nemgpu_shard_grow_draws(self._h))
+
+    def shard_book_draws(self, n):
+        self._chk(self.lib.nemgpu_shard_book_draws(self._h, int(n)))
 
     def shard_set_sweep_number(self, n):
         self._chk(self.lib.nemgpu_shard_set_sweep_number(self._h, int(n)))
