@@ -198,6 +198,28 @@ int nemgpu_deal_groups(int count, int group, int n_devices, int* slot_of_problem
    With the same seed and tie-free data the result equals the reference's (which seeds with time(NULL)).
    best_start: 0-based index of the chosen start, -1 if every start ended with an empty class. */
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
+/* The same run with what the reference writes to <Fname>.log for INIT_RANDOM (nem_alg.c:1632-1636, 1662-1669: "Random
+   initialization %d :", the start's line 0, then NemAlgo's line per iteration): the starts run one after the other and
+   `fn` is called on the calling thread for every event, in the reference's order.  The pointers of an event are host
+   arrays that are valid during the call only. */
+typedef struct nemgpu_log_event {
+    int kind;                     /* NEMGPU_LOG_START | _LINE | _EMPTY */
+    int start;                    /* 0-based start */
+    int iter;                     /* _LINE: 0 = the start's initial partition, else the iteration; _EMPTY: the iteration */
+    int emptyk;                   /* _EMPTY: the class (1..K) */
+    const float* crit_before;     /* _LINE: D,G,U,M,L,Z of the partition the E-step sweep started from (WriteLogCrit, :2361) */
+    const float* crit_after;      /* _LINE: ... of the partition it left (:2398) */
+    const float* prop;            /* _LINE: K */
+    const float* center;          /* _LINE: K*D */
+    const float* disp;            /* _LINE: K*D */
+    const float* nbobs_k;         /* _LINE, iter > 0: K class sizes of this iteration's EstimPara; _EMPTY: EstimSizes'
+                                     sizes of the partition that emptied a class (the next start's line 0 prints them,
+                                     nothing resets NbObs_KD between starts); _LINE, iter 0: NULL */
+} nemgpu_log_event;
+enum { NEMGPU_LOG_START = 0, NEMGPU_LOG_LINE = 1, NEMGPU_LOG_EMPTY = 2 };
+typedef void (*nemgpu_log_fn)(const nemgpu_log_event* ev, void* user);
+int nemgpu_run_random_logged(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start,
+                             nemgpu_log_fn fn, void* user);
 /* Test hook: the first `count` values random() returns after srandom(seed), from the restated generator. */
 int nemgpu_glibc_random(uint32_t seed, int count, int32_t* out);
 
@@ -371,6 +393,13 @@ float nemgpu_chain_host(const double* x, long long n, float init, int mode);
    that for integer x below 2^24 (csrc/nem_ff.hpp) */
 float nemgpu_repeat_add_host(float x, long long times, int mode);
 int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out);
+/* InerToDispK_'s d-ordered float sum of a class's inertia values (nem_mod.c:1054-1058): under NCEM they are
+   non-negative multiples of 1/2 below 2^24, and the library evaluates the chain in pieces on one wavefront
+   (pangenomenem_amd/csrc/nem_halfsum.hpp).  Test hooks on arbitrary such values: nemgpu_halfsum_host -- mode 0: the
+   plain loop, mode 1: the host emulation of the device procedure (stepped: adds it took for real; no GPU needed);
+   nemgpu_halfsum_device -- the device procedure itself (n <= 8192). */
+float nemgpu_halfsum_host(const float* x, int n, int mode, int* stepped);
+int nemgpu_halfsum_device(const float* x, int n, int device, float* out);
 
 /* nemgpu_destroy parks an engine's stream, first 16 MB of device memory and pinned control block (up to 16 sets
    per process) for the next nemgpu_create on the same device -- a nem() call creates and destroys an engine, and

@@ -251,9 +251,12 @@ class Reference:
                     zero_density=("density = 0" in text))
 
     def classify_random(self, x, nei, k, n_starts=50, rng_seed=1, algo="ncem", beta=0.5, disper="sk_", propor="pk",
-                        cvtest="clas", cvthres=1e-8, it_max=100):
-        """ClassifyByNem with InitMode = INIT_RANDOM after srandom(rng_seed) (the reference seeds with time())."""
+                        cvtest="clas", cvthres=1e-8, it_max=100, log_path=None):
+        """ClassifyByNem with InitMode = INIT_RANDOM after srandom(rng_seed) (the reference seeds with time()).
+        log_path: the reference writes its own per-iteration log there (DoLog, StartLogFile nem_alg.c:1478-1498)."""
         n, d = x.shape
+        self.lib.ref_set_log.restype = None
+        self.lib.ref_set_log(C.c_char_p(log_path.encode()) if log_path else None)
         xf = np.ascontiguousarray(x, np.float32)
         ptr, idx, w = _csr(n, nei)
         prop = np.zeros(k, np.float32)
@@ -270,6 +273,7 @@ class Reference:
                                        _p(prop, C.c_float), _p(center, C.c_float), _p(disp, C.c_float),
                                        _p(c, C.c_float), _p(nk, C.c_float), _p(crit, C.c_float), log, len(log),
                                        C.byref(secs))
+        self.lib.ref_set_log(None)
         text = log.value.decode("latin1")
         m = re.search(r"Best start was (\d+)", text)
         return dict(status=sts, c=c, prop=prop, center=center, disp=disp, nbobs_k=nk, crit=crit,

@@ -69,6 +69,15 @@ int ref_classify_ex(int n, int d, int k,
                     float* classif_nk, float* nbobs_k, float* crit6,
                     char* log_text, int log_cap, double* secs);
 
+/* The reference's own per-iteration log (<Fname>.log, StartLogFile nem_alg.c:1478-1498): the next ref_classify*
+   call writes it to `path` (DoLog = TRUE, LogName = path, as nem_exe.c:446-447 does); NULL or "" switches it off. */
+static char g_log_name[LEN_FILENAME + 1] = "";
+void ref_set_log(const char* path)
+{
+    g_log_name[0] = '\0';
+    if (path) strncat(g_log_name, path, LEN_FILENAME);
+}
+
 int ref_classify(int n, int d, int k,
                  const float* x_nd,
                  const int* nei_ptr, const int* nei_idx, const float* nei_w,
@@ -174,7 +183,7 @@ int ref_classify_ex(int n, int d, int k,
     para.Crit = DEFAULT_CRIT;
     para.CvThres = cvthres;
     para.CvTest = (CvemET)cvtest;
-    para.DoLog = FALSE;
+    para.DoLog = g_log_name[0] ? TRUE : FALSE;
     para.NbIters = nbiters;
     para.NbEIters = DEFAULT_NBEITERS;
     para.NbRandomInits = nb_random_inits;
@@ -189,7 +198,7 @@ int ref_classify_ex(int n, int d, int k,
     para.SiteUpdate = DEFAULT_UPDATE;
     para.TieRule = DEFAULT_TIE;
     para.Debug = FALSE;
-    strcpy(para.LogName, "");
+    strcpy(para.LogName, g_log_name);
 
     /* CriterT -- MakeErrinfo("") => Kr = 0 (nem_exe.c:1157-1161) */
     crit.Errinfo.Kc = k;

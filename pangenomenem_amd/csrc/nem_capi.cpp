@@ -245,6 +245,62 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
     return nemgpu_criteria(e, res->crit);
 }
 
+// The INIT_RANDOM run with the reference's log (RandNemAlgo, nem_alg.c:1632-1636, 1662-1669, 1730-1732): per start
+// "Random initialization %d :", line 0 (the start's own parameters; NbObs_KD is whatever the run so far left there --
+// NaN from InitPara, :1270-1276, before the first start, then the sizes of the last EstimPara, which nothing resets),
+// WriteLogHeader and NemAlgo's line per iteration; "Best start was %d (U = %g)" at the end.
+struct RandomLog {
+    FILE* fl; float mult; float beta; int k, d;
+    std::vector<float> nk_left;                                              // NbObs_K as the run so far left it
+    std::string buf;
+    void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), fl); buf.clear(); } }
+};
+
+void random_log_event(const nemgpu_log_event* ev, void* user)
+{
+    RandomLog& L = *static_cast<RandomLog*>(user);
+    char t[96];
+    if (ev->kind == NEMGPU_LOG_START) {
+        L.flush();
+        fprintf(L.fl, "\nRandom initialization %d :\n", ev->start + 1);
+        fprintf(L.fl, "%4d ", 0);
+        return;
+    }
+    if (ev->kind == NEMGPU_LOG_EMPTY) {
+        snprintf(t, sizeof t, "%4d  Class %d empty at iteration %d\n", ev->iter, ev->emptyk, ev->iter);     // :1798, :1835-1837
+        L.buf += t;
+        L.nk_left.assign(ev->nbobs_k, ev->nbobs_k + L.k);
+        return;
+    }
+    const size_t kd = (size_t)L.k * L.d;
+    LogParams P{std::vector<float>(ev->prop, ev->prop + L.k), std::vector<float>(ev->center, ev->center + kd),
+                std::vector<float>(ev->disp, ev->disp + kd), L.nk_left};
+    if (ev->iter > 0) {
+        P.nk.assign(ev->nbobs_k, ev->nbobs_k + L.k);
+        L.nk_left = P.nk;
+        snprintf(t, sizeof t, "%4d ", ev->iter);
+        L.buf += t;
+    }
+    log_crit(L.buf, ev->crit_before, L.mult); log_crit(L.buf, ev->crit_after, L.mult);
+    log_classes(L.buf, P, L.beta, L.k, L.d, true);
+    if (ev->iter == 0) {                                                     // Needinit, :1985-1986; NemAlgo's header, :1783
+        L.buf += "\n";
+        L.flush();
+        log_header(L.fl, L.k, L.d);
+    } else if (L.buf.size() > (1u << 20)) L.flush();
+}
+
+int run_random_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res, int* best)
+{
+    RandomLog L{fl, log_mult(n), cfg.beta, k, d, std::vector<float>((size_t)k, std::nanf("")), std::string()};
+    fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
+    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)L.mult);
+    const int rc = nemgpu_run_random_logged(e, 50, cfg.tie_seed, res, best, random_log_event, &L);
+    L.flush();
+    if (rc == NEMGPU_OK && *best >= 0) fprintf(fl, "Best start was %d (U = %g)\n", *best + 1, (double)res->crit[3]);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" int nem(const char* Fname, const int nk, const char* algo, const float beta, const char* convergence,
@@ -416,7 +472,12 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
             // RandNemAlgo with the reference's 50 starts (DEFAULT_NBRANDINITS, nem_typ.h:94); the draws come from the
             // reference's generator seeded like its NemPara.Seed (time(NULL), or NEM_MI355X_SEED)
             int best = -1;
-            rc = nemgpu_run_random(e, 50, cfg.tie_seed, &res, &best);
+            // dolog: the reference's log of every start (the starts then run one after the other, one logged step per
+            // host round trip); NEM_MI355X_LOG=0 keeps the lock-step run and writes a header-only log
+            const char* lenv = getenv("NEM_MI355X_LOG");
+            FILE* fl = (dolog && !(lenv && lenv[0] == '0')) ? fopen((base + ".log").c_str(), "w") : nullptr;
+            if (fl) { rc = run_random_logged(e, cfg, in.n, in.d, nk, fl, &res, &best); fclose(fl); full_log = true; }
+            else rc = nemgpu_run_random(e, 50, cfg.tie_seed, &res, &best);
             if (rc == NEMGPU_OK && best >= 0)
                 lg.pr("Best start was %d (%s = %g)\n", best + 1, "M", (double)res.crit[3]);                  // nem_alg.c:1722-1725
         } else {

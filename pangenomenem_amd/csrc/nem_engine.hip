@@ -28,6 +28,7 @@
 #include "nem_internal.hpp"
 #include "nem_ff.hpp"
 #include "nem_chain.hpp"
+#include "nem_halfsum.hpp"
 #include "nem_rng.hpp"
 #include "nem_kernels.hpp"
 
@@ -2193,8 +2194,9 @@ int nemgpu_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
 // stream submission and one wait: the two criteria passes and the copies are enqueued behind the iteration before
 // anyone knows how it ended.  An iteration the host has to finish (more relaxation rounds) or a criterion-driven
 // convergence test takes the plain sequence of calls instead.
-int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, float crit_before[6], float crit_after[6],
-                          float* prop, float* center, float* disp, float* nbobs_k)
+// keep_draws: a start of RandNemAlgo -- the tie stream goes on where the start before left it (one srandom per nem() call)
+static int iterate_logged_impl(nemgpu_engine* e, int with_init, bool keep_draws, nemgpu_result* res, float crit_before[6],
+                               float crit_after[6], float* prop, float* center, float* disp, float* nbobs_k)
 {
     if (!e || !crit_before || !crit_after) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
@@ -2212,7 +2214,9 @@ int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, f
     char* st = nullptr; size_t got = 0;
     if (with_init && (crit_test(e) || e->libc() || !(e->lo == 0 && e->hi == e->n_total))) {
         // (the start whose two sweeps the host completes one after the other: the plain sequence of calls)
+        const int draws = e->draws;
         if ((r = reset_state(e))) return r;
+        if (keep_draws) e->draws = draws;
         if ((r = init_partition(e))) return r;
         e->crit_ref = 0.0f;
         if (e->cfg.cvtest == NEMGPU_CV_CRIT_LOGGED) {              // (what the first iteration's criterion is compared with)
@@ -2222,7 +2226,7 @@ int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, f
         }
     } else if (!crit_test(e) && e->lo == 0 && e->hi == e->n_total) {
         LoopCursor lc;
-        if (with_init) e->draws = 0;
+        if (with_init && !keep_draws) e->draws = 0;
         if ((r = loop_begin(e, lc, with_init ? 0 : 1, with_init != 0))) return r;
         if (loop_wants_batch(e, lc)) {
             if ((r = batch_plan(e, lc))) return r;
@@ -2265,6 +2269,12 @@ int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, f
     fill_result(e, res);
     if (res) res->loop_seconds = secs;
     return NEMGPU_OK;
+}
+
+int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, float crit_before[6], float crit_after[6],
+                          float* prop, float* center, float* disp, float* nbobs_k)
+{
+    return iterate_logged_impl(e, with_init, false, res, crit_before, crit_after, prop, center, disp, nbobs_k);
 }
 
 int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
@@ -2523,7 +2533,24 @@ int nemgpu_solve_many_devices(nemgpu_problem* P, int count, const nemgpu_config*
     return rc;
 }
 
+static int run_random_impl(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start,
+                           nemgpu_log_fn fn, void* user);
+
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
+{
+    return run_random_impl(e, n_starts, seed, res, best_start, nullptr, nullptr);
+}
+
+int nemgpu_run_random_logged(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start,
+                             nemgpu_log_fn fn, void* user)
+{
+    if (!fn) return NEMGPU_E_FUNCARG;
+    return run_random_impl(e, n_starts, seed, res, best_start, fn, user);
+}
+
+// fn != nullptr: the starts one after the other, one logged step per host round trip (nemgpu_iterate_logged's form)
+static int run_random_impl(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start,
+                           nemgpu_log_fn fn, void* user)
 {
     if (!e || n_starts <= 0) return NEMGPU_E_FUNCARG;
     if (e->lo != 0 || e->hi != e->n_total) { set_error("random starts need the whole problem on one engine"); return NEMGPU_E_FUNCARG; }
@@ -2534,7 +2561,7 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
         // the starts are independent EM runs on ONE matrix: by default they run in lock step, every launch serving all
         // of them (NEM_MI355X_BATCH_STARTS=0: one after the other on this engine)
         const char* g = getenv("NEM_MI355X_BATCH_STARTS");
-        if (n_starts > 1 && !(g && g[0] == '0') && !crit_test(e)) return run_random_lockstep(e, n_starts, seed, res, best_start);
+        if (!fn && n_starts > 1 && !(g && g[0] == '0') && !crit_test(e)) return run_random_lockstep(e, n_starts, seed, res, best_start);
     }
     int r;
     const int n = e->n, d = e->d, k = e->k, wf = e->wf;
@@ -2599,12 +2626,49 @@ int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_resu
         HIPCHK(copy_sync(e, e->center0, center.data(), sizeof(float) * kd, hipMemcpyHostToDevice));
         HIPCHK(copy_sync(e, e->disp0, disp.data(), sizeof(float) * kd, hipMemcpyHostToDevice));
         // ComputePartitionFromPara + NemAlgo + criteria, as nemgpu_run does
-        if ((r = iterate(e, e->cfg.it_max, true))) { cleanup(); return r; }
+        float crit[6];
+        bool have_crit = false;
+        if (!fn) {
+            if ((r = iterate(e, e->cfg.it_max, true))) { cleanup(); return r; }
+        } else {
+            nemgpu_log_event ev{};
+            ev.kind = NEMGPU_LOG_START; ev.start = s;
+            fn(&ev, user);
+            float cb[6], ca[6];
+            std::vector<float> nb((size_t)k);
+            nemgpu_result r1{};
+            if ((r = iterate_logged_impl(e, 1, true, &r1, cb, ca, prop.data(), center.data(), disp.data(), nullptr))) { cleanup(); return r; }
+            ev.kind = NEMGPU_LOG_LINE; ev.iter = 0; ev.crit_before = cb; ev.crit_after = ca;
+            ev.prop = prop.data(); ev.center = center.data(); ev.disp = disp.data(); ev.nbobs_k = nullptr;
+            fn(&ev, user);
+            for (int iter = 1; iter <= e->cfg.it_max && !e->converged && e->status == NEMGPU_OK; iter++) {
+                if ((r = iterate_logged_impl(e, 0, true, &r1, cb, ca, prop.data(), center.data(), disp.data(), nb.data()))) { cleanup(); return r; }
+                ev.iter = iter; ev.nbobs_k = nb.data();
+                if (e->status == NEMGPU_W_EMPTYCLASS) {
+                    // EstimSizes (nem_mod.c:1275-1317) ran before the empty class was found: i-ordered float sums per class
+                    std::vector<float> part((size_t)n * k);
+                    if ((r = nemgpu_get_partition(e, part.data()))) { cleanup(); return r; }
+                    for (int h = 0; h < k; h++) {
+                        float acc = 0.0f;
+                        for (int i = 0; i < n; i++) acc += part[(size_t)i * k + h];
+                        nb[(size_t)h] = acc;
+                    }
+                    ev.kind = NEMGPU_LOG_EMPTY; ev.emptyk = e->emptyk;
+                    fn(&ev, user);
+                    break;
+                }
+                ev.kind = NEMGPU_LOG_LINE;
+                fn(&ev, user);
+                memcpy(crit, ca, sizeof crit);                     // (of the final partition, on the final densities, if the run ends here)
+                have_crit = true;
+            }
+            if (e->status == NEMGPU_W_EMPTYCLASS) have_crit = false;
+        }
         if (e->iters == 0) {
             if ((r = do_mstep(e)) || (r = do_tables(e)) || (r = do_density(e))) { cleanup(); return r; }
+            have_crit = false;
         }
-        float crit[6];
-        if ((r = criteria(e, crit))) { cleanup(); return r; }
+        if (!have_crit && (r = criteria(e, crit))) { cleanup(); return r; }
         last_status = e->status;
         if (e->status == NEMGPU_OK) {
             nbsucc++;
@@ -3872,6 +3936,35 @@ extern "C" int nemgpu_chain_device(const double* x, long long n, float init, int
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (n > 0) HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
     nemk::launch_chain_debug(dx, n, init, dout, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipStreamDestroy(st); (void)hipFree(dx); (void)hipFree(dout);
+    return NEMGPU_OK;
+}
+
+// ---- test hooks for the piecewise d-ordered chain of non-negative multiples of 1/2 (nem_halfsum.hpp) ----
+// mode 0: the plain sequential loop; 1: the host emulation of the device procedure (stepped: how many of the n adds it
+// took for real).  No GPU needed.
+extern "C" float nemgpu_halfsum_host(const float* x, int n, int mode, int* stepped)
+{
+    if (stepped) *stepped = mode == 0 ? n : 0;
+    if (x == nullptr || n <= 0) return 0.0f;
+    return mode == 0 ? nemk::halfsum_plain(x, n) : nemk::halfsum_host(x, n, stepped);
+}
+
+// the device procedure (n <= 8192) on device `device`
+extern "C" int nemgpu_halfsum_device(const float* x, int n, int device, float* out)
+{
+    if (x == nullptr || out == nullptr || n < 0 || n > 8192) { set_error("nemgpu_halfsum_device: bad argument"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(device));
+    float* dx = nullptr; float* dout = nullptr;
+    HIPCHK(hipMalloc(&dx, (size_t)std::max(n, 1) * sizeof(float)));
+    HIPCHK(hipMalloc(&dout, sizeof(float)));
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    nemk::launch_halfsum_debug(dx, n, dout, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout, sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

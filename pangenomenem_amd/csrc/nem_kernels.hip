@@ -19,6 +19,7 @@
 
 #include "nem_ff.hpp"
 #include "nem_chain.hpp"
+#include "nem_halfsum.hpp"
 #include "nem_kernels.hpp"
 
 namespace nemk {
@@ -1759,11 +1760,16 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
                     if (blockIdx.x == 0) g_phase[12] = wall_clock64();
 #endif
                 }
-                if (tid == 0) {
+                if (a.mode == 1) {
+                    // NCEM: non-negative multiples of 1/2 -- the chain in pieces, one wavefront (nem_halfsum.hpp: exact
+                    // prefix sums tell which float binade a step runs in, a run of steps inside one binade is a
+                    // two-parity integer map, the few steps around a power of two are taken for real)
+                    if (tid < 64) { const float si = halfsum_wave(s_in, D); if (tid == 0) s_si = si; }
+                } else if (tid == 0) {
                     float si = 0.0f;
                     // groups of 32 values, two register sets: one is loaded from LDS while the other is added
                     // (measured and dropped, round 3: the chain as a block-wide scan of parity maps, binade by binade
-                    //  -- nem_halfchain.hpp, exact, tested -- 42 us against 33.5: seven passes of ~5 us each)
+                    //  -- exact, tested -- 42 us against 33.5: seven block-wide passes of ~5 us each)
                     const int ng = (D + 31) >> 5, last = CAP / 32 - 1;
                     float4 A[8], B[8];
 #pragma unroll
@@ -3127,6 +3133,23 @@ __global__ __launch_bounds__(CH_T) void k_chain_debug(const double* __restrict__
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_chain_debug, dim3(1), dim3(CH_T), 0, s, x, n, init, out);
+}
+
+// test hook: the piecewise d-ordered chain of nem_halfsum.hpp on `n` values staged in LDS (as k_finish has them)
+constexpr int kHalfsumDebugCap = 8192;
+__global__ void __launch_bounds__(64) k_halfsum_debug(const float* __restrict__ x, int n, float* __restrict__ out)
+{
+    __shared__ float s_x[kHalfsumDebugCap];
+    for (int i = threadIdx.x; i < n; i += 64) s_x[i] = x[i];
+    __syncthreads();
+    const float r = halfsum_wave(s_x, n);
+    if (threadIdx.x == 0) *out = r;
+}
+bool launch_halfsum_debug(const float* x, int n, float* out, hipStream_t s)
+{
+    if (n < 0 || n > kHalfsumDebugCap) return false;
+    hipLaunchKernelGGL(k_halfsum_debug, dim3(1), dim3(64), 0, s, x, n, out);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from tests.golden_util import case_names, load_case
-from tests.util import maxdiff
+from tests.util import assert_printed_g_close, maxdiff
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -89,7 +89,7 @@ def test_dropin_nem_writes_reference_files(gpu_lib, tmp_path, name):
             ta, tb = a.split(), b.split()
             assert len(ta) == len(tb) == 5 and ta[4] == tb[4] == b"nan"
             for u, v in zip(ta[:4], tb[:4]):
-                assert abs(float(u) - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (a, b)
+                assert_printed_g_close(u.decode(), v.decode(), (a, b))
         else:
             assert a == b, (i, a, b)
     # the reference-side parser (run_partitioning's contract) accepts our files
@@ -191,3 +191,49 @@ def test_dropin_crit_convergence_equals_the_reference(gpu_lib, tmp_path, algo, d
     assert open(base + ".uf", "rb").read() == open(ref_base + ".uf", "rb").read()
     ours_mf, ref_mf = open(base + ".mf", "rb").read().split(b"\n"), open(ref_base + ".mf", "rb").read().split(b"\n")
     assert ours_mf[-4:] == ref_mf[-4:]
+
+
+RANDOM_LOGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_logs")
+
+
+def _random_log_cases():
+    return sorted(x for x in os.listdir(RANDOM_LOGS) if os.path.isdir(os.path.join(RANDOM_LOGS, x))) if os.path.isdir(RANDOM_LOGS) else []
+
+
+@pytest.mark.parametrize("case", _random_log_cases())
+def test_dropin_random_start_log_equals_the_reference_fixture(gpu_lib, tmp_path, monkeypatch, case):
+    """<Fname>.log of an INIT_RANDOM run (init_mode=1, dolog=1): RandNemAlgo's "Random initialization %d :" blocks --
+    line 0 with the start's drawn centres and whatever NbObs_KD the run so far left (NaN, then the last EstimPara's
+    sizes, an emptied class's included), the header, a line per iteration, "Class %d empty ...", "Best start was" --
+    against the text the unmodified reference wrote for the same inputs and srandom() seed
+    (tests/golden/make_random_logs.py; nem_alg.c:1632-1636, 1662-1669, 1730-1732)."""
+    import gzip
+    import json
+    from pangenomenem_amd import nemfiles, synth
+    import nem as nem_module
+    from tests.util import assert_same_nem_log
+    here = os.path.join(RANDOM_LOGS, case)
+    meta = json.load(open(os.path.join(here, "meta.json")))
+    z = np.load(os.path.join(here, "inputs.npz"))
+    n, d, k = int(z["n"]), int(z["d"]), int(z["k"])
+    x = np.unpackbits(z["xbits"], axis=1, bitorder="little")[:, :d]
+    nei = (z["nei_ptr"], z["nei_idx"], z["nei_w"])
+    prop, center, disp = synth.default_init(d)
+    base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
+    os.remove(base + ".m")                                     # not read in this mode (nem_exe.c:513-522)
+    monkeypatch.setenv("NEM_MI355X_SEED", str(meta["seed"]))
+    rc = nem_module.nem(base.encode(), k, meta["algo"].encode(), meta["beta"], b"clas", 1e-8, b"fuzzy", 100, True, b"bern",
+                        b"pk", meta["disper"].encode(), 1)
+    assert rc == 0
+    want = gzip.open(os.path.join(here, "ref_log.txt.gz"), "rt").read()
+    got = open(base + ".log").read()
+    assert got.count("Random initialization") == 50 and got.count(" empty at iteration ") == meta["starts_with_empty_class"]
+    assert_same_nem_log(got, want)
+    assert "Best start was %d " % (meta["best_start"] + 1) in open(base + ".stderr").read()
+    # NEM_MI355X_LOG=0: the lock-step run and a header-only log; the same partition
+    uf = open(base + ".uf").read()
+    monkeypatch.setenv("NEM_MI355X_LOG", "0")
+    assert nem_module.nem(base.encode(), k, meta["algo"].encode(), meta["beta"], b"clas", 1e-8, b"fuzzy", 100, True, b"bern",
+                          b"pk", meta["disper"].encode(), 1) == 0
+    assert open(base + ".uf").read() == uf
+    assert "Random initialization" not in open(base + ".log").read()
