@@ -394,12 +394,15 @@ float nemgpu_chain_host(const double* x, long long n, float init, int mode);
 float nemgpu_repeat_add_host(float x, long long times, int mode);
 int nemgpu_chain_device(const double* x, long long n, float init, int device, float* out);
 /* InerToDispK_'s d-ordered float sum of a class's inertia values (nem_mod.c:1054-1058): under NCEM they are
-   non-negative multiples of 1/2 below 2^24, and the library evaluates the chain in pieces on one wavefront
-   (pangenomenem_amd/csrc/nem_halfsum.hpp).  Test hooks on arbitrary such values: nemgpu_halfsum_host -- mode 0: the
-   plain loop, mode 1: the host emulation of the device procedure (stepped: adds it took for real; no GPU needed);
-   nemgpu_halfsum_device -- the device procedure itself (n <= 8192). */
+   non-negative multiples of 1/2 below 2^24, and the library evaluates the chain in pieces, all threads of a block at
+   once (pangenomenem_amd/csrc/nem_halfsum.hpp).  Test hooks on arbitrary such values: nemgpu_halfsum_host -- mode 0:
+   the plain loop, mode w = 1..16: the host emulation of the device procedure with w wavefronts (stepped: adds it took
+   for real; no GPU needed); nemgpu_halfsum_device -- the device procedure itself (n <= 8192, waves 1 or 16);
+   nemgpu_halfsum_profile -- its in-kernel timing: us[0..3] = prefix sums, classification + walk, scan + hand-over,
+   ordered pass; us[4] = the same chain as plain dependent adds on one lane. */
 float nemgpu_halfsum_host(const float* x, int n, int mode, int* stepped);
-int nemgpu_halfsum_device(const float* x, int n, int device, float* out);
+int nemgpu_halfsum_device(const float* x, int n, int waves, int device, float* out);
+int nemgpu_halfsum_profile(const float* x, int n, int waves, int device, double us[5]);
 
 /* nemgpu_destroy parks an engine's stream, first 16 MB of device memory and pinned control block (up to 16 sets
    per process) for the next nemgpu_create on the same device -- a nem() call creates and destroys an engine, and

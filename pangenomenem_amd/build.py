@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("nem_kernels.hip", "nem_engine.hip", "nem_io.cpp", "nem_capi.cpp")]
-HDR = [os.path.join(HERE, "csrc", f) for f in ("nem_kernels.hpp", "nem_internal.hpp", "nem_ff.hpp", "nem_rng.hpp", "nem_chain.hpp")] + \
+HDR = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".hpp")) + \
       [os.path.join(HERE, "..", "include", "nem_mi355x.h")]
 LIB = os.path.join(HERE, "lib", "libnem_mi355x.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17", "-ldl",

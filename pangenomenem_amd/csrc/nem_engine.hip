@@ -3944,30 +3944,53 @@ extern "C" int nemgpu_chain_device(const double* x, long long n, float init, int
 }
 
 // ---- test hooks for the piecewise d-ordered chain of non-negative multiples of 1/2 (nem_halfsum.hpp) ----
-// mode 0: the plain sequential loop; 1: the host emulation of the device procedure (stepped: how many of the n adds it
-// took for real).  No GPU needed.
+// mode 0: the plain sequential loop; mode w = 1 .. 16: the host emulation of the device procedure with w wavefronts
+// (stepped: how many of the n adds it took for real).  No GPU needed.
 extern "C" float nemgpu_halfsum_host(const float* x, int n, int mode, int* stepped)
 {
     if (stepped) *stepped = mode == 0 ? n : 0;
-    if (x == nullptr || n <= 0) return 0.0f;
-    return mode == 0 ? nemk::halfsum_plain(x, n) : nemk::halfsum_host(x, n, stepped);
+    if (x == nullptr || n <= 0 || mode < 0 || mode > nemk::kHsMaxWaves) return 0.0f;
+    return mode == 0 ? nemk::halfsum_plain(x, n) : nemk::halfsum_host(x, n, mode, stepped);
 }
 
-// the device procedure (n <= 8192) on device `device`
-extern "C" int nemgpu_halfsum_device(const float* x, int n, int device, float* out)
+// the device procedure (n <= 8192; waves = 16: the block of k_finish, 1: one wavefront) on device `device`
+extern "C" int nemgpu_halfsum_device(const float* x, int n, int waves, int device, float* out)
 {
-    if (x == nullptr || out == nullptr || n < 0 || n > 8192) { set_error("nemgpu_halfsum_device: bad argument"); return NEMGPU_E_FUNCARG; }
+    if (x == nullptr || out == nullptr || n < 0 || n > 8192 || (waves != 1 && waves != 16)) { set_error("nemgpu_halfsum_device: bad argument"); return NEMGPU_E_FUNCARG; }
     HIPCHK(hipSetDevice(device));
     float* dx = nullptr; float* dout = nullptr;
     HIPCHK(hipMalloc(&dx, (size_t)std::max(n, 1) * sizeof(float)));
-    HIPCHK(hipMalloc(&dout, sizeof(float)));
+    HIPCHK(hipMalloc(&dout, 2 * sizeof(float)));
     hipStream_t st;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (n > 0) HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
-    nemk::launch_halfsum_debug(dx, n, dout, st);
+    nemk::launch_halfsum_debug(dx, n, waves, dout, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout, sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     (void)hipStreamDestroy(st); (void)hipFree(dx); (void)hipFree(dout);
+    return NEMGPU_OK;
+}
+
+// where the device procedure spends its time (in-kernel clock, 100 MHz): us[0..3] = prefix sums, classification + walk,
+// scan + hand-over, ordered pass; us[4] = the same chain as plain dependent adds on one lane
+extern "C" int nemgpu_halfsum_profile(const float* x, int n, int waves, int device, double us[5])
+{
+    if (x == nullptr || us == nullptr || n < 0 || n > 8192 || (waves != 1 && waves != 16)) { set_error("nemgpu_halfsum_profile: bad argument"); return NEMGPU_E_FUNCARG; }
+    HIPCHK(hipSetDevice(device));
+    float* dx = nullptr; float* dout = nullptr; long long* dst = nullptr;
+    HIPCHK(hipMalloc(&dx, (size_t)std::max(n, 1) * sizeof(float)));
+    HIPCHK(hipMalloc(&dout, 2 * sizeof(float)));
+    HIPCHK(hipMalloc(&dst, 6 * sizeof(long long)));
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (n > 0) HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    long long h[6];
+    for (int rep = 0; rep < 3; rep++) nemk::launch_halfsum_debug(dx, n, waves, dout, st, dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h, dst, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 5; i++) us[i] = (double)(h[i + 1] - h[i]) * 0.01;
+    (void)hipStreamDestroy(st); (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dst);
     return NEMGPU_OK;
 }

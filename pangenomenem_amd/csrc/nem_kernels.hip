@@ -1641,6 +1641,7 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
 {
     constexpr int CAP = 1024 * NI;
     __shared__ float4 s_in4[CAP / 4];
+    __shared__ HsShared s_hs;
     __shared__ float s_si, s_sn, s_eps0;
     __shared__ double s_l1, s_l0;
     __shared__ unsigned long long s_tot2;
@@ -1761,10 +1762,11 @@ __device__ __forceinline__ void finish_lean(const FinishArgs& a)
 #endif
                 }
                 if (a.mode == 1) {
-                    // NCEM: non-negative multiples of 1/2 -- the chain in pieces, one wavefront (nem_halfsum.hpp: exact
+                    // NCEM: non-negative multiples of 1/2 -- the chain in pieces, the whole block (nem_halfsum.hpp: exact
                     // prefix sums tell which float binade a step runs in, a run of steps inside one binade is a
                     // two-parity integer map, the few steps around a power of two are taken for real)
-                    if (tid < 64) { const float si = halfsum_wave(s_in, D); if (tid == 0) s_si = si; }
+                    const float si = halfsum_block<16>(s_in, D, s_hs);
+                    if (tid == 0) s_si = si;
                 } else if (tid == 0) {
                     float si = 0.0f;
                     // groups of 32 values, two register sets: one is loaded from LDS while the other is added
@@ -3137,18 +3139,32 @@ void launch_chain_debug(const double* x, long long n, float init, float* out, hi
 
 // test hook: the piecewise d-ordered chain of nem_halfsum.hpp on `n` values staged in LDS (as k_finish has them)
 constexpr int kHalfsumDebugCap = 8192;
-__global__ void __launch_bounds__(64) k_halfsum_debug(const float* __restrict__ x, int n, float* __restrict__ out)
+template <int W>
+__global__ void __launch_bounds__(64 * W) k_halfsum_debug(const float* __restrict__ x, int n, float* __restrict__ out,
+                                                          long long* __restrict__ stamps)
 {
     __shared__ float s_x[kHalfsumDebugCap];
-    for (int i = threadIdx.x; i < n; i += 64) s_x[i] = x[i];
+    __shared__ HsShared s_hs;
+    for (int i = threadIdx.x; i < n; i += 64 * W) s_x[i] = x[i];
     __syncthreads();
-    const float r = halfsum_wave(s_x, n);
-    if (threadIdx.x == 0) *out = r;
+    const float r = halfsum_block<W>(s_x, n, s_hs, stamps != nullptr);
+    if (threadIdx.x == 0) {
+        *out = r;
+        if (stamps) {                                                // + the plain chain on one lane, for comparison
+            float s = 0.0f;
+            for (int i = 0; i < n; i++) s += s_x[i];
+            s_hs.stamps[5] = wall_clock64();
+            out[1] = s;
+            for (int i = 0; i < 6; i++) stamps[i] = s_hs.stamps[i];
+        }
+    }
 }
-bool launch_halfsum_debug(const float* x, int n, float* out, hipStream_t s)
+bool launch_halfsum_debug(const float* x, int n, int waves, float* out, hipStream_t s, long long* stamps)
 {
     if (n < 0 || n > kHalfsumDebugCap) return false;
-    hipLaunchKernelGGL(k_halfsum_debug, dim3(1), dim3(64), 0, s, x, n, out);
+    if (waves == 16) hipLaunchKernelGGL(k_halfsum_debug<16>, dim3(1), dim3(1024), 0, s, x, n, out, stamps);
+    else if (waves == 1) hipLaunchKernelGGL(k_halfsum_debug<1>, dim3(1), dim3(64), 0, s, x, n, out, stamps);
+    else return false;
     return true;
 }
 

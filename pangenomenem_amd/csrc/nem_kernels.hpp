@@ -179,7 +179,7 @@ void launch_mstep_fuzzy(int n, int npad, int K, int D, const uint32_t* xw, const
 void launch_conv_fuzzy(size_t m, const float* c, const float* cold, float thres, int* flags, const int* stop,
                        const CtrlArgs* ctrl, hipStream_t s);
 void launch_chain_debug(const double* x, long long n, float init, float* out, hipStream_t s);
-bool launch_halfsum_debug(const float* x, int n, float* out, hipStream_t s);   // n <= 8192
+bool launch_halfsum_debug(const float* x, int n, int waves, float* out, hipStream_t s, long long* stamps = nullptr);   // n <= 8192, waves 1 | 16; out[2], stamps[6] when timing
 void launch_calib_read(const uint32_t* buf, size_t words, uint32_t* sink, hipStream_t s);
 void launch_onehot(int n, int K, const uint8_t* lab, float* c, hipStream_t s);
 constexpr int kCritReduceThreads = 1024;   // block size of k_crit_reduce (CH_T in nem_kernels.hip)

@@ -18,7 +18,7 @@ def lib():
     lib.nemgpu_halfsum_host.restype = C.c_float
     lib.nemgpu_halfsum_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     lib.nemgpu_halfsum_device.restype = C.c_int
-    lib.nemgpu_halfsum_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.nemgpu_halfsum_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     return lib
 
 
@@ -80,29 +80,30 @@ def cases():
 CASES = cases()
 
 
+@pytest.mark.parametrize("waves", [16, 1, 5])
 @pytest.mark.parametrize("name,x", CASES, ids=[c[0] for c in CASES])
-def test_piecewise_chain_equals_the_plain_loop(lib, name, x):
+def test_piecewise_chain_equals_the_plain_loop(lib, name, x, waves):
     assert np.all(x >= 0) and np.all(x * 2 == np.floor(x * 2)) and np.all(x < 2.0 ** 24)
     stepped = C.c_int(0)
     want = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 0, None)
-    got = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 1, C.byref(stepped))
+    got = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), waves, C.byref(stepped))
     assert np.float32(want).view(np.uint32) == np.float32(got).view(np.uint32), (name, want, got)
-    if len(x) <= 6000:                                   # (the C loop itself against numpy's float32 arithmetic)
+    if len(x) <= 6000 and waves == 16:                   # (the C loop itself against numpy's float32 arithmetic)
         assert np.float32(want) == numpy_chain(x)
     assert 0 <= stepped.value <= len(x)
 
 
 def test_counts_like_chains_are_mostly_maps(lib):
-    """the case the kernel meets (200 000 x 5 000: class counts, totals near 2^29): a few dozen of the 5 000 adds are
-    taken for real, the rest are integer maps"""
+    """the case the kernel meets (200 000 x 5 000: class counts, totals near 2^29): only the ranges that hold a power of
+    two the sum passes -- a thread's five elements each -- are added for real, the rest are integer maps"""
     rng = np.random.Generator(np.random.PCG64(5))
     nk = 70000
     s1 = rng.integers(0, nk + 1, size=5000)
     x = np.ascontiguousarray(np.minimum(s1, nk - s1), np.float32)
     stepped = C.c_int(0)
-    got = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 1, C.byref(stepped))
+    got = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 16, C.byref(stepped))
     assert got == lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 0, None)
-    assert stepped.value < 100, stepped.value
+    assert stepped.value <= 8 * 5, stepped.value
 
 
 def test_random_chains_fuzz(lib):
@@ -117,15 +118,16 @@ def test_random_chains_fuzz(lib):
             x = np.floor(x)                              # integers only
         x = np.ascontiguousarray(x, np.float32)
         want = lib.nemgpu_halfsum_host(x.ctypes.data, n, 0, None)
-        got = lib.nemgpu_halfsum_host(x.ctypes.data, n, 1, None)
+        got = lib.nemgpu_halfsum_host(x.ctypes.data, n, (16, 1, 3, 8)[t % 4], None)
         assert np.float32(want).view(np.uint32) == np.float32(got).view(np.uint32), (t, n, scale, want, got)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("waves", [16, 1])
 @pytest.mark.parametrize("name,x", CASES, ids=[c[0] for c in CASES])
-def test_device_procedure_equals_the_plain_loop(gpu_lib, lib, name, x):
+def test_device_procedure_equals_the_plain_loop(gpu_lib, lib, name, x, waves):
     out = C.c_float(0)
-    assert lib.nemgpu_halfsum_device(x.ctypes.data, len(x), 0, C.byref(out)) == 0
+    assert lib.nemgpu_halfsum_device(x.ctypes.data, len(x), waves, 0, C.byref(out)) == 0
     want = lib.nemgpu_halfsum_host(x.ctypes.data, len(x), 0, None)
     assert np.float32(want).view(np.uint32) == np.float32(out.value).view(np.uint32), (name, want, out.value)
 
@@ -141,6 +143,6 @@ def test_device_procedure_fuzz(gpu_lib, lib):
             x[rng.random(n) < rng.random()] = 0.0
         x = np.ascontiguousarray(x, np.float32)
         out = C.c_float(0)
-        assert lib.nemgpu_halfsum_device(x.ctypes.data, n, 0, C.byref(out)) == 0
+        assert lib.nemgpu_halfsum_device(x.ctypes.data, n, (16, 1)[t % 2], 0, C.byref(out)) == 0
         want = lib.nemgpu_halfsum_host(x.ctypes.data, n, 0, None)
         assert np.float32(want).view(np.uint32) == np.float32(out.value).view(np.uint32), (t, n, scale)
