@@ -273,7 +273,7 @@ def rocprof_average_ms(kernel, n_loc, d):
         for w in rec.get("workloads", []):
             if w.get("families") == n_loc and w.get("organisms") == d:
                 for name, v in w.get("kernels", {}).items():
-                    if name.startswith(kernel):
+                    if name == kernel or name.startswith(kernel + "<"):
                         return v["avg_ms"]
     except (OSError, ValueError):
         pass

@@ -59,10 +59,24 @@ def full_launch_us(trace_csv, kernel):
 
 
 def main():
-    for cfg in ("c2", "c3", "c4", "c2_fuzzy", "b16"):
+    averages = []
+    for cfg in ("c2", "c3", "c4", "c2_fuzzy", "b16", "dist1"):
         f = newest("%s_%s/*/*_kernel_stats.csv" % (R, cfg))
         if f:
             shutil.copy(f, os.path.join(HERE, "%s_%s_kernel_stats.csv" % (R, cfg)))
+            shape = {"c2": (20000, 500), "c3": (50000, 1000), "c4": (200000, 5000)}.get(cfg)
+            if shape:
+                # what bench.py quotes as rocprof_avg_launch_ms: the kernel-trace average of every launch of the run
+                ks = {}
+                for r in csv.DictReader(open(f)):
+                    ks[short(r["Name"])] = {"avg_ms": float(r["AverageNs"]) * 1e-6, "calls": int(r["Calls"]),
+                                            "min_ms": float(r["MinNs"]) * 1e-6, "max_ms": float(r["MaxNs"]) * 1e-6}
+                averages.append({"families": shape[0], "organisms": shape[1], "source": "%s_%s_kernel_stats.csv" % (R, cfg),
+                                 "kernels": ks})
+    if averages:
+        json.dump({"what": "rocprofv3 --kernel-trace --stats averages per kernel (all launches of the profiled bench run, "
+                           "the early returns at the stop word included)", "workloads": averages},
+                  open(os.path.join(HERE, "%s_kernel_averages.json" % R), "w"), indent=1)
     calib = newest("%s_calib/*/*_counter_collection.csv" % R)
     factor = None
     if calib:
@@ -131,7 +145,8 @@ def main():
     # written by tests/test_gpu_dropin_fullsize.py whenever the GPU tests run)
     for name in ("bench_c2.json", "bench_c2_driver.json", "bench_20000x500.json", "bench_50000x1000.json",
                  "bench_200000x5000.json", "bench_20000x500_latent3.json", "bench_20000x500_fuzzy.json",
-                 "bench_20000x500_skd.json", "bench_dist_world1.json", "bench_2ranks_gloo_one_gpu.json",
+                 "bench_20000x500_skd.json", "bench_dist_world1.json", "bench_2ranks_gloo_one_gpu.json", "dist_world1.json",
+                 "dist_world1_20000x500.json", "dist_2ranks_gloo_strong.json", "dist_2ranks_gloo_replicas.json", "dist_2ranks_gloo_weak.json",
                  "pcie_inclusive.json", "batch_chunks.json", "batch_lockstep.json", "random_starts.json",
                  "dropin_whole_call.json", "dropin_logged.json", "fuzzy_mstep.txt", "fuzzy_mstep_lane_per_chain.txt", "fuzzy_mstep_wave_per_chain.txt"):
         b = os.path.join(OUT, "%s_%s" % (R, name))
