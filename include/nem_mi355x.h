@@ -276,6 +276,20 @@ int nemgpu_shard_estep_round1(nemgpu_engine* e, float beta, int sweep_id, const 
    depend on each other), else the two launches */
 int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id, const uint8_t* labels_old_dev,
                                      const uint8_t* labels_guess_dev, uint8_t* labels_out_dev, int32_t* stats_dev);
+/* Fuzzy NEM (algo = nem) on several GPUs -- SURVEY.md 8e's exact alternative to an all-reduce, which cannot reproduce
+   the reference's i-ordered float sums (nem_mod.c:1303-1313, 1677-1686): the E-step sharded over FAMILIES, the M-step
+   over ORGANISMS.  Per rank two engines: a row engine (its families x all organisms; site range [lo, hi) of n_total)
+   and a column engine (all families x its organisms).  The membership matrix lives in caller-owned device arrays
+   float[n_total][K] that the caller all-gathers after every relaxation round; the statistics of the organism slices
+   are all-gathered into arrays of K, K*D, K*D floats.  One step per call, every call synchronises
+   (pangenomenem_amd/distributed.py: ShardedFuzzyNem).  Results equal the single engine's bit for bit. */
+int nemgpu_shard_fuzzy_layout(nemgpu_engine* e, int n_true);      /* families of the whole problem (n_total may be padded) */
+int nemgpu_shard_fuzzy_round(nemgpu_engine* e, float beta, int sweep_id, int round, const float* c_old_dev, const float* c_guess_dev,
+                             float* c_out_dev, int* changed, int* nzero, int* firstzero);
+int nemgpu_shard_fuzzy_mstep_cols(nemgpu_engine* e, const float* c_dev, float* nbobs_out_dev, float* center_out_dev, float* iner_out_dev);
+int nemgpu_shard_fuzzy_finish(nemgpu_engine* e, const float* nbobs_dev, const float* center_dev, const float* iner_dev, int* emptyk);
+int nemgpu_shard_fuzzy_moved(nemgpu_engine* e, const float* c_new_dev, const float* c_old_dev, int* moved);
+
 /* nemgpu_shard_begin for a batch that starts the run over: nemgpu_reset, the cleared loop control and the density
    tables in one launch */
 int nemgpu_shard_begin_restart(nemgpu_engine* e);

@@ -3241,6 +3241,126 @@ int nemgpu_shard_estep_round1_counts(nemgpu_engine* e, float beta, int sweep_id,
     return NEMGPU_OK;
 }
 
+// ---- fuzzy NEM on several GPUs (SURVEY.md 8e's exact alternative) ----------------------------------------------
+// The fuzzy M-step's sums are i-ordered float accumulators (nem_mod.c:1303-1313, 1677-1686, 1448-1458): no reduction
+// over family shards reproduces them.  So the E-step is sharded over FAMILIES (this engine: rows [lo, hi), the
+// memberships of every family in caller-owned arrays float[n_total][K] that the caller all-gathers between relaxation
+// rounds) and the M-step over ORGANISMS (a second engine per rank that holds ALL families x its slice of the
+// organisms: every chain is summed on one device over the whole, gathered membership matrix, in family order).
+// Host-driven, one step per call; pangenomenem_amd/distributed.py:ShardedFuzzyNem drives it.
+
+// families of the whole problem when n_total carries padding (proportions divide by it, nem_mod.c:456-465)
+int nemgpu_shard_fuzzy_layout(nemgpu_engine* e, int n_true)
+{
+    if (!e || n_true <= 0 || n_true > e->n_total) return NEMGPU_E_FUNCARG;
+    if (e->ncem()) { set_error("nemgpu_shard_fuzzy_*: the engine must be configured with algo = nem"); return NEMGPU_E_ARG; }
+    e->n_true = n_true;
+    return NEMGPU_OK;
+}
+
+// one relaxation round of the E-step sweep over this engine's families: c_out[lo..hi) from the guess c_guess (round 0:
+// the old partition) -- the other families' rows of c_out are left alone (the caller's all-gather fills them).
+// changed / nzero / firstzero (host): the round's flags (firstzero: global index of the first family whose densities
+// all vanished, -1 if none).  Synchronises.
+int nemgpu_shard_fuzzy_round(nemgpu_engine* e, float beta, int sweep_id, int round, const float* c_old_dev, const float* c_guess_dev,
+                             float* c_out_dev, int* changed, int* nzero, int* firstzero)
+{
+    if (!e || !c_old_dev || !c_guess_dev || !c_out_dev || round < 0) return NEMGPU_E_FUNCARG;
+    if (e->ncem()) { set_error("nemgpu_shard_fuzzy_round: the engine must be configured with algo = nem"); return NEMGPU_E_ARG; }
+    HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    const int slot = round % kRoundCap;
+    HIPCHK(hipMemsetAsync(e->round_flags(slot), 0, FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+    SweepArgs a{};
+    a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad;
+    a.use_nei = (e->has_graph && beta != 0.0f) ? 1 : 0;
+    a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w;
+    a.beta = beta; a.pkfki = e->pkfki;
+    a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = (uint32_t)sweep_id;
+    a.c_old = c_old_dev; a.c_guess = c_guess_dev; a.c_out = c_out_dev;
+    a.flags = e->round_flags(slot);
+    a.fold_ticket = e->sweep_next + 32;
+    launch_sweep(a, false, e->stream);
+    HIPCHK(hipGetLastError());
+    e->flags_clean = false;
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if ((r = check_fault(e))) return r;
+    const int* f = e->h_round(slot);
+    if (changed) *changed = f[FLAG_CHANGED];
+    if (nzero) *nzero = f[FLAG_NZERO];
+    if (firstzero) *firstzero = f[FLAG_NZERO] > 0 ? e->n_total - f[FLAG_FIRSTZERO] : -1;
+    return NEMGPU_OK;
+}
+
+// EstimSizes / EstimLaplaceCenters / EstimLaplaceIner for THIS engine's organisms on the memberships of all its
+// families (c_dev: float[n][K], the whole gathered matrix for an organism-slice engine): class sizes, centres and
+// inertia to device arrays of the caller's (K, K * d, K * d floats).  Dispersions are not derived here: InerToDisp
+// needs every organism (nemgpu_shard_fuzzy_finish).
+int nemgpu_shard_fuzzy_mstep_cols(nemgpu_engine* e, const float* c_dev, float* nbobs_out_dev, float* center_out_dev, float* iner_out_dev)
+{
+    if (!e || !c_dev || !nbobs_out_dev || !center_out_dev || !iner_out_dev) return NEMGPU_E_FUNCARG;
+    if (e->ncem()) { set_error("nemgpu_shard_fuzzy_mstep_cols: the engine must be configured with algo = nem"); return NEMGPU_E_ARG; }
+    HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    launch_mstep_fuzzy(e->n, e->npad, e->k, e->d, e->xw, e->xt, e->nw64, c_dev + (size_t)e->lo * e->k,
+                       e->fuzzy_chains ? e->fz_ct : nullptr, e->nbobs_k,
+                       e->fz_in0, e->fz_in1, e->fz_inh, e->fz_lastz, e->fz_any1, e->center, e->iner, nullptr, e->stream,
+                       e->fuzzy_chains == 2 ? e->fz_chk : nullptr, e->iter_flags() + FLAG_FAULT, e->fault_inject);
+    HIPCHK(hipGetLastError());
+    const size_t kd = (size_t)e->k * e->d;
+    HIPCHK(hipMemcpyAsync(nbobs_out_dev, e->nbobs_k, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(center_out_dev, e->center, sizeof(float) * kd, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(iner_out_dev, e->iner, sizeof(float) * kd, hipMemcpyDeviceToDevice, e->stream));
+    e->tables_fresh = false; e->density_fresh = false;
+    return read_iter_flags(e);                                     // (waits; a stalled hand-over of the M-step is an error)
+}
+
+// the rest of EstimPara on the gathered statistics of ALL organisms (device arrays: K, K * D, K * D floats): InerToDisp*
+// (nem_mod.c:922-1174), proportions, the empty-class test, the density tables -- then E1 on this engine's families.
+// emptyk (host): 0, or the class (1..K) EstimLaplaceCenters found empty (nothing else was updated for it).
+int nemgpu_shard_fuzzy_finish(nemgpu_engine* e, const float* nbobs_dev, const float* center_dev, const float* iner_dev, int* emptyk)
+{
+    if (!e || !nbobs_dev || !center_dev || !iner_dev) return NEMGPU_E_FUNCARG;
+    if (e->ncem()) { set_error("nemgpu_shard_fuzzy_finish: the engine must be configured with algo = nem"); return NEMGPU_E_ARG; }
+    HIPCHK(hipSetDevice(e->device));
+    { const int fr = flush_reset(e); if (fr) return fr; }
+    int r;
+    if ((r = ensure_state_buffers(e))) return r;
+    const size_t kd = (size_t)e->k * e->d;
+    HIPCHK(hipMemcpyAsync(e->nbobs_k, nbobs_dev, sizeof(float) * e->k, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->center, center_dev, sizeof(float) * kd, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->iner, iner_dev, sizeof(float) * kd, hipMemcpyDeviceToDevice, e->stream));
+    launch_finish(finish_args(e, 2, nullptr), e->stream);
+    HIPCHK(hipGetLastError());
+    e->tables_fresh = true; e->density_fresh = false;
+    if ((r = read_iter_flags(e))) return r;
+    const int ek = e->h_iter()[FLAG_EMPTYK];
+    if (emptyk) *emptyk = ek;
+    if (ek != 0) return NEMGPU_W_EMPTYCLASS;                       // nem_alg.c:1831-1838: the E-step does not run
+    return do_density(e);
+}
+
+// HasConverged's CVTEST_CLAS (nem_alg.c:2075-2089) over this engine's families: moved (host) = some membership moved
+// by the threshold or more
+int nemgpu_shard_fuzzy_moved(nemgpu_engine* e, const float* c_new_dev, const float* c_old_dev, int* moved)
+{
+    if (!e || !c_new_dev || !c_old_dev || !moved) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
+    launch_conv_fuzzy((size_t)e->n * e->k, c_new_dev + (size_t)e->lo * e->k, c_old_dev + (size_t)e->lo * e->k, e->cfg.cvthres,
+                      e->iter_flags(), nullptr, nullptr, e->stream);
+    HIPCHK(hipGetLastError());
+    int r;
+    if ((r = read_iter_flags(e))) return r;
+    *moved = e->h_iter()[FLAG_MOVED];
+    return NEMGPU_OK;
+}
+
 // convergence test over the whole label array + the device-side loop tests (k_ctrl logic)
 int nemgpu_shard_finish_iteration(nemgpu_engine* e, float beta, int is_init, const uint8_t* labels_old_dev,
                                   const uint8_t* labels_q_dev, const uint8_t* labels_r_dev)

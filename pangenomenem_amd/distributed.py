@@ -609,3 +609,221 @@ class ShardedNem:
         cfg = dict(algo="ncem", beta=beta, disper="sk_", propor="pk", cvtest="none", it_max=100)
         st = GpuStepper(x_local, nei, k, n_total, world, rank, prop, center, disp, device, cfg)
         return cls(st, comm or Comm(), n_total, beta, cvtest="none")
+
+
+# ======================================================================================================
+# Fuzzy NEM (algo = "nem") on several GPUs: E-step sharded over families, M-step over organisms
+# ======================================================================================================
+def organism_bounds(d, world, rank):
+    """Contiguous blocks of ceil(d/world) organisms: the chains a rank sums in the M-step."""
+    blk = (d + world - 1) // world
+    lo = min(rank * blk, d)
+    return lo, min(lo + blk, d), blk
+
+
+class FuzzyGpuStepper:
+    """One rank's compute of the organism/family-sharded fuzzy EM: a ROW engine (its families x all organisms: E1 and
+    the relaxation rounds of the E-step sweep) and a COLUMN engine (all families x its organisms: the M-step's
+    i-ordered chains), both behind the nemgpu_shard_fuzzy_* C ABI.  Membership matrices are torch tensors
+    float32[world * blk, K] owned by the driver."""
+
+    def __init__(self, x_rows, x_cols, nei_rows, k, n_total, d, world, rank, prop, center, disp, device, cfg):
+        import ctypes as C
+        import torch
+        from .engine import NemEngine
+        self.torch, self.C = torch, C
+        self.device = torch.device("cuda", device)
+        self.k, self.d, self.n_total, self.world, self.rank = k, d, n_total, world, rank
+        lo, hi, blk = shard_bounds(n_total, world, rank)
+        dlo, dhi, dblk = organism_bounds(d, world, rank)
+        if hi <= lo or dhi <= dlo:
+            raise ValueError("rank %d would own no family or no organism (%d x %d over %d ranks): use fewer ranks"
+                             % (rank, n_total, d, world))
+        assert x_rows.shape == (hi - lo, d) and x_cols.shape == (n_total, dhi - dlo)
+        self.blk, self.dblk, self.n_pad, self.dlo, self.dhi = blk, dblk, world * blk, dlo, dhi
+        self.stream = torch.cuda.Stream(self.device)
+        cfg = dict(cfg, algo="nem")
+        center = np.asarray(center, np.float32).reshape(k, d)
+        disp = np.asarray(disp, np.float32).reshape(k, d)
+        self.row = NemEngine(self.n_pad, d, k, device=device, stream=self.stream.cuda_stream, site_lo=lo, site_hi=hi)
+        self.row.set_matrix(x_rows)
+        self.row.set_graph(nei_rows)
+        self.row.set_params(prop, center, disp)
+        self.row.configure(**cfg)
+        self.row._chk(self.row.lib.nemgpu_shard_fuzzy_layout(self.row._h, n_total))
+        self.col = NemEngine(self.n_pad, dhi - dlo, k, device=device, stream=self.stream.cuda_stream, site_lo=0, site_hi=n_total)
+        self.col.set_matrix(x_cols)
+        self.col.set_graph(None)
+        self.col.set_params(prop, np.ascontiguousarray(center[:, dlo:dhi]), np.ascontiguousarray(disp[:, dlo:dhi]))
+        self.col.configure(**cfg)
+        self._tmp = [torch.zeros(k * (dhi - dlo), dtype=torch.float32, device=self.device) for _ in range(2)]
+
+    def alloc(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float32, device=self.device)
+
+    def _p(self, t):
+        return self.C.c_void_p(t.data_ptr())
+
+    def reset(self):
+        self.row.reset()
+
+    def density(self):
+        with self.torch.cuda.stream(self.stream):
+            self.row._chk(self.row.lib.nemgpu_density(self.row._h))
+
+    def round(self, beta, sweep_id, r, old, guess, out):
+        C = self.C
+        ch, nz, fz = C.c_int(0), C.c_int(0), C.c_int(-1)
+        with self.torch.cuda.stream(self.stream):
+            self.row._chk(self.row.lib.nemgpu_shard_fuzzy_round(self.row._h, C.c_float(beta), int(sweep_id), int(r), self._p(old),
+                                                                self._p(guess), self._p(out), C.byref(ch), C.byref(nz), C.byref(fz)))
+        return ch.value, nz.value, fz.value
+
+    def mstep_cols(self, c, stats_block):
+        """stats_block: this rank's float32[K + 2 K dblk] block {N_k | centres [K, dblk] | inertia [K, dblk]}"""
+        k, dl, db = self.k, self.dhi - self.dlo, self.dblk
+        nb = stats_block[:k]
+        with self.torch.cuda.stream(self.stream):
+            self.col._chk(self.col.lib.nemgpu_shard_fuzzy_mstep_cols(self.col._h, self._p(c), self._p(nb), self._p(self._tmp[0]),
+                                                                     self._p(self._tmp[1])))
+            stats_block[k:k + k * db].view(k, db)[:, :dl] = self._tmp[0].view(k, dl)
+            stats_block[k + k * db:].view(k, db)[:, :dl] = self._tmp[1].view(k, dl)
+        self.stream.synchronize()
+
+    def finish(self, nb, center_full, iner_full):
+        ek = self.C.c_int(0)
+        with self.torch.cuda.stream(self.stream):
+            rc = self.row.lib.nemgpu_shard_fuzzy_finish(self.row._h, self._p(nb), self._p(center_full), self._p(iner_full), self.C.byref(ek))
+        self.row._chk(rc, allow=(STATUS_OK, STATUS_W_EMPTYCLASS))
+        return ek.value
+
+    def moved(self, new, old):
+        mv = self.C.c_int(0)
+        with self.torch.cuda.stream(self.stream):
+            self.row._chk(self.row.lib.nemgpu_shard_fuzzy_moved(self.row._h, self._p(new), self._p(old), self.C.byref(mv)))
+        return mv.value
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def params(self):
+        return self.row.params()
+
+
+class ShardedFuzzyNem:
+    """NemAlgo (nem_alg.c:1746-1879) for algo = "nem" on `world` ranks, bit-identical to one engine (and to the
+    reference): SURVEY.md 8e's exact alternative to an all-reduce of float sums.
+      * E1 and the E-step sweep run on the rank's FAMILIES; the sweep is the relaxation of pangenomenem_amd's single
+        engine (round r evaluates every site against the memberships of round r-1; a round that changes nothing
+        anywhere is the sequential sweep's result) with ONE all-gather of the membership rows per round and one
+        max-reduction of the "changed" flags;
+      * the M-step's i-ordered chains (class sizes, the zeros' weights of the medians, the inertia sums) run on the
+        rank's ORGANISMS over the whole gathered membership matrix, in family order; one all-gather carries every
+        rank's {N_k, centres, inertia} block; every rank then derives dispersions, proportions and tables for all
+        organisms (InerToDisp's d-ordered sums need them all).
+    Host-driven (one step per library call): an exactness path, not a fast one."""
+
+    def __init__(self, stepper, comm, n_total, d, k, beta, cvtest="clas", cvthres=1e-8):
+        self.st, self.comm = stepper, comm
+        self.n_total, self.d, self.k, self.beta = n_total, d, k, beta
+        self.cvtest, self.cvthres = cvtest, cvthres
+        self.world, self.rank = comm.world, comm.rank
+        self.blk = (n_total + self.world - 1) // self.world
+        self.dblk = (d + self.world - 1) // self.world
+        self.n_pad = self.world * self.blk
+        self.c = [stepper.alloc(self.n_pad, k) for _ in range(3)]
+        self.sw = k + 2 * k * self.dblk
+        self.stats = stepper.alloc(self.world * self.sw)
+        self.iters, self.converged, self.status, self.emptyk = 0, False, STATUS_OK, 0
+        self.sweep_rounds, self.zero_density, self.first_zero = 0, 0, -1
+        self.cur = 0
+
+    def _gather_rows(self, t):
+        self.st.sync()
+        flat = t.view(self.st.torch.uint8).reshape(-1) if hasattr(t, "view") else t
+        self.comm.allgather_blocks_(flat, self.blk * self.k * 4)
+
+    def _sweep(self, P, beta, sweep_id):
+        """One Gauss-Seidel sweep (ComputePartitionNEM, nem_alg.c:2330-2405) from buffer P by relaxation rounds."""
+        Q, R = (P + 1) % 3, (P + 2) % 3
+        r = 0
+        verify = beta != 0.0
+        while True:
+            guess, out = (P, Q) if r == 0 else ((R, Q) if r % 2 == 0 else (Q, R))
+            changed, nz, fz = self.st.round(beta, sweep_id, r, self.c[P], self.c[guess], self.c[out])
+            self._gather_rows(self.c[out])
+            r += 1
+            if not verify or self.comm.allreduce_max_int(changed) == 0:
+                break
+        self.sweep_rounds += r
+        nz_all = self.comm.allreduce_sum_int(nz)
+        if nz_all > 0:
+            self.zero_density += nz_all
+            first = -self.comm.allreduce_max_int(-fz if fz >= 0 else -(1 << 30))
+            if self.first_zero < 0 and first < (1 << 30):
+                self.first_zero = first
+        return out
+
+    def _mstep(self, cur):
+        k, db, sw = self.k, self.dblk, self.sw
+        mine = self.stats[self.rank * sw:(self.rank + 1) * sw]
+        self.st.mstep_cols(self.c[cur], mine)
+        flat = self.stats.view(self.st.torch.uint8).reshape(-1) if hasattr(self.stats, "view") else self.stats
+        self.comm.allgather_blocks_(flat, sw * 4)
+        blocks = self.stats.view(self.world, sw)
+        nb = blocks[self.rank, :k].contiguous()                 # (every rank summed the same memberships in the same order)
+        cen = blocks[:, k:k + k * db].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
+        ine = blocks[:, k + k * db:].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
+        return self.st.finish(nb, cen, ine)
+
+    def run(self, it_max=100):
+        self.st.reset()
+        for t in self.c:
+            t.zero_()
+        self.iters, self.converged, self.status, self.emptyk = 0, False, STATUS_OK, 0
+        self.sweep_rounds, self.zero_density, self.first_zero = 0, 0, -1
+        # ComputePartitionFromPara(Needinit = 1): densities of the initial parameters, blind sweep, sweep
+        self.st.density()
+        cur = self._sweep(0, 0.0, 0)
+        cur = self._sweep(cur, self.beta, 1)
+        sweep_id = 2
+        for _ in range(it_max):
+            ek = self._mstep(cur)
+            if ek != 0:                                          # nem_alg.c:1831-1838
+                self.status, self.emptyk = STATUS_W_EMPTYCLASS, ek
+                self.iters += 1
+                break
+            new = self._sweep(cur, self.beta, sweep_id)
+            sweep_id += 1
+            self.iters += 1
+            old, cur = cur, new
+            if self.cvtest == "clas":
+                moved = self.comm.allreduce_max_int(self.st.moved(self.c[cur], self.c[old]))
+                if not moved:
+                    self.converged = True
+                    break
+        self.cur = cur
+        return dict(status=self.status, iters=self.iters, converged=self.converged, emptyk=self.emptyk,
+                    sweep_rounds=self.sweep_rounds, zero_density=self.zero_density, first_zero=self.first_zero)
+
+    def memberships(self):
+        """float32[n_total, K]: the final partition (every rank holds all of it)."""
+        t = self.c[self.cur][:self.n_total]
+        return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+    def params(self):
+        return self.st.params()
+
+    @classmethod
+    def from_problem(cls, x, nei, k, prop, center, disp, beta, rank, world, device, comm=None, disper="sk_", propor="pk",
+                     cvtest="clas", cvthres=1e-8):
+        """Shard a whole problem held by every rank (tests, small runs): rows [lo, hi) for the row engine, the
+        organism slice of all rows for the column engine."""
+        n, d = x.shape
+        lo, hi, _ = shard_bounds(n, world, rank)
+        dlo, dhi, _ = organism_bounds(d, world, rank)
+        nei_rows = slice_graph(nei, lo, hi) if nei is not None else None
+        cfg = dict(beta=beta, disper=disper, propor=propor, cvtest=cvtest, cvthres=cvthres, it_max=100)
+        st = FuzzyGpuStepper(np.ascontiguousarray(x[lo:hi]), np.ascontiguousarray(x[:, dlo:dhi]), nei_rows, k, n, d, world, rank,
+                             prop, center, disp, device, cfg)
+        return cls(st, comm or Comm(), n, d, k, beta, cvtest=cvtest, cvthres=cvthres)

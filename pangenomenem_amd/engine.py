@@ -126,6 +126,11 @@ def load_library():
     lib.nemgpu_shard_grow_draws.argtypes = [vp]
     lib.nemgpu_shard_book_draws.argtypes = [vp, C.c_int]
     lib.nemgpu_shard_set_sweep_number.argtypes = [vp, C.c_int]
+    lib.nemgpu_shard_fuzzy_layout.argtypes = [vp, C.c_int]
+    lib.nemgpu_shard_fuzzy_round.argtypes = [vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, ip, ip, ip]
+    lib.nemgpu_shard_fuzzy_mstep_cols.argtypes = [vp, vp, vp, vp, vp]
+    lib.nemgpu_shard_fuzzy_finish.argtypes = [vp, vp, vp, vp, ip]
+    lib.nemgpu_shard_fuzzy_moved.argtypes = [vp, vp, vp, ip]
     lib.nemio_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.nemio_free.argtypes = [vp]
     lib.nemio_free.restype = None
