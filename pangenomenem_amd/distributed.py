@@ -703,6 +703,11 @@ class FuzzyGpuStepper:
             self.row._chk(self.row.lib.nemgpu_shard_fuzzy_moved(self.row._h, self._p(new), self._p(old), self.C.byref(mv)))
         return mv.value
 
+    def on_stream(self):
+        """torch work (collectives, the reshuffling of gathered blocks) goes on the engines' stream: stream order is
+        what orders it against the library's launches"""
+        return self.torch.cuda.stream(self.stream)
+
     def sync(self):
         self.stream.synchronize()
 
@@ -739,9 +744,10 @@ class ShardedFuzzyNem:
         self.cur = 0
 
     def _gather_rows(self, t):
+        with self.st.on_stream():
+            flat = t.view(self.st.torch.uint8).reshape(-1)
+            self.comm.allgather_blocks_(flat, self.blk * self.k * 4)
         self.st.sync()
-        flat = t.view(self.st.torch.uint8).reshape(-1) if hasattr(t, "view") else t
-        self.comm.allgather_blocks_(flat, self.blk * self.k * 4)
 
     def _sweep(self, P, beta, sweep_id):
         """One Gauss-Seidel sweep (ComputePartitionNEM, nem_alg.c:2330-2405) from buffer P by relaxation rounds."""
@@ -768,18 +774,22 @@ class ShardedFuzzyNem:
         k, db, sw = self.k, self.dblk, self.sw
         mine = self.stats[self.rank * sw:(self.rank + 1) * sw]
         self.st.mstep_cols(self.c[cur], mine)
-        flat = self.stats.view(self.st.torch.uint8).reshape(-1) if hasattr(self.stats, "view") else self.stats
-        self.comm.allgather_blocks_(flat, sw * 4)
-        blocks = self.stats.view(self.world, sw)
-        nb = blocks[self.rank, :k].contiguous()                 # (every rank summed the same memberships in the same order)
-        cen = blocks[:, k:k + k * db].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
-        ine = blocks[:, k + k * db:].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
+        with self.st.on_stream():
+            flat = self.stats.view(self.st.torch.uint8).reshape(-1)
+            self.comm.allgather_blocks_(flat, sw * 4)
+            blocks = self.stats.view(self.world, sw)
+            nb = blocks[self.rank, :k].contiguous()             # (every rank summed the same memberships in the same order)
+            cen = blocks[:, k:k + k * db].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
+            ine = blocks[:, k + k * db:].reshape(self.world, k, db).permute(1, 0, 2).reshape(k, self.world * db)[:, :self.d].contiguous()
+        self.st.sync()
         return self.st.finish(nb, cen, ine)
 
     def run(self, it_max=100):
         self.st.reset()
-        for t in self.c:
-            t.zero_()
+        with self.st.on_stream():
+            for t in self.c:
+                t.zero_()
+        self.st.sync()
         self.iters, self.converged, self.status, self.emptyk = 0, False, STATUS_OK, 0
         self.sweep_rounds, self.zero_density, self.first_zero = 0, 0, -1
         # ComputePartitionFromPara(Needinit = 1): densities of the initial parameters, blind sweep, sweep
@@ -802,6 +812,8 @@ class ShardedFuzzyNem:
                 if not moved:
                     self.converged = True
                     break
+        if self.iters == 0:                                      # nem_alg.c:1845-1851: parameters of the partition, their densities
+            self._mstep(cur)
         self.cur = cur
         return dict(status=self.status, iters=self.iters, converged=self.converged, emptyk=self.emptyk,
                     sweep_rounds=self.sweep_rounds, zero_density=self.zero_density, first_zero=self.first_zero)

@@ -42,6 +42,10 @@ class OracleFuzzyStepper:
     def sync(self):
         pass
 
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def density(self):
         self.pk, self.lp, _ = self.o.density(self.x_rows, self.prop, self.center, self.disp)
 
@@ -101,7 +105,7 @@ class OracleFuzzyStepper:
         return dict(prop=self.prop, center=self.center, disp=self.disp, nbobs_k=self.nbobs_k)
 
 
-def _worker(rank, world, initfile, n, d, k, beta, disper, seed, outdir):
+def _worker(rank, world, initfile, n, d, k, beta, disper, seed, it_max, outdir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from oracle.pyoracle import Oracle
@@ -114,28 +118,28 @@ def _worker(rank, world, initfile, n, d, k, beta, disper, seed, outdir):
         prop, center, disp = synth.default_init(d)
         st = OracleFuzzyStepper(Oracle(), x, nei, k, world, rank, prop, center, disp, disper, "pk", 1e-8)
         job = ShardedFuzzyNem(st, Comm(), n, d, k, beta, cvtest="clas", cvthres=1e-8)
-        res = job.run(12)
+        res = job.run(it_max)
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), c=job.memberships(), iters=res["iters"], converged=res["converged"],
                  status=res["status"], emptyk=res["emptyk"], rounds=res["sweep_rounds"], **st.params())
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, n, d, k, beta, disper, seed):
+def _run(world, n, d, k, beta, disper, seed, it_max=12):
     import torch.multiprocessing as mp
     outdir = tempfile.mkdtemp(prefix="nemfz_")
-    mp.spawn(_worker, args=(world, os.path.join(outdir, "rdv"), n, d, k, beta, disper, seed, outdir), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, os.path.join(outdir, "rdv"), n, d, k, beta, disper, seed, it_max, outdir), nprocs=world, join=True)
     return [np.load(os.path.join(outdir, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,n,d,beta,disper", [(2, 700, 15, 0.5, "sk_"), (3, 500, 20, 1.0, "skd"), (2, 401, 9, 0.0, "sk_"),
-                                                   (3, 64, 7, 0.5, "skd")])
-def test_sharded_fuzzy_em_equals_the_single_process_oracle(oracle, world, n, d, beta, disper):
+@pytest.mark.parametrize("world,n,d,beta,disper,it_max", [(2, 700, 15, 0.5, "sk_", 12), (3, 500, 20, 1.0, "skd", 12), (2, 401, 9, 0.0, "sk_", 12),
+                                                          (3, 64, 7, 0.5, "skd", 12), (2, 300, 11, 0.5, "sk_", 0)])
+def test_sharded_fuzzy_em_equals_the_single_process_oracle(oracle, world, n, d, beta, disper, it_max):
     from pangenomenem_amd import synth
-    outs = _run(world, n, d, 3, beta, disper, 4)
+    outs = _run(world, n, d, 3, beta, disper, 4, it_max)
     x, _ = synth.ushaped_pa_matrix(n, d, 4)
     prop, center, disp = synth.default_init(d)
-    want = oracle.run(x, synth.contiguity_graph(n, 4), 3, prop, center, disp, algo="nem", beta=beta, disper=disper, it_max=12)
+    want = oracle.run(x, synth.contiguity_graph(n, 4), 3, prop, center, disp, algo="nem", beta=beta, disper=disper, it_max=it_max)
     for o in outs:
         assert int(o["status"]) == want["status"] and int(o["iters"]) == want["iters"] and bool(o["converged"]) == want["converged"]
         assert np.array_equal(o["c"].view(np.uint32), want["c"].view(np.uint32))              # memberships: bit for bit

@@ -44,13 +44,13 @@ def _run(world, backend, n, d, beta, disper, it_max):
     return [np.load(os.path.join(outdir, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,backend,n,d,beta,disper", [(1, "nccl", 3000, 40, 0.5, "sk_"), (2, "gloo", 3000, 40, 0.5, "sk_"),
-                                                           (3, "gloo", 2500, 70, 1.0, "skd"), (2, "gloo", 1501, 33, 0.0, "sk_")])
-def test_gpu_sharded_fuzzy_equals_the_single_engine_and_the_oracle(gpu_lib, oracle, world, backend, n, d, beta, disper):
+@pytest.mark.parametrize("world,backend,n,d,beta,disper,it_max", [(1, "nccl", 3000, 40, 0.5, "sk_", 10), (2, "gloo", 3000, 40, 0.5, "sk_", 10),
+                                                                  (3, "gloo", 2500, 70, 1.0, "skd", 10), (2, "gloo", 1501, 33, 0.0, "sk_", 10),
+                                                                  (2, "gloo", 1000, 20, 0.5, "sk_", 0), (2, "gloo", 20000, 500, 0.5, "sk_", 3)])
+def test_gpu_sharded_fuzzy_equals_the_single_engine_and_the_oracle(gpu_lib, oracle, world, backend, n, d, beta, disper, it_max):
     from pangenomenem_amd import synth
     from pangenomenem_amd.engine import solve
     from tests.util import maxdiff
-    it_max = 10
     outs = _run(world, backend, n, d, beta, disper, it_max)
     x, _ = synth.ushaped_pa_matrix(n, d, 4)
     nei = synth.contiguity_graph(n, 4)
