@@ -2,6 +2,8 @@
 on the same seeded inputs.  Bar (BASELINE.json north_star): integer labels bit-exact; posteriors,
 epsilon, pi within 1e-6.  In practice every float below is compared bit-for-bit except the two
 places a device libm call enters (exp -> pk*fk, exp -> MRF factor), which get an explicit bound."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -85,7 +87,7 @@ def test_density_fast_forward_falls_back_for_dispersions_above_half(gpu_lib, ora
     eng.close()
 
 
-@pytest.mark.parametrize("algo,disper", [("ncem", "sk_"), ("nem", "sk_"), ("ncem", "s__")])
+@pytest.mark.parametrize("algo,disper", [("ncem", "sk_"), ("nem", "sk_"), ("ncem", "s__"), ("ncem", "skd")])
 def test_full_run_with_fast_forward_forced(gpu_lib, oracle, algo, disper):
     """Whole EM with the fast-forwarded E1 (the automatic mode would step a problem this small)."""
     from pangenomenem_amd.engine import solve
@@ -245,3 +247,56 @@ def test_k_sweep_free_dispersion(gpu_lib, oracle, k):
         assert maxdiff(got["c"], want["c"]) <= TOL, algo
         assert maxdiff(got["disp"], want["disp"]) <= TOL, algo
         assert maxdiff(got["prop"], want["prop"]) <= TOL, algo
+
+
+@pytest.mark.parametrize("n,d,k", [(2048, 15, 3), (1500, 33, 3), (3000, 70, 4), (2500, 300, 3), (1200, 1000, 3), (20000, 500, 3),
+                                   (4000, 257, 6)])
+def test_free_dispersion_fast_forward_equals_stepping(gpu_lib, oracle, n, d, k):
+    """Free dispersion (skd, PPanGGOLiN's free_dispersion): every organism of a class has its own epsilon, E1's chain
+    takes the general path of k_density_fused whatever the fast-forward switch says (a per-organism fast-forward was
+    built, measured and dropped in round 3) -- both settings of the switch give the same run, bit
+    for bit, and it equals the oracle's."""
+    from pangenomenem_amd.engine import solve
+    x, _ = synth.ushaped_pa_matrix(n, d, n + d)
+    nei = synth.contiguity_graph(n, n + d)
+    if k == 3:
+        prop, center, disp = synth.default_init(d)
+    else:
+        prop, center, disp = synth.kclass_init(x, k)
+    cfg = dict(algo="ncem", beta=0.5, disper="skd", propor="pk", it_max=8, tie="hash", seed=5)
+    runs = [solve(x, nei, k, prop, center, disp, fast_forward=mode, **cfg) for mode in (1, 0)]
+    a, b = runs
+    assert a["iters"] == b["iters"] and a["status"] == b["status"]
+    assert np.array_equal(a["c"], b["c"])
+    for key in ("disp", "prop", "center", "nbobs_k", "crit"):
+        assert bits_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    want = oracle.run(x, nei, k, prop, center, disp, **cfg)
+    assert a["iters"] == want["iters"] and a["status"] == want["status"]
+    if a["status"] == 0:
+        assert np.array_equal(a["c"], want["c"]) and bits_equal(a["center"], want["center"])
+        assert maxdiff(a["disp"], want["disp"]) <= TOL and maxdiff(a["prop"], want["prop"]) <= TOL
+
+
+def test_free_dispersion_fast_forward_density_is_bit_exact(gpu_lib, oracle):
+    """the densities after two free-dispersion iterations (dispersions of every size): LogPkFki equals the oracle's
+    bit for bit with the fast-forward switch on and off"""
+    from pangenomenem_amd.engine import NemEngine
+    n, d = 3000, 420
+    x, _ = synth.ushaped_pa_matrix(n, d, 77)
+    nei = synth.contiguity_graph(n, 77)
+    prop, center, disp = synth.default_init(d)
+    for mode in (1, 0):
+        eng = NemEngine(n, d, 3)
+        eng.set_matrix(x)
+        eng.set_graph(nei)
+        eng.set_params(prop, center, disp)
+        eng.configure(algo="ncem", beta=0.5, disper="skd", it_max=2, cvtest="none", tie="hash", seed=5)
+        eng.set_fast_forward(mode)
+        eng.run()
+        pk = np.zeros((n, 3), np.float64); lp = np.zeros((n, 3), np.float32)
+        eng._chk(eng.lib.nemgpu_get_density(eng._h, pk.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p)))
+        par = eng.params()
+        eng.close()
+        opk, olp, _ = oracle.density(x, par["prop"], par["center"], par["disp"])
+        assert bits_equal(lp, olp)
+        assert ulp_diff64(pk, opk) <= 2
