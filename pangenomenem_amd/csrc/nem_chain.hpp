@@ -50,6 +50,10 @@ NEM_HD inline bool ready(float acc, int& E, int& neg)
     return E >= 1 && E <= 253;
 }
 
+// an accumulator no finite addend can move: +-inf (until `poison` arrives: a NaN or the opposite infinity) and NaN
+NEM_HD inline bool absorbing(float acc) { return ((f2u(acc) >> 23) & 255u) == 255u; }
+NEM_HD inline bool poison(float inf_acc, double x) { return x != x || (x - x != 0.0 && (x < 0.0) != (inf_acc < 0.0f)); }
+
 // s / u as a double: (+-) 2^(150 - E), a normal double for every float exponent field E
 NEM_HD inline double scale(int E, int neg)
 {
@@ -85,7 +89,8 @@ NEM_HD inline bool increment(double x, double sc, long long& inc)
 // Sequential steps taken in a row after an element the integer form could not take: 16, doubling up to 256 while
 // the integer form advances by fewer than 64 elements between two such events (the first binades of a sum, or ties
 // on a coarse grid), back to 16 otherwise; an accumulator the integer form cannot leave at all (zero, subnormal,
-// non-finite) quadruples it up to a whole window.  The result does not depend on it -- both forms are exact --
+// subnormal) quadruples it up to a whole window; an infinite or NaN accumulator skips to the value that changes it (see
+// `absorbing`).  The result does not depend on it -- both forms are exact --
 // only the time does.
 constexpr int kBurst = 16, kBurstTies = 256, kBurstMax = 4096;
 NEM_HD inline int next_burst(int burst, long long advanced)
@@ -107,6 +112,15 @@ inline float run_segmented(const double* x, long long n, float acc, int lanes = 
         while (wpos < wn) {
             int E, neg;
             if (!ready(acc, E, neg)) {
+                if (absorbing(acc)) {
+                    // an infinite accumulator stays what it is until a NaN or the opposite infinity arrives, a NaN for
+                    // good: the steps in between change nothing and are not taken
+                    long long p = wn;
+                    if (!(acc != acc)) for (long long q = wpos; q < wn; q++) if (poison(acc, xs[q])) { p = q; break; }
+                    if (p < wn) acc = step(acc, xs[p++]);
+                    wpos = p;
+                    continue;
+                }
                 for (int b = 0; b < burst && wpos < wn; b++) acc = step(acc, xs[wpos++]);
                 burst = next_burst(burst, -1);
                 continue;

@@ -50,6 +50,20 @@ def cases():
     x = rng.uniform(0, 1, 3000); x[700] = np.nan
     out.append(("nan", x, 0.0))
     out.append(("overflow", np.full(4000, 3e38), 0.0))
+    # an accumulator that is infinite (or NaN) for most of the chain: the steps that change nothing are skipped
+    out.append(("all -inf", np.full(20000, -np.inf), 0.0))                               # (every criterion at 200 000 x 5 000)
+    x = rng.uniform(-1, 1, 30000); x[3] = -np.inf
+    out.append(("-inf then finite", x, 0.0))
+    x = rng.uniform(-1, 1, 30000); x[3] = -np.inf; x[17000] = np.inf
+    out.append(("-inf then +inf", x, 0.0))
+    x = rng.uniform(-1, 1, 30000); x[3] = np.inf; x[29999] = np.nan
+    out.append(("+inf then nan", x, 0.0))
+    x = rng.uniform(-1, 1, 30000); x[5000] = np.inf; x[5001] = np.inf; x[9000] = -np.inf
+    out.append(("+inf +inf -inf", x, 2.5))
+    out.append(("inf accumulator", rng.uniform(-1, 1, 9000), np.inf))
+    out.append(("nan accumulator", rng.uniform(-1, 1, 9000), np.nan))
+    x = rng.uniform(-1, 1, 9000); x[4096] = -np.inf
+    out.append(("-inf accumulator meets -inf", x, -np.inf))
     # sizes around the window / chunk boundaries
     for n in (0, 1, 2, 3, 4, 5, 63, 64, 65, 4095, 4096, 4097, 8192, 12289):
         out.append(("n=%d" % n, rng.uniform(0.5, 1.5, n), 0.0))
