@@ -11,6 +11,7 @@
 // denormals preserved.  Where a sum is order-independent (NCEM: c in {0,1} => integer
 // counts < 2^24) it is computed with popcounts over bit-packed rows instead.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
@@ -1082,8 +1083,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     __shared__ double s_exp[NCEM ? kExpTab : 1];
     __shared__ uint8_t s_lab[NCEM ? BS : 1];             // the block's labels while it iterates
     __shared__ uint64_t s_drew[BS / 64];                 // TIE_LIBC: per wave, which of its sites drew
-    const int i = bx * BS + threadIdx.x;
-    const bool active = i < a.n_local;
+    const int spb = (BS > 256 && a.spb > 0) ? a.spb : BS;   // sites of this block (large shards: fewer than the launch bound)
+    const int i = bx * spb + threadIdx.x;
+    const bool active = (int)threadIdx.x < spb && i < a.n_local;
     const int gi = a.lo + (active ? i : 0);
     const int K = KT > 0 ? KT : a.K;
     constexpr int KA = KT > 0 ? KT : kMaxKernelK;
@@ -1109,7 +1111,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     // rounds: label changes run down the path inside one launch instead of one launch per hop.
     // ------------------------------------------------------------------------------------------
     constexpr bool libc = LIBC;
-    const int blk_lo = a.lo + bx * BS;           // first label slot of this block
+    const int blk_lo = a.lo + bx * spb;          // first label slot of this block
     double pkf[KA];
 #pragma unroll
     for (int k = 0; k < KA; k++) if (k < K) pkf[k] = active && !skip ? a.pkfki[(size_t)k * a.npad + i] : 0.0;
@@ -1252,7 +1254,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         __syncthreads();
         if (threadIdx.x == 0) {
             int cnt = 0;
-            for (int w = 0; w < BS / 64; w++) cnt += (int)__popcll(s_drew[w]);
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) cnt += (int)__popcll(s_drew[w]);
             if (cnt != a.tie_cnt_guess[bx]) changed = true;
             a.tie_cnt_out[bx] = cnt;
             if (cnt > 0) atomicAdd(&a.flags[FLAG_NTIES], cnt);
@@ -3362,10 +3364,10 @@ static bool record_op(int kind, int variant, dim3 grid, unsigned block, const Ar
 static int sweep_variant(int K, bool ncem, bool big, bool libc) { return (K >= 1 && K <= 10 ? K : 0) | (ncem ? 16 : 0) | (big ? 32 : 0) | (libc && ncem ? 64 : 0); }
 
 template <bool BATCHED>
-static void sweep_dispatch(int variant, dim3 grid, hipStream_t s, const SweepArgs* a, const void* arr, int stride, const int* gx)
+static void sweep_dispatch(int variant, dim3 grid, unsigned bdim, hipStream_t s, const SweepArgs* a, const void* arr, int stride, const int* gx)
 {
     const int kt = variant & 15; const bool ncem = (variant & 16) != 0, big = (variant & 32) != 0, libc = (variant & 64) != 0;
-    dim3 block(big ? 1024 : 256);
+    dim3 block(bdim);                                    // (256; the large-shard instances: SweepArgs::spb rounded up to whole waves, at most 1024)
 #define NEM_SW2(KT_, NC_, BS_, LC_)                                                                                \
     do {                                                                                                           \
         if (BATCHED) hipLaunchKernelGGL((k_sweep_b<KT_, NC_, BS_, LC_>), grid, block, 0, s, arr, stride, gx);     \
@@ -3385,17 +3387,29 @@ static void sweep_dispatch(int variant, dim3 grid, hipStream_t s, const SweepArg
 #undef NEM_SW2
 }
 
-void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s)
+void launch_sweep(const SweepArgs& a0, bool ncem, hipStream_t s)
 {
-    // large shards run 1024-site blocks: the per-block flag atomics (one address) are what a round costs when
-    // every site reports something (e.g. all densities underflow at D = 5000)
-    const bool generic = !(a.K >= 1 && a.K <= 10);
-    const bool big = a.n_local >= 65536 && !generic;
-    const int bs = big ? 1024 : 256;
+    // Large shards run up to 1024 sites per block (the per-block flag atomics -- one address -- were what a round cost
+    // when every site reports something, e.g. all densities underflow at D = 5000; the tally now rides on the
+    // last-block ticket, but a round is still bound by each block's instruction stream): as many sites per block as
+    // fill the chip's 256 CUs evenly -- 200 000 sites: 241 blocks of 832 instead of 196 of 1024 on 256 CUs.
+    const bool generic = !(a0.K >= 1 && a0.K <= 10);
+    const bool big = a0.n_local >= 65536 && !generic;
+    SweepArgs a = a0;
+    int bs = 256;
+    a.spb = 0;
+    static const bool balanced = !(getenv("NEM_MI355X_SWEEP_SPB") && getenv("NEM_MI355X_SWEEP_SPB")[0] == '0');   // (0: 1024 sites per block)
+    if (big && !balanced) { a.spb = 1024; bs = 1024; }
+    else if (big) {
+        const int waves_of_blocks = (a.n_local + 256 * 1024 - 1) / (256 * 1024);
+        const int per_block = (a.n_local + 256 * waves_of_blocks - 1) / (256 * waves_of_blocks);
+        a.spb = std::min(1024, std::max(256, (per_block + 63) / 64 * 64));
+        bs = a.spb;
+    }
     dim3 grid((a.n_local + bs - 1) / bs);
     const int variant = sweep_variant(a.K, ncem, big, a.tie_rule == NEMGPU_TIE_LIBC);
     if (record_op(OP_SWEEP, variant, grid, (unsigned)bs, a)) return;
-    sweep_dispatch<false>(variant, grid, s, &a, nullptr, 0, nullptr);
+    sweep_dispatch<false>(variant, grid, (unsigned)bs, s, &a, nullptr, 0, nullptr);
 }
 
 void launch_ctrl(const CtrlArgs& a, hipStream_t s)
@@ -3575,7 +3589,7 @@ void launch_zipped(int kind, int variant, int B, const void* arr, int stride, co
     case OP_FINISH: hipLaunchKernelGGL(k_finish_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_DENSITY: hipLaunchKernelGGL(k_density_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_DENSITY_FUSED: hipLaunchKernelGGL(k_density_fused_b, grid, blk, 0, s, arr, stride, gx); break;
-    case OP_SWEEP: sweep_dispatch<true>(variant, grid, s, nullptr, arr, stride, gx); break;
+    case OP_SWEEP: sweep_dispatch<true>(variant, grid, block, s, nullptr, arr, stride, gx); break;
     case OP_COUNTS:
         if (variant == 4) hipLaunchKernelGGL(k_mstep_counts_b<4>, grid, blk, 0, s, arr, stride, gx);
         else hipLaunchKernelGGL(k_mstep_counts_b<1>, grid, blk, 0, s, arr, stride, gx);

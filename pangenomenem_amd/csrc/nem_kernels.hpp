@@ -91,6 +91,8 @@ struct SweepArgs {
     // in the GUESS buffer (the others slot_stride bytes apart), rank_index = this rank, rank_tot_out = this rank's slot
     // in the output buffer (written by the last block of the round)
     const uint8_t* rank_tot_in; int rank_index; uint8_t* rank_tot_out;
+    // sites per block of the large-shard kernel instances (set by launch_sweep; 0: the kernel's block size)
+    int spb;
 };
 // argument blocks of the kernels whose launch wrappers take scalars (the batched launches need them as structs)
 struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const uint8_t* lab_old; uint64_t* mask; int* flags;

@@ -1,6 +1,13 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/r03z && mkdir -p $O
 Q="--no-north-star --no-cpu-baseline"
-timeout -k 10 900 python3 -m pytest tests/test_chain.py tests/test_gpu_golden.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py tests/test_gpu_dropin_fullsize.py -x -q -m gpu --timeout 400 > $O/tests.log 2>&1; rc=$?; echo tests rc=$rc; tail -4 $O/tests.log
-if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4prof -- python3 bench.py --families 200000 --organisms 5000 --steps 20 --warmup 4 --repeats 3 $Q > $O/c4p.json 2>/dev/null
-python3 profiles/dropin_logged.py > $O/dropin_logged.json 2>$O/dropin_logged.err; cat $O/dropin_logged.json | tr -d '\n' | cut -c1-1500; echo
+for r in 1 2 3; do
+python3 bench.py --families 200000 --organisms 5000 --steps 100 --warmup 10 --repeats 7 $Q > $O/c4_new_$r.json 2>/dev/null
+NEM_MI355X_SWEEP_SPB=0 python3 bench.py --families 200000 --organisms 5000 --steps 100 --warmup 10 --repeats 7 $Q > $O/c4_old_$r.json 2>/dev/null
+done
+python3 bench.py --families 100000 --organisms 1000 --steps 200 --warmup 20 --repeats 7 $Q > $O/c100_new.json 2>/dev/null
+NEM_MI355X_SWEEP_SPB=0 python3 bench.py --families 100000 --organisms 1000 --steps 200 --warmup 20 --repeats 7 $Q > $O/c100_old.json 2>/dev/null
+python3 - <<'PY'
+import json
+for f in ['c4_new_1','c4_old_1','c4_new_2','c4_old_2','c4_new_3','c4_old_3','c100_new','c100_old']:
+    d=json.load(open('gpurun_out/r03z/%s.json'%f)); print(f, round(d['ms_per_step'],5), round(d['ms_per_step_min'],5), [(k['kernel'],round(k['avg_launch_ms']*1e3,2)) for k in d['roofline']['kernels']])
+PY
