@@ -280,7 +280,7 @@ def rocprof_average_ms(kernel, n_loc, d):
     return None
 
 
-def roofline_block(kernels, n_loc, d):
+def roofline_block(kernels, n_loc, d, profiled_workload=True):
     """kernels: engine.profile_kernels() -- {E1, one relaxation round, M-step counts}, each timed live with HIP events
     around a string of back-to-back launches on the engine's stream (no event pair per launch).  The block's own fields
     are the dominant kernel's (E1, the longest launch of the iteration); `kernels` lists all three."""
@@ -289,8 +289,10 @@ def roofline_block(kernels, n_loc, d):
         ach = kr["algorithmic_bytes_per_launch"] / (kr["avg_launch_ms"] * 1e-3) / 1e9 if kr["avg_launch_ms"] > 0 else 0.0
         rows.append(dict(kernel=kr["kernel"], what=kr["what"], algorithmic_bytes_per_launch=kr["algorithmic_bytes_per_launch"],
                          avg_launch_ms=kr["avg_launch_ms"], launches_timed=kr["launches_timed"], achieved=ach, unit="GB/s",
-                         frac=ach / HBM_PEAK_GBS, rocprof_avg_launch_ms=rocprof_average_ms(kr["kernel"], n_loc, d),
-                         traffic=pmc_traffic(kr["kernel"], n_loc, d)))
+                         frac=ach / HBM_PEAK_GBS,
+                         # (the committed traces and counters are of the default model on the default data)
+                         rocprof_avg_launch_ms=rocprof_average_ms(kr["kernel"], n_loc, d) if profiled_workload else None,
+                         traffic=pmc_traffic(kr["kernel"], n_loc, d) if profiled_workload else None))
     e1 = rows[0]
     return {
         "bound": "hbm",
@@ -587,7 +589,8 @@ def main():
                 "cycle_iterations": extra["cycle_iterations"],
                 "parallelism": parallelism,
             },
-            "roofline": roofline_block(kernels, n_loc, d),
+            "roofline": roofline_block(kernels, n_loc, d, profiled_workload=(args.algo == "ncem" and args.disper == "sk_" and not ksweep
+                                                                              and args.spectrum == "ushape" and not multi)),
         }
         out["roofline"]["whole_iteration_algorithmic_GBps"] = whole_iteration_bytes(n_tot, d, k, nnz) * steps_total / med / 1e9
         out.update(extra)
