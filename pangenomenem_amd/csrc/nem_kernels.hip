@@ -1074,6 +1074,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         return;
     }
     __shared__ int s_nzero, s_first;
+    // "a label changed" / "a label moved": per block, then ONE device-scope atomic -- behind a device-scope look at the
+    // flag -- instead of one per wave behind a plain load (which another XCD's L2 answers with a stale 0 long after the
+    // flag was set: at 200 000 x 5 000, where every wave has something to report, a round's 3 136 same-address atomics
+    // were 10-40 us of its 24-52)
+    __shared__ int s_chg, s_mov;
     // NCEM: the MRF factor exp(beta * context) takes few distinct arguments -- the context of a class is a sum of edge
     // weights, small integers in PPanGGOLiN's graphs (numbers of organisms sharing an adjacency): the block fills a table
     // exp((double)beta * (double)(float)m), m = 0 .. kExpTab - 1, with the SAME device exp on the same argument the site
@@ -1095,7 +1100,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     // used -- behind the label store, which they might alias -- they would be one more memory latency at the tail
     int my_guess = 0, my_old = 0, my_new = 255;           // my_guess: the whole byte; my_old: the class
     if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi] & kLabMask; }
-    if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; }
+    if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; s_chg = 0; s_mov = 0; }
     if (NCEM) s_lab[threadIdx.x] = (uint8_t)my_guess;
     if (NCEM && a.use_nei && !skip && threadIdx.x < kExpTab) s_exp[threadIdx.x] = exp((double)a.beta * (double)(float)threadIdx.x);
     __syncthreads();
@@ -1294,7 +1299,22 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         }
     }
     }
-    if (__any(changed) && (threadIdx.x & 63) == 0 && a.flags[FLAG_CHANGED] == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
+    if (__any(changed) && (threadIdx.x & 63) == 0) s_chg = 1;
+    // the iteration's bookkeeping, when it rides in this round (see SweepArgs): the site's label, "moved"
+    int post_lab = 255;
+    if (NCEM && a.post_on) {
+        int moved = 0;
+        if (active) {
+            // (a round that skipped its sites and posts its own output reads that output back: not a case the
+            //  engine enqueues, the verification round posts its guess)
+            // (a round that skipped its sites -- a round before it changed nothing -- has no output of its own: the
+            //  partition is in the sweep's first buffer, the guess of odd rounds and the output of even ones)
+            if (skip) post_lab = (a.post_skip_guess ? my_guess : (int)a.lab_out[gi]) & kLabMask;
+            else post_lab = a.post_from_guess ? (my_guess & kLabMask) : (my_new != 255 ? my_new : ((int)a.lab_out[gi] & kLabMask));
+            if (a.post_moved) moved = (post_lab != my_old);
+        }
+        if (__any(moved) && (threadIdx.x & 63) == 0) s_mov = 1;
+    }
     // zero-density sites (nem_alg.c:2603-2613): count and first index, one pair of atomics per block
     const uint64_t zmask = __ballot(zero_density);
     if (zmask != 0ull && (threadIdx.x & 63) == 0) {
@@ -1311,25 +1331,19 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         if (!fold) atomicAdd(&a.flags[FLAG_NZERO], s_nzero);
         if (a.flags[FLAG_FIRSTZERO] < s_first) atomicMax(&a.flags[FLAG_FIRSTZERO], s_first);   // first site = n_total - max
     }
+    if (threadIdx.x == 0) {
+        if (s_chg && __hip_atomic_load(&a.flags[FLAG_CHANGED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&a.flags[FLAG_CHANGED], 1);
+        if (NCEM && a.post_on && s_mov && __hip_atomic_load(&a.post_flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            atomicOr(&a.post_flags[FLAG_MOVED], 1);
+    }
     if (NCEM && a.post_on) {                             // k_labels_post's work, see SweepArgs
-        int lab = 255, moved = 0;
-        if (active) {
-            // (a round that skipped its sites and posts its own output reads that output back: not a case the
-            //  engine enqueues, the verification round posts its guess)
-            // (a round that skipped its sites -- a round before it changed nothing -- has no output of its own: the
-            //  partition is in the sweep's first buffer, the guess of odd rounds and the output of even ones)
-            if (skip) lab = (a.post_skip_guess ? my_guess : (int)a.lab_out[gi]) & kLabMask;
-            else lab = a.post_from_guess ? (my_guess & kLabMask) : (my_new != 255 ? my_new : ((int)a.lab_out[gi] & kLabMask));
-            if (a.post_moved) moved = (lab != my_old);
-        }
         const int wave = i >> 6;
         if (wave < a.post_nw64 && !a.post_no_masks) {
             for (int k = 0; k < K; k++) {
-                const uint64_t m = __ballot(lab == k);
+                const uint64_t m = __ballot(post_lab == k);
                 if ((threadIdx.x & 63) == 0) a.post_mask[(size_t)k * a.post_nw64 + wave] = m;
             }
         }
-        if (__any(moved) && (threadIdx.x & 63) == 0 && a.post_flags[FLAG_MOVED] == 0) atomicOr(&a.post_flags[FLAG_MOVED], 1);
     }
     const bool post_ctrl = NCEM && a.post_on && a.post_ctrl.ctrl != nullptr;
     if (a.publish_byte != nullptr || post_ctrl || fold) {
@@ -1376,7 +1390,9 @@ __device__ __forceinline__ void labels_post_body(int n_local, int lo, int K, int
         }
         any_moved |= __any(moved);
     }
-    if (any_moved && lane == 0 && flags[FLAG_MOVED] == 0) atomicOr(&flags[FLAG_MOVED], 1);
+    // (one device-scope atomic per block at most, behind a device-scope look at the flag: see sweep_body)
+    const int blk_moved = __syncthreads_or(any_moved);
+    if (blk_moved && threadIdx.x == 0 && __hip_atomic_load(&flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[FLAG_MOVED], 1);
     if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, nblk)) ctrl_logic(ca);
 }
 
@@ -2907,7 +2923,10 @@ __device__ __forceinline__ void conv_fuzzy_body(size_t m, const float* __restric
         if (dif < 0) dif = -dif;
         bad = (dif >= thres);
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[FLAG_MOVED], 1);
+    // (one device-scope atomic per block at most, behind a device-scope look at the flag: a fuzzy partition moves
+    //  everywhere, and 938 same-address atomics were the whole of this launch's 4.7 us at 20 000 x 500)
+    const int blk_bad = __syncthreads_or(bad);
+    if (blk_bad && threadIdx.x == 0 && __hip_atomic_load(&flags[FLAG_MOVED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&flags[FLAG_MOVED], 1);
     if (ca.ctrl != nullptr && last_block_ticket(ca.ticket, nblk)) ctrl_logic(ca);
 }
 
