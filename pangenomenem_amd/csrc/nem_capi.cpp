@@ -10,6 +10,10 @@
 #include <cstring>
 #include <ctime>
 #include <future>
+#include <deque>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <unistd.h>
 #include <string>
@@ -249,54 +253,108 @@ int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, 
 // "Random initialization %d :", line 0 (the start's own parameters; NbObs_KD is whatever the run so far left there --
 // NaN from InitPara, :1270-1276, before the first start, then the sizes of the last EstimPara, which nothing resets),
 // WriteLogHeader and NemAlgo's line per iteration; "Best start was %d (U = %g)" at the end.
+// The text is put together and written by a helper thread, in order, while the device runs the next logged step (a
+// line is 9 000 numbers at configs[1] size, a run of 50 starts some 30 MB).
+struct LogJob {
+    enum Kind { TEXT, LINE, HEADER } kind = TEXT;
+    std::string text;                                                       // TEXT: as it is; LINE: what precedes the criteria
+    float cb[6], ca[6];
+    LogParams P;
+    bool blank_after = false;                                               // LINE: Needinit's empty line (:1985-1986)
+};
+class LogWriter {
+public:
+    LogWriter(FILE* fl, float mult, float beta, int k, int d) : fl_(fl), mult_(mult), beta_(beta), k_(k), d_(d), th_([this] { run(); }) {}
+    ~LogWriter() { finish(); }
+    void push(LogJob&& j) { { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(j)); } cv_.notify_one(); }
+    void finish()
+    {
+        if (!th_.joinable()) return;
+        { std::lock_guard<std::mutex> g(m_); done_ = true; }
+        cv_.notify_one();
+        th_.join();
+    }
+private:
+    void run()
+    {
+        std::string out;
+        for (;;) {
+            LogJob j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return done_ || !q_.empty(); });
+                if (q_.empty()) break;
+                j = std::move(q_.front());
+                q_.pop_front();
+            }
+            out.clear();
+            if (j.kind == LogJob::HEADER) { log_header(fl_, k_, d_); continue; }
+            out = j.text;
+            if (j.kind == LogJob::LINE) {
+                log_crit(out, j.cb, mult_); log_crit(out, j.ca, mult_);
+                log_classes(out, j.P, beta_, k_, d_, true);
+                if (j.blank_after) out += "\n";
+            }
+            fwrite(out.data(), 1, out.size(), fl_);
+        }
+    }
+    FILE* fl_; float mult_, beta_; int k_, d_;
+    std::mutex m_; std::condition_variable cv_; std::deque<LogJob> q_; bool done_ = false;
+    std::thread th_;
+};
+
 struct RandomLog {
-    FILE* fl; float mult; float beta; int k, d;
+    LogWriter* w; int k, d;
     std::vector<float> nk_left;                                              // NbObs_K as the run so far left it
-    std::string buf;
-    void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), fl); buf.clear(); } }
 };
 
 void random_log_event(const nemgpu_log_event* ev, void* user)
 {
     RandomLog& L = *static_cast<RandomLog*>(user);
     char t[96];
+    LogJob j;
     if (ev->kind == NEMGPU_LOG_START) {
-        L.flush();
-        fprintf(L.fl, "\nRandom initialization %d :\n", ev->start + 1);
-        fprintf(L.fl, "%4d ", 0);
+        snprintf(t, sizeof t, "\nRandom initialization %d :\n%4d ", ev->start + 1, 0);
+        j.text = t;
+        L.w->push(std::move(j));
         return;
     }
     if (ev->kind == NEMGPU_LOG_EMPTY) {
         snprintf(t, sizeof t, "%4d  Class %d empty at iteration %d\n", ev->iter, ev->emptyk, ev->iter);     // :1798, :1835-1837
-        L.buf += t;
+        j.text = t;
+        L.w->push(std::move(j));
         L.nk_left.assign(ev->nbobs_k, ev->nbobs_k + L.k);
         return;
     }
     const size_t kd = (size_t)L.k * L.d;
-    LogParams P{std::vector<float>(ev->prop, ev->prop + L.k), std::vector<float>(ev->center, ev->center + kd),
-                std::vector<float>(ev->disp, ev->disp + kd), L.nk_left};
+    j.kind = LogJob::LINE;
+    j.P = LogParams{std::vector<float>(ev->prop, ev->prop + L.k), std::vector<float>(ev->center, ev->center + kd),
+                    std::vector<float>(ev->disp, ev->disp + kd), L.nk_left};
+    memcpy(j.cb, ev->crit_before, sizeof j.cb); memcpy(j.ca, ev->crit_after, sizeof j.ca);
     if (ev->iter > 0) {
-        P.nk.assign(ev->nbobs_k, ev->nbobs_k + L.k);
-        L.nk_left = P.nk;
+        j.P.nk.assign(ev->nbobs_k, ev->nbobs_k + L.k);
+        L.nk_left = j.P.nk;
         snprintf(t, sizeof t, "%4d ", ev->iter);
-        L.buf += t;
+        j.text = t;
     }
-    log_crit(L.buf, ev->crit_before, L.mult); log_crit(L.buf, ev->crit_after, L.mult);
-    log_classes(L.buf, P, L.beta, L.k, L.d, true);
-    if (ev->iter == 0) {                                                     // Needinit, :1985-1986; NemAlgo's header, :1783
-        L.buf += "\n";
-        L.flush();
-        log_header(L.fl, L.k, L.d);
-    } else if (L.buf.size() > (1u << 20)) L.flush();
+    j.blank_after = ev->iter == 0;                                           // Needinit, :1985-1986
+    L.w->push(std::move(j));
+    if (ev->iter == 0) { LogJob h; h.kind = LogJob::HEADER; L.w->push(std::move(h)); }   // NemAlgo's header, :1783
 }
 
 int run_random_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res, int* best)
 {
-    RandomLog L{fl, log_mult(n), cfg.beta, k, d, std::vector<float>((size_t)k, std::nanf("")), std::string()};
+    const float mult = log_mult(n);
     fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
-    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)L.mult);
-    const int rc = nemgpu_run_random_logged(e, 50, cfg.tie_seed, res, best, random_log_event, &L);
-    L.flush();
+    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)mult);
+    fflush(fl);
+    int rc;
+    {
+        LogWriter w(fl, mult, cfg.beta, k, d);
+        RandomLog L{&w, k, d, std::vector<float>((size_t)k, std::nanf(""))};
+        rc = nemgpu_run_random_logged(e, 50, cfg.tie_seed, res, best, random_log_event, &L);
+        w.finish();
+    }
     if (rc == NEMGPU_OK && *best >= 0) fprintf(fl, "Best start was %d (U = %g)\n", *best + 1, (double)res->crit[3]);
     return rc;
 }
