@@ -2909,15 +2909,31 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
         if ((r = iterate_many(E, L))) return r;
         for (int j = 0; j < M; j++)
             if (E[j]->iters == 0) { if ((r = do_mstep(E[j])) || (r = do_tables(E[j])) || (r = do_density(E[j]))) return r; }
+        std::vector<float> crits((size_t)M * 6);
+        bool staged = false;
         {
             std::vector<Recorder> recs((size_t)M);
             std::vector<int> all((size_t)M);
             for (int j = 0; j < M; j++) all[j] = j;
-            if ((r = lockstep(E, all, recs, [&](int m) { return criteria_enqueue(E[m], -1); }, false))) return r;
+            // (the starts' criteria to the batch's staging area behind the zipped criteria launches, ONE copy to the host:
+            //  see run_many)
+            nemgpu_engine::ZipContext* z = zip_context(E[0]);
+            staged = z != nullptr && z->zip_flags_dev != nullptr && z->zip_flags_host != nullptr && z->zip_flags_cap >= (size_t)8 * M;
+            if ((r = lockstep(E, all, recs, [&](int m) {
+                    const int rr = criteria_enqueue(E[m], -1);
+                    if (rr == NEMGPU_OK && staged) launch_copy_words(reinterpret_cast<const int*>(E[m]->crit6_dev), z->zip_flags_dev + (size_t)8 * m, 6, E[0]->stream);
+                    return rr;
+                }, false))) return r;
+            if (staged) {
+                HIPCHK(hipMemcpyAsync(z->zip_flags_host, z->zip_flags_dev, (size_t)8 * M * sizeof(int), hipMemcpyDeviceToHost, E[0]->stream));
+                HIPCHK(hipStreamSynchronize(E[0]->stream));
+                for (int j = 0; j < M; j++) memcpy(crits.data() + (size_t)j * 6, z->zip_flags_host + (size_t)8 * j, 6 * sizeof(float));
+            }
         }
-        std::vector<float> crits((size_t)M * 6);
-        for (int j = 0; j < M; j++)
-            HIPCHK(hipMemcpyAsync(crits.data() + (size_t)j * 6, E[j]->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        if (!staged) {
+            for (int j = 0; j < M; j++)
+                HIPCHK(hipMemcpyAsync(crits.data() + (size_t)j * 6, E[j]->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        }
         HIPCHK(hipStreamSynchronize(e->stream));
         // the starts of this round that stand: all of them, or (TIE_LIBC) up to the first one whose sweeps drew
         int valid = M;
