@@ -187,6 +187,8 @@ struct nemgpu_engine {
     bool fault_seen = false; int fault_inject = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
+    hipEvent_t ready_ev = nullptr;             // nemgpu_solve_many: recorded behind the engine's uploads on its builder's stream,
+    bool ready_pending = false;                // which carries other engines' uploads too -- a run waits for the event, not the stream
 
     // Device memory comes from a few large zeroed chunks (one hipMalloc + one fill each) that buffers are carved
     // from and that live as long as the engine: a nem() call creates and destroys an engine, and ~50 hipMalloc /
@@ -273,6 +275,7 @@ size_t pool_round(size_t bytes)
     const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : ((size_t)64 << 10);
     return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
 }
+static std::atomic<long long> g_pool_miss[2], g_pool_spill[2];   // NEM_MI355X_BATCH_PROF: blocks allocated / freed for real (device, pinned)
 // a block of at least `bytes` (at most a quarter more) from the pool, else a new one; *got = its real size
 hipError_t pool_get(int device, bool pinned, size_t bytes, char** out, size_t* got)
 {
@@ -290,6 +293,7 @@ hipError_t pool_get(int device, bool pinned, size_t bytes, char** out, size_t* g
         }
     }
     *got = want;
+    g_pool_miss[pinned ? 1 : 0]++;
     hipError_t err = pinned ? hipHostMalloc((void**)out, want) : hipMalloc((void**)out, want);
     if (err != hipSuccess) {                             // out of memory with blocks idle in the pool: give them back
         (void)hipGetLastError();
@@ -311,7 +315,29 @@ void pool_put(int device, bool pinned, char* ptr, size_t size)
             return;
         }
     }
+    g_pool_spill[pinned ? 1 : 0]++;
     if (pinned) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+}
+// an engine's blocks in one visit to the pool (a destroyed engine gives back about ten: with 8-16 threads destroying
+// the members of a finished group at once, a lock per block was 0.1-0.25 ms per engine in lock hand-overs)
+struct PoolBlock { bool pinned; char* ptr; size_t size; };
+void pool_put_many(int device, std::vector<PoolBlock>& blocks)
+{
+    std::vector<PoolBlock> spill;
+    if (device >= 0 && device < kPoolDevices) {
+        ResourcePool& P = g_pools[device];
+        std::lock_guard<std::mutex> lock(P.m);
+        for (const PoolBlock& b : blocks) {
+            if (!b.ptr) continue;
+            size_t& held = b.pinned ? P.pinned_bytes : P.dev_bytes;
+            if (b.size > 0 && held + b.size <= (b.pinned ? kPoolPinnedBytes : pool_dev_cap())) {
+                (b.pinned ? P.pinned : P.dev).emplace(b.size, b.ptr);
+                held += b.size;
+            } else spill.push_back(b);
+        }
+    } else spill = blocks;
+    for (const PoolBlock& b : spill) if (b.ptr) { g_pool_spill[b.pinned ? 1 : 0]++; if (b.pinned) (void)hipHostFree(b.ptr); else (void)hipFree(b.ptr); }
+    blocks.clear();
 }
 void release_staging(nemgpu_engine* e);
 void zip_context_release(nemgpu_engine* lead);
@@ -1509,7 +1535,33 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
 
 // several whole runs (nemgpu_run) in lock step; every engine complete (matrix, graph, parameters, configuration), all on
 // one device.  They are run on E[0]'s stream for the duration.
-int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
+// A group's results in one block (nemgpu_solve_many): every member's partition and parameter block (the layout of
+// nemgpu_get_results' staging block) are copied by zipped launches behind the criteria into `dev`, `stride` bytes apart,
+// and reach `host` (pinned) in ONE copy before run_many returns.  Per-member copies from the workers' threads cost
+// 0.2-0.7 ms each once 8-16 threads were inside the runtime together.
+struct GroupFetch { char* dev = nullptr; char* host = nullptr; size_t stride = 0; bool filled = false; };
+static size_t result_part_bytes(const nemgpu_engine* e) { return e->ncem() ? ((size_t)e->n + 3) & ~(size_t)3 : sizeof(float) * (size_t)e->n * e->k; }
+static size_t result_block_bytes(const nemgpu_engine* e) { return result_part_bytes(e) + sizeof(float) * e->par_words; }
+
+// a staging block [partition (b_part bytes) | prop | center | disp | nbobs_k] into the caller's arrays
+static void result_unpack(const nemgpu_engine* e, const char* st, size_t b_part, float* prop, float* center, float* disp, float* nbobs_k, float* c_nk)
+{
+    const size_t kd = (size_t)e->k * e->d, n = (size_t)e->n, k = (size_t)e->k;
+    const char* par = st + b_part;
+    if (c_nk) {
+        if (e->ncem()) {
+            const uint8_t* lab = (const uint8_t*)st;
+            for (size_t i = 0; i < n; i++)                          // LabelToClassVector, nem_alg.c:649-664
+                for (size_t h = 0; h < k; h++) c_nk[i * k + h] = ((size_t)(lab[i] & 0x7F) == h) ? 1.0f : 0.0f;
+        } else memcpy(c_nk, st, sizeof(float) * n * k);
+    }
+    if (prop) memcpy(prop, par, sizeof(float) * k);
+    if (center) memcpy(center, par + sizeof(float) * e->par_o_center, sizeof(float) * kd);
+    if (disp) memcpy(disp, par + sizeof(float) * e->par_o_disp, sizeof(float) * kd);
+    if (nbobs_k) memcpy(nbobs_k, par + sizeof(float) * e->par_o_nb, sizeof(float) * k);
+}
+
+int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results, GroupFetch* gf = nullptr)
 {
     int r;
     const int B = (int)E.size();
@@ -1532,8 +1584,15 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
         }
         ~StreamLoan() { give_back(); }
     } loan(E, lead);
+    static const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    double laps[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int j) { auto t1 = std::chrono::steady_clock::now(); laps[j] += std::chrono::duration<double>(t1 - tp).count() * 1e6; tp = t1; };
     for (int i = 0; i < B; i++) {
-        HIPCHK(hipStreamSynchronize(E[i]->stream));            // (an early return gives back what was taken so far)
+        if (E[i]->ready_pending) {                             // (built by nemgpu_solve_many: see ready_ev)
+            HIPCHK(hipStreamWaitEvent(lead->stream, E[i]->ready_ev, 0));
+            E[i]->ready_pending = false;
+        } else HIPCHK(hipStreamSynchronize(E[i]->stream));     // (an early return gives back what was taken so far)
         loan.own[i] = E[i]->stream;
         E[i]->stream = lead->stream;
         loan.taken = i + 1;
@@ -1546,17 +1605,21 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
             return NEMGPU_OK;
         }
     }
+    lap(0);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<LoopCursor> L((size_t)B);
     r = NEMGPU_OK;
     for (int i = 0; i < B && r == NEMGPU_OK; i++) { E[i]->draws = 0; r = loop_begin(E[i], L[i], E[i]->cfg.it_max, true); }
+    lap(1);
     if (r == NEMGPU_OK) r = iterate_many(E, L);
+    lap(2);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < B && r == NEMGPU_OK; i++) {
         if (E[i]->iters == 0) {                                    // nem_alg.c:1845-1851
             if ((r = do_mstep(E[i])) || (r = do_tables(E[i])) || (r = do_density(E[i]))) break;
         }
     }
+    lap(3);
     if (r == NEMGPU_OK && results != nullptr) {
         std::vector<Recorder> recs((size_t)B);
         std::vector<int> all((size_t)B);
@@ -1569,8 +1632,21 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
         r = lockstep(E, all, recs, [&](int m) {
             const int rr = criteria_enqueue(E[m], -1);
             if (rr == NEMGPU_OK && staged) launch_copy_words(reinterpret_cast<const int*>(E[m]->crit6_dev), z->zip_flags_dev + (size_t)8 * m, 6, lead->stream);
+            if (rr == NEMGPU_OK && gf != nullptr) {
+                nemgpu_engine* e = E[m];
+                char* dst = gf->dev + gf->stride * (size_t)m;
+                const size_t b_part = result_part_bytes(e);
+                const void* part = e->ncem() ? (const void*)(e->lab[e->cur] + e->lo) : (const void*)(e->cbuf[e->cur] + (size_t)e->lo * e->k);
+                launch_copy_words(reinterpret_cast<const int*>(part), reinterpret_cast<int*>(dst), (int)(b_part / 4), lead->stream);
+                launch_copy_words(reinterpret_cast<const int*>(e->prop), reinterpret_cast<int*>(dst + b_part), (int)e->par_words, lead->stream);
+            }
             return rr;
         }, false);
+        if (r == NEMGPU_OK && gf != nullptr) {
+            if (hipMemcpyAsync(gf->host, gf->dev, gf->stride * (size_t)B, hipMemcpyDeviceToHost, lead->stream) != hipSuccess) {
+                set_error("results copy failed"); r = NEMGPU_E_DEVICE;
+            } else gf->filled = true;                              // (once the wait below is over)
+        }
         if (r == NEMGPU_OK && staged &&
             hipMemcpyAsync(z->zip_flags_host, z->zip_flags_dev, (size_t)8 * B * sizeof(int), hipMemcpyDeviceToHost, lead->stream) != hipSuccess) {
             set_error("criteria copy failed"); r = NEMGPU_E_DEVICE;
@@ -1586,7 +1662,11 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results)
         if (r == NEMGPU_OK && staged)
             for (int i = 0; i < B; i++) memcpy(results[i].crit, z->zip_flags_host + (size_t)8 * i, 6 * sizeof(float));
     }
+    lap(4);
     restore();
+    lap(5);
+    if (prof) fprintf(stderr, "[run_many] %d members: waits for the uploads %.0f us, loop_begin %.0f, iterations %.0f, it_max 0 %.0f, criteria + results %.0f, streams back %.0f\n",
+                      B, laps[0], laps[1], laps[2], laps[3], laps[4], laps[5]);
     return r;
 }
 
@@ -1879,29 +1959,41 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
 
 void rccl_release(nemgpu_engine* e);
 
+static std::atomic<long long> g_destroy_ns[5];               // NEM_MI355X_BATCH_PROF: where nemgpu_destroy's time goes
 void nemgpu_destroy(nemgpu_engine* e)
 {
     if (!e) return;
     for (nemgpu_engine* c : e->clones) nemgpu_destroy(c);
     e->clones.clear();
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int j) { auto t1 = std::chrono::steady_clock::now(); g_destroy_ns[j] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(); t0 = t1; };
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    pool_put(e->device, false, e->clone_slab, e->clone_slab_size);
-    pool_put(e->device, true, (char*)e->clone_flags_host, e->clone_flags_size);
+    lap(0);
+    std::vector<PoolBlock> blocks;
+    blocks.push_back({false, e->clone_slab, e->clone_slab_size});
+    blocks.push_back({true, (char*)e->clone_flags_host, e->clone_flags_size});
     e->clone_slab = nullptr; e->clone_flags_host = nullptr;
     rccl_release(e);
     drop_graphs(e);
     if (g_alloc_engine == e) g_alloc_engine = nullptr;
+    lap(1);
     // (the stream is idle: everything the engine held goes back to the device's pool for the next engines)
-    release_staging(e);
-    if (e->host_bits_pin) pool_put(e->device, true, (char*)e->host_bits, e->host_bits_pin);
-    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.owned) pool_put(e->device, false, c.base, c.size);
+    for (const nemgpu_engine::Staged& st : e->staging) blocks.push_back({true, st.p, st.size});
+    e->staging.clear();
+    if (e->host_bits_pin) blocks.push_back({true, (char*)e->host_bits, e->host_bits_pin});
+    for (const nemgpu_engine::Chunk& c : e->chunks) if (c.owned) blocks.push_back({false, c.base, c.size});
+    if (e->flags_host && !e->flags_host_borrowed) blocks.push_back({true, (char*)e->flags_host, e->flags_host_size});
+    pool_put_many(e->device, blocks);
     zip_context_release(e);
-    if (e->flags_host && !e->flags_host_borrowed) pool_put(e->device, true, (char*)e->flags_host, e->flags_host_size);
     if (e->own_stream && e->stream) pool_stream_put(e->device, e->stream);
+    lap(2);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ready_ev) (void)hipEventDestroy(e->ready_ev);
+    lap(3);
     delete e;
+    lap(4);
 }
 
 void nemgpu_release_cached(void)
@@ -2374,6 +2466,9 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     std::mutex m;
     std::condition_variable cv;
     std::deque<int> fetchq;
+    struct GroupSlab { char* host = nullptr; size_t size = 0, stride = 0; int left = 0; };
+    std::vector<GroupSlab> gslab((size_t)G);                     // a group's results on the host (GroupFetch), until its last fetch
+    std::vector<int> gslot((size_t)count, -1);
     int build_next = 0, build_limit = std::min(count, 2 * group), fetched = 0;
     bool quit = false;
 
@@ -2381,20 +2476,40 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     // worker's stream, the lock-step runs have one of their own, so that a group's run and the next groups' uploads
     // are not ordered behind each other.
     std::vector<hipStream_t> wstream((size_t)workers, nullptr);
-    hipStream_t rstream = nullptr;
+    hipStream_t rstream = nullptr, fstream = nullptr;
     (void)hipSetDevice(device);
     if (pool_stream_get(device, &rstream) != hipSuccess) { set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+    if (pool_stream_get(device, &fstream) != hipSuccess) { (void)hipGetLastError(); fstream = nullptr; }
+    const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
+    double slow_build[6] = {0, 0, 0, 0, 0, 0}, slow_fetch[3] = {0, 0, 0};      // (profile: the slowest build / fetch, by stage)
+    std::mutex pm;
     auto build = [&](int i, hipStream_t st) {
         nemgpu_problem& q = P[i];
         nemgpu_engine* e = nullptr;
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        auto t0 = now();
         int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, st);
+        t[1] = since(t0);
         if (r == NEMGPU_OK) r = q.x_bits ? nemgpu_set_matrix_bits(e, q.x_bits) : nemgpu_set_matrix_bytes(e, q.x_bytes);
+        t[2] = since(t0);
         if (r == NEMGPU_OK) {
             if (q.nei_ptr) r = nemgpu_set_graph(e, q.nei_ptr, q.nei_idx, q.nei_w);
             else { std::vector<int32_t> z((size_t)q.n + 1, 0); r = nemgpu_set_graph(e, z.data(), nullptr, nullptr); }
         }
+        t[3] = since(t0);
         if (r == NEMGPU_OK) r = nemgpu_set_params(e, q.prop, q.center, q.disp);
         if (r == NEMGPU_OK) r = nemgpu_configure(e, cfg);
+        t[4] = since(t0);
+        if (r == NEMGPU_OK && st != nullptr) {
+            // the builder's stream goes on to other engines' uploads: the run waits for THIS engine's, by event
+            if (hipEventCreateWithFlags(&e->ready_ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(e->ready_ev, st) == hipSuccess)
+                e->ready_pending = true;
+            else (void)hipGetLastError();                          // (no event: the run waits for the stream, as before)
+        }
+        t[5] = since(t0);
+        if (prof) { std::lock_guard<std::mutex> lock(pm); if (t[5] > slow_build[5]) for (int j = 1; j < 6; j++) slow_build[j] = t[j]; slow_build[0] += t[5]; }
         if (r != NEMGPU_OK) { errs[(size_t)i] = g_last_error; if (e) nemgpu_destroy(e); e = nullptr; }
         q.rc = r;
         eng[(size_t)i] = e;
@@ -2403,11 +2518,23 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
         nemgpu_problem& q = P[i];
         nemgpu_engine* e = eng[(size_t)i];
         if (!e) return;
+        auto t0 = now();
+        // (its run is over and was waited for: whatever it still copies goes to the fetch stream, not behind the uploads
+        // its builder's stream has taken in the meantime)
+        if (!e->own_stream && fstream != nullptr) e->stream = fstream;
+        GroupSlab& gs = gslab[(size_t)(i / group)];
         if (q.rc == NEMGPU_OK && (q.out_prop || q.out_center || q.out_disp || q.out_nbobs_k || q.out_c)) {
-            q.rc = nemgpu_get_results(e, q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c);
-            if (q.rc != NEMGPU_OK) errs[(size_t)i] = g_last_error;
+            if (gs.host != nullptr && gslot[(size_t)i] >= 0)
+                result_unpack(e, gs.host + gs.stride * (size_t)gslot[(size_t)i], result_part_bytes(e), q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c);
+            else {
+                q.rc = nemgpu_get_results(e, q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c);
+                if (q.rc != NEMGPU_OK) errs[(size_t)i] = g_last_error;
+            }
         }
+        const double t1 = since(t0);
         nemgpu_destroy(e);
+        const double t2 = since(t0);
+        if (prof) { std::lock_guard<std::mutex> lock(pm); if (t2 > slow_fetch[2]) { slow_fetch[1] = t1; slow_fetch[2] = t2; } slow_fetch[0] += t2; }
         eng[(size_t)i] = nullptr;
     };
     auto worker = [&](int w) {
@@ -2419,6 +2546,8 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
             if (!fetchq.empty()) {                                 // results first: they free engines for the builders
                 const int i = fetchq.front(); fetchq.pop_front();
                 lock.unlock(); fetch(i); lock.lock();
+                GroupSlab& gs = gslab[(size_t)(i / group)];
+                if (gs.host != nullptr && --gs.left == 0) { pool_put(device, true, gs.host, gs.size); gs.host = nullptr; }
                 fetched++;
                 cv.notify_all();
             } else if (build_next < build_limit) {
@@ -2433,10 +2562,7 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     for (int t = 0; t < workers; t++) pool.emplace_back(worker, t);
     int rc = NEMGPU_OK;
     std::string first_err;
-    const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
     double t_wait = 0, t_run = 0, t_tail = 0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
     for (int g = 0; g < G; g++) {
         const int i0 = g * group, i1 = std::min(count, i0 + group);
         {
@@ -2454,11 +2580,30 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
             const auto t0 = now();
             // (the lead's own stream is a worker's: what it still has to upload is waited for, then the run moves)
             hipStream_t lead_own = E[0]->stream;
-            int r = hipStreamSynchronize(lead_own) == hipSuccess ? NEMGPU_OK : NEMGPU_E_DEVICE;
+            int r = E[0]->ready_pending || hipStreamSynchronize(lead_own) == hipSuccess ? NEMGPU_OK : NEMGPU_E_DEVICE;
             if (r == NEMGPU_OK) {
                 if (!E[0]->own_stream) E[0]->stream = rstream;
-                r = run_many(E, R.data());
+                // the group's partitions and parameters come back with the run, in one block
+                GroupFetch gf;
+                size_t dev_size = 0, host_size = 0;
+                for (nemgpu_engine* e : E) gf.stride = std::max(gf.stride, (result_block_bytes(e) + 63) & ~(size_t)63);
+                const size_t total = gf.stride * E.size();
+                bool want = false;
+                for (int i : who) want = want || P[i].out_prop || P[i].out_center || P[i].out_disp || P[i].out_nbobs_k || P[i].out_c;
+                if (want && total <= kStageMax) {
+                    if (pool_get(device, false, total, &gf.dev, &dev_size) != hipSuccess) { (void)hipGetLastError(); gf.dev = nullptr; }
+                    if (gf.dev && pool_get(device, true, total, &gf.host, &host_size) != hipSuccess) { (void)hipGetLastError(); gf.host = nullptr; }
+                }
+                const bool grouped = gf.dev != nullptr && gf.host != nullptr;
+                r = run_many(E, R.data(), grouped ? &gf : nullptr);
                 if (!E[0]->own_stream) { (void)hipStreamSynchronize(rstream); E[0]->stream = lead_own; }
+                if (gf.dev) pool_put(device, false, gf.dev, dev_size);
+                if (grouped && r == NEMGPU_OK && gf.filled) {
+                    std::lock_guard<std::mutex> lock(m);
+                    GroupSlab& gs = gslab[(size_t)g];
+                    gs.host = gf.host; gs.size = host_size; gs.stride = gf.stride; gs.left = (int)E.size();
+                    for (size_t j = 0; j < E.size(); j++) gslot[(size_t)who[j]] = (int)j;
+                } else if (gf.host) pool_put(device, true, gf.host, host_size);
             }
             t_run += since(t0);
             for (size_t j = 0; j < E.size(); j++) { P[who[j]].result = R[j]; if (r != NEMGPU_OK) P[who[j]].rc = r; }
@@ -2481,14 +2626,29 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
         quit = true;
         t_tail = since(t0);
     }
+    if (prof) {
+        fprintf(stderr, "[destroy] stream wait %.2f ms, graphs %.2f, pool %.2f, events %.2f, delete %.2f (all engines so far)\n", g_destroy_ns[0] * 1e-6,
+                g_destroy_ns[1] * 1e-6, g_destroy_ns[2] * 1e-6, g_destroy_ns[3] * 1e-6, g_destroy_ns[4] * 1e-6);
+        for (auto& a : g_destroy_ns) a = 0;
+        fprintf(stderr, "[pool] idle: device %.0f MB, pinned %.0f MB; since the last report: allocated %lld device / %lld pinned blocks, freed %lld / %lld\n",
+                g_pools[device].dev_bytes / 1048576.0, g_pools[device].pinned_bytes / 1048576.0, (long long)g_pool_miss[0], (long long)g_pool_miss[1],
+                (long long)g_pool_spill[0], (long long)g_pool_spill[1]);
+        for (int j = 0; j < 2; j++) { g_pool_miss[j] = 0; g_pool_spill[j] = 0; }
+    }
     if (prof)
         fprintf(stderr, "[solve_many] %d problems, %d workers, groups of %d: waited for builds %.2f ms, lock-step runs %.2f ms, "
-                        "waited for the last results %.2f ms\n", count, workers, group, t_wait * 1e3, t_run * 1e3, t_tail * 1e3);
+                        "waited for the last results %.2f ms\n"
+                        "             builds %.2f ms in all, the slowest: create %.0f us, matrix %.0f, graph %.0f, parameters %.0f, event %.0f; "
+                        "fetches %.2f ms in all, the slowest: results %.0f us, destroy %.0f\n",
+                count, workers, group, t_wait * 1e3, t_run * 1e3, t_tail * 1e3, slow_build[0] * 1e3, slow_build[1] * 1e6,
+                (slow_build[2] - slow_build[1]) * 1e6, (slow_build[3] - slow_build[2]) * 1e6, (slow_build[4] - slow_build[3]) * 1e6,
+                (slow_build[5] - slow_build[4]) * 1e6, slow_fetch[0] * 1e3, slow_fetch[1] * 1e6, (slow_fetch[2] - slow_fetch[1]) * 1e6);
     cv.notify_all();
     for (std::thread& t : pool) t.join();
     for (hipStream_t st : wstream) if (st) { (void)hipStreamSynchronize(st); pool_stream_put(device, st); }
     (void)hipStreamSynchronize(rstream);
     pool_stream_put(device, rstream);
+    if (fstream) { (void)hipStreamSynchronize(fstream); pool_stream_put(device, fstream); }
     for (int i = 0; i < count; i++)
         if (P[i].rc != NEMGPU_OK && rc == NEMGPU_OK) { rc = P[i].rc; first_err = errs[(size_t)i]; }
     if (rc != NEMGPU_OK && !first_err.empty()) set_error(first_err);
@@ -3796,14 +3956,13 @@ int nemgpu_get_results(nemgpu_engine* e, float* prop, float* center, float* disp
     if (!e) return NEMGPU_E_FUNCARG;
     HIPCHK(hipSetDevice(e->device));
     { const int fr = flush_reset(e); if (fr) return fr; }
-    const size_t kd = (size_t)e->k * e->d, n = (size_t)e->n, k = (size_t)e->k;
+    const size_t n = (size_t)e->n, k = (size_t)e->k;
     if (c_nk) {
         if (e->ncem() ? !e->lab[e->cur] : !e->cbuf[e->cur]) { set_error("no partition yet"); return NEMGPU_E_FUNCARG; }
     }
     const size_t b_part = c_nk ? (e->ncem() ? (n + 3) & ~(size_t)3 : sizeof(float) * n * k) : 0;
     const bool want_par = prop || center || disp || nbobs_k;
-    const size_t o_prop = b_part, o_center = o_prop + sizeof(float) * e->par_o_center, o_disp = o_prop + sizeof(float) * e->par_o_disp,
-                 o_nb = o_prop + sizeof(float) * e->par_o_nb, total = o_prop + (want_par ? sizeof(float) * e->par_words : 0);
+    const size_t o_prop = b_part, total = o_prop + (want_par ? sizeof(float) * e->par_words : 0);
     char* st = nullptr; size_t got = 0;
     std::vector<char> own;
     const bool pinned = total <= kStageMax && pool_get(e->device, true, total, &st, &got) == hipSuccess;
@@ -3818,19 +3977,7 @@ int nemgpu_get_results(nemgpu_engine* e, float* prop, float* center, float* disp
     }
     if (want_par) D2H(o_prop, e->prop, sizeof(float) * e->par_words);   // prop | center | disp | nbobs_k: one block
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    if (err == hipSuccess) {
-        if (c_nk) {
-            if (e->ncem()) {
-                const uint8_t* lab = (const uint8_t*)st;
-                for (size_t i = 0; i < n; i++)                      // LabelToClassVector, nem_alg.c:649-664
-                    for (size_t h = 0; h < k; h++) c_nk[i * k + h] = ((size_t)(lab[i] & 0x7F) == h) ? 1.0f : 0.0f;
-            } else memcpy(c_nk, st, sizeof(float) * n * k);
-        }
-        if (prop) memcpy(prop, st + o_prop, sizeof(float) * k);
-        if (center) memcpy(center, st + o_center, sizeof(float) * kd);
-        if (disp) memcpy(disp, st + o_disp, sizeof(float) * kd);
-        if (nbobs_k) memcpy(nbobs_k, st + o_nb, sizeof(float) * k);
-    }
+    if (err == hipSuccess) result_unpack(e, st, b_part, prop, center, disp, nbobs_k, c_nk);
     if (pinned) pool_put(e->device, true, st, got);
     HIPCHK(err);
     return NEMGPU_OK;

@@ -230,3 +230,19 @@ def test_solve_many_over_a_device_list_equals_one_device(gpu_lib):
     from pangenomenem_amd.engine import NemGpuError
     with pytest.raises(NemGpuError, match="device"):
         solve_many(probs[:2], devices=[0, 99], **cfg)
+
+
+def test_solve_many_fuzzy_memberships_come_back_with_the_group(gpu_lib):
+    """NEM (fuzzy) problems of different shapes in one group: the memberships (n x k floats per member) and the parameter
+    blocks reach the host in the group's one copy -- every member's are its own solve()'s."""
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import solve
+    probs = _problems(7, n=2500, d=90)
+    probs[2] = (probs[2][0], None) + probs[2][2:]
+    cfg = dict(algo="nem", beta=0.5, disper="sk_")
+    want = [solve(*p, **cfg) for p in probs]
+    for batch in (solve_many(probs, workers=4, group=4, **cfg), solve_many(probs, workers=2, group=7, **cfg)):
+        for got, w in zip(batch, want):
+            assert got["iters"] == w["iters"] and got["status"] == w["status"]
+            for f in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+                assert np.array_equal(got[f], w[f]), f
