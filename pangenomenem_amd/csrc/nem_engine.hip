@@ -187,6 +187,7 @@ struct nemgpu_engine {
     bool fault_seen = false; int fault_inject = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
+    bool defer_layout = false, layout_pending = false;   // nemgpu_solve_many: the device layouts are made by the group's run (zipped)
     hipEvent_t ready_ev = nullptr;             // nemgpu_solve_many: recorded behind the engine's uploads on its builder's stream,
     bool ready_pending = false;                // which carries other engines' uploads too -- a run waits for the event, not the stream
 
@@ -255,6 +256,7 @@ void alloc_for(nemgpu_engine* e) { g_alloc_engine = e; g_alloc_stream = e->strea
 struct ResourcePool {
     std::mutex m;
     std::vector<hipStream_t> streams;
+    std::vector<hipStream_t> run_streams;                   // highest priority (nemgpu_solve_many's lock-step runs)
     std::multimap<size_t, char*> dev, pinned;
     size_t dev_bytes = 0, pinned_bytes = 0;
     std::vector<nemgpu_engine::ZipContext*> zips;           // lock-step contexts (slabs + captured graphs), most recent last
@@ -357,6 +359,30 @@ void pool_stream_put(int device, hipStream_t s)             // (idle)
     if (device >= 0 && device < kPoolDevices) {
         std::lock_guard<std::mutex> lock(g_pools[device].m);
         if (g_pools[device].streams.size() < kPoolStreams) { g_pools[device].streams.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+// The stream of nemgpu_solve_many's lock-step runs: of the highest priority the device offers.  A run is a chain of ~45
+// dependent launches; on a plain stream every one of them queued behind whatever the builders' streams had in flight
+// (16 MB fills, layout kernels, uploads) and a group took 2-2.4 ms next to the builders against 0.9 ms alone.
+hipError_t pool_run_stream_get(int device, hipStream_t* out)
+{
+    *out = nullptr;
+    if (device >= 0 && device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[device].m);
+        auto& v = g_pools[device].run_streams;
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+}
+void pool_run_stream_put(int device, hipStream_t s)         // (idle)
+{
+    if (!s) return;
+    if (device >= 0 && device < kPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_pools[device].m);
+        if (g_pools[device].run_streams.size() < 16) { g_pools[device].run_streams.push_back(s); return; }
     }
     (void)hipStreamDestroy(s);
 }
@@ -1500,6 +1526,15 @@ int lockstep(std::vector<nemgpu_engine*>& E, const std::vector<int>& members, st
 }
 
 // the EM loops of several engines in lock step (all on E[0]'s stream); L: their cursors after loop_begin
+// a member whose matrix was uploaded by nemgpu_solve_many's builders: its device layouts ride at the head of the group's
+// first step (recorded: one launch each for all members)
+static void pending_layout(nemgpu_engine* e)
+{
+    if (!e->layout_pending) return;
+    launch_layout(e->xf_stage, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->perm, e->xws, e->stream);
+    e->layout_pending = false;
+}
+
 int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
 {
     int r;
@@ -1511,7 +1546,7 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
     for (int i = 0; i < B; i++) if (L[i].first && E[i]->libc()) members.push_back(i);
     if (!members.empty()) {
         std::vector<SweepCtx> ctx((size_t)B);
-        if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_a(E[m], ctx[m]); }, true))) return r;
+        if ((r = lockstep(E, members, recs, [&](int m) { pending_layout(E[m]); return libc_init_a(E[m], ctx[m]); }, true))) return r;
         for (int m : members) if ((r = sweep_complete(E[m], ctx[m], nullptr, nullptr, true))) return r;
         if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_b(E[m], ctx[m]); }, true))) return r;
         for (int m : members) if ((r = sweep_complete(E[m], ctx[m], nullptr, nullptr, true))) return r;
@@ -1523,6 +1558,7 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
         for (int i = 0; i < B; i++) if (loop_wants_batch(E[i], L[i])) members.push_back(i);
         if (members.empty()) break;
         r = lockstep(E, members, recs, [&](int m) {
+            pending_layout(E[m]);
             int rr = batch_plan(E[m], L[m]);
             if (rr == NEMGPU_OK) rr = batch_enqueue(E[m], L[m], false);
             return rr;
@@ -1600,6 +1636,7 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results, GroupFetch*
     auto restore = [&]() { loan.give_back(); };
     for (int i = 0; i < B; i++) {
         if (crit_test(E[i])) {                                     // (a host round trip per iteration: nothing to share)
+            for (int j = 0; j < B; j++) pending_layout(E[j]);      // (still on the lead's stream, behind the waits for the uploads)
             restore();
             for (int j = 0; j < B; j++) { int rr = nemgpu_run(E[j], results ? &results[j] : nullptr); if (rr) return rr; }
             return NEMGPU_OK;
@@ -1612,6 +1649,7 @@ int run_many(std::vector<nemgpu_engine*>& E, nemgpu_result* results, GroupFetch*
     for (int i = 0; i < B && r == NEMGPU_OK; i++) { E[i]->draws = 0; r = loop_begin(E[i], L[i], E[i]->cfg.it_max, true); }
     lap(1);
     if (r == NEMGPU_OK) r = iterate_many(E, L);
+    for (int i = 0; i < B; i++) pending_layout(E[i]);             // (it_max 0: no step has carried them)
     lap(2);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < B && r == NEMGPU_OK; i++) {
@@ -2009,6 +2047,7 @@ void nemgpu_release_cached(void)
         {
             std::lock_guard<std::mutex> lock(P.m);                                // (... which is emptied here)
             streams.swap(P.streams); devm.swap(P.dev); pin.swap(P.pinned);
+            streams.insert(streams.end(), P.run_streams.begin(), P.run_streams.end()); P.run_streams.clear();
             P.dev_bytes = P.pinned_bytes = 0;
         }
         if (streams.empty() && devm.empty() && pin.empty()) continue;
@@ -2042,6 +2081,37 @@ static uint32_t* host_bits_reserve(nemgpu_engine* e, size_t words)
 // bit rows (already in e->host_bits) -> device layouts.  pc: the rows' popcounts when the caller has them, else null.
 // With pinned bit rows nothing here waits for the device: the copies and the layout kernels are ordered on the
 // engine's stream ahead of everything that reads the layouts.
+// Row popcounts of the family-major bit rows (the density kernels' lane order): with the CPU's popcnt instruction when
+// it has one (20 000 x 500: 180 -> 45 us of a 0.36 ms engine build -- the builders are what bounds nemgpu_solve_many
+// once the runs overlap them).  Host code only.
+__attribute__((visibility("hidden"))) void nem_row_popcounts(const uint32_t* bits, int n, int wf, int* pc);
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("popcnt"))) static void row_popcounts_hw(const uint32_t* bits, int n, int wf, int* pc)
+{
+    for (int i = 0; i < n; i++) {
+        const uint32_t* row = bits + (size_t)i * wf;
+        int c = 0, w = 0;
+        for (; w + 2 <= wf; w += 2) { uint64_t v; memcpy(&v, row + w, 8); c += (int)__builtin_popcountll(v); }
+        if (w < wf) c += __builtin_popcount(row[w]);
+        pc[i] = c;
+    }
+}
+static void row_popcounts_sw(const uint32_t* bits, int n, int wf, int* pc)
+{
+    for (int i = 0; i < n; i++) {
+        const uint32_t* row = bits + (size_t)i * wf;
+        int c = 0;
+        for (int w = 0; w < wf; w++) c += __builtin_popcount(row[w]);
+        pc[i] = c;
+    }
+}
+void nem_row_popcounts(const uint32_t* bits, int n, int wf, int* pc)
+{
+    static const bool hw = __builtin_cpu_supports("popcnt") != 0;
+    if (hw) row_popcounts_hw(bits, n, wf, pc); else row_popcounts_sw(bits, n, wf, pc);
+}
+#endif
+
 static int upload_bits(nemgpu_engine* e, const int* pc_in)
 {
     HIPCHK(hipSetDevice(e->device));
@@ -2059,12 +2129,7 @@ static int upload_bits(nemgpu_engine* e, const int* pc_in)
         std::vector<int> pc_own;
         if (pc_in == nullptr) {
             pc_own.resize((size_t)e->n);
-            for (int i = 0; i < e->n; i++) {
-                const uint32_t* row = xbits_host + (size_t)i * e->wf;
-                int c = 0;
-                for (int w = 0; w < e->wf; w++) c += __builtin_popcount(row[w]);
-                pc_own[i] = c;
-            }
+            nem_row_popcounts(xbits_host, e->n, e->wf, pc_own.data());
             pc_in = pc_own.data();
         }
         const int* pc = pc_in;
@@ -2091,7 +2156,9 @@ static int upload_bits(nemgpu_engine* e, const int* pc_in)
     hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
         err = hipMemcpyAsync(e->perm, perm, (size_t)e->npad * sizeof(int), hipMemcpyHostToDevice, e->stream);
-    if (err == hipSuccess) {
+    e->layout_pending = false;
+    if (err == hipSuccess && e->defer_layout && async && staged_in_chunk) e->layout_pending = true;   // (run_many: pending_layout)
+    else if (err == hipSuccess) {
         launch_layout(xf, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->perm, e->xws, e->stream);
         err = hipGetLastError();
     }
@@ -2129,14 +2196,14 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
     const int d = e->d, wf = e->wf;
     uint32_t* bits = host_bits_reserve(e, (size_t)e->n * wf);
     std::vector<int> pc((size_t)e->n);
-    // one pass: 8 values per load (bit 0 of each byte -> one byte), a whole 32-organism word at a time, the row's
-    // popcount (the density kernels' lane order) on the way
+    // 8 values per load (bit 0 of each byte -> one byte), a whole 32-organism word at a time; then the rows' popcounts
+    // (the density kernels' lane order)
     auto pack_rows = [&](int r0, int r1, uint64_t* bad_out) {
         uint64_t bad = 0;
         for (int i = r0; i < r1; i++) {
             const uint8_t* row = x_host + (size_t)i * d;
             uint32_t* out = bits + (size_t)i * wf;
-            int j = 0, cnt = 0;
+            int j = 0;
             for (; j + 32 <= d; j += 32) {
                 uint64_t w[4];
                 memcpy(w, row + j, 32);
@@ -2145,7 +2212,6 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
                 for (int q = 0; q < 4; q++)
                     v |= (uint32_t)(((w[q] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * q);
                 out[j >> 5] = v;
-                cnt += __builtin_popcount(v);
             }
             if (j < d) {
                 uint32_t v = 0;
@@ -2158,10 +2224,9 @@ int nemgpu_set_matrix_bytes(nemgpu_engine* e, const uint8_t* x_host)
                 }
                 for (; j < d; j++, b++) { bad |= row[j]; v |= (uint32_t)(row[j] & 1u) << b; }
                 out[wf - 1] = v;
-                cnt += __builtin_popcount(v);
             }
-            pc[i] = cnt;
         }
+        nem_row_popcounts(bits + (size_t)r0 * wf, r1 - r0, wf, pc.data() + r0);
         *bad_out = bad;
     };
     // rows are independent: matrices of 4 MB and more are packed by up to 4 threads
@@ -2478,7 +2543,7 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     std::vector<hipStream_t> wstream((size_t)workers, nullptr);
     hipStream_t rstream = nullptr, fstream = nullptr;
     (void)hipSetDevice(device);
-    if (pool_stream_get(device, &rstream) != hipSuccess) { set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
+    if (pool_run_stream_get(device, &rstream) != hipSuccess) { set_error("hipStreamCreate failed"); return NEMGPU_E_DEVICE; }
     if (pool_stream_get(device, &fstream) != hipSuccess) { (void)hipGetLastError(); fstream = nullptr; }
     const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -2491,6 +2556,7 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
         double t[6] = {0, 0, 0, 0, 0, 0};
         auto t0 = now();
         int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, st);
+        if (r == NEMGPU_OK && st != nullptr) e->defer_layout = true;
         t[1] = since(t0);
         if (r == NEMGPU_OK) r = q.x_bits ? nemgpu_set_matrix_bits(e, q.x_bits) : nemgpu_set_matrix_bytes(e, q.x_bytes);
         t[2] = since(t0);
@@ -2647,7 +2713,7 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     for (std::thread& t : pool) t.join();
     for (hipStream_t st : wstream) if (st) { (void)hipStreamSynchronize(st); pool_stream_put(device, st); }
     (void)hipStreamSynchronize(rstream);
-    pool_stream_put(device, rstream);
+    pool_run_stream_put(device, rstream);
     if (fstream) { (void)hipStreamSynchronize(fstream); pool_stream_put(device, fstream); }
     for (int i = 0; i < count; i++)
         if (P[i].rc != NEMGPU_OK && rc == NEMGPU_OK) { rc = P[i].rc; first_err = errs[(size_t)i]; }

@@ -98,35 +98,35 @@ __device__ __forceinline__ float chain_add16(float s, const float4& a, const flo
 //   xw  [W][npad]   word-major: lane i reads word w of family i  -> coalesced E1 reads
 //   xt  [d][nw64]   organism-major bit rows (bit j = local family j) -> popcount M-step
 // ------------------------------------------------------------------------------------------
-__global__ void k_layout_words(const uint32_t* __restrict__ xf, int n, int wf, int W, int npad,
-                               uint32_t* __restrict__ xw)
+// words: block (bx, w) -- lane i <- word w of family i (xw) and of family perm[i] (xws, E1's sorted copy), one read pass
+__device__ __forceinline__ void layout_words_body(const LayoutArgs& a, int bx)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int w = blockIdx.y;
-    if (i >= npad) return;
-    uint32_t v = 0;
-    if (i < n && w < wf) v = xf[(size_t)i * wf + w];
-    xw[(size_t)w * npad + i] = v;
+    const int i = bx * 256 + (int)threadIdx.x;
+    const int w = blockIdx.y;                                      // 0 .. 4 * ceil(W / 4) - 1
+    if (i >= a.npad) return;
+    uint32_t v = 0, vs = 0;
+    if (i < a.n && w < a.wf) { v = a.xf[(size_t)i * a.wf + w]; vs = a.xf[(size_t)a.perm[i] * a.wf + w]; }
+    if (w < a.W) a.xw[(size_t)w * a.npad + i] = v;
+    a.xws[((size_t)(w >> 2) * a.npad + i) * 4 + (w & 3)] = vs;     // uint4[W4][npad]: words 4g..4g+3 of lane i together
 }
 
 // one wave = 64 families x one 32-organism word: 32 ballots transpose the 64x32 bit tile
-__global__ void k_layout_bits(const uint32_t* __restrict__ xw, int npad, int d, int nw64,
-                              uint64_t* __restrict__ xt)
+__device__ __forceinline__ void layout_bits_body(const LayoutArgs& a, int bx)
 {
-    int lane = threadIdx.x & 63;
-    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // 64-family block index
-    int w = blockIdx.y;
-    if (wave >= nw64) return;
-    int i = wave * 64 + lane;
-    uint32_t v = (i < npad) ? xw[(size_t)w * npad + i] : 0u;
+    const int lane = threadIdx.x & 63;
+    const int wave = (bx * 256 + (int)threadIdx.x) >> 6;           // 64-family block index
+    const int w = blockIdx.y;
+    if (wave >= a.nw64) return;
+    const int i = wave * 64 + lane;
+    const uint32_t v = (i < a.npad) ? a.xw[(size_t)w * a.npad + i] : 0u;
     uint64_t mine = 0;
 #pragma unroll
     for (int b = 0; b < 32; b++) {
-        uint64_t m = __ballot((v >> b) & 1u);
+        const uint64_t m = __ballot((v >> b) & 1u);
         if (lane == b) mine = m;
     }
-    int org = w * 32 + lane;
-    if (lane < 32 && org < d) xt[(size_t)org * nw64 + wave] = mine;
+    const int org = w * 32 + lane;
+    if (lane < 32 && org < a.d) a.xt[(size_t)org * a.nw64 + wave] = mine;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3209,27 +3209,6 @@ bool launch_halfsum_debug(const float* x, int n, int waves, float* out, hipStrea
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-// same, lane i <- family perm[i] (E1's sorted copy)
-__global__ void k_layout_words_perm(const uint32_t* __restrict__ xf, const int* __restrict__ perm, int n, int wf, int W,
-                                    int npad, uint32_t* __restrict__ xws)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int w = blockIdx.y;
-    if (i >= npad) return;
-    uint32_t v = 0;
-    if (i < n && w < wf) v = xf[(size_t)perm[i] * wf + w];
-    xws[((size_t)(w >> 2) * npad + i) * 4 + (w & 3)] = v;          // uint4[W4][npad]: words 4g..4g+3 of lane i together
-}
-
-void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
-                   const int* perm, uint32_t* xws, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_layout_words, dim3((npad + 255) / 256, W), dim3(256), 0, s, xf, n, wf, W, npad, xw);
-    hipLaunchKernelGGL(k_layout_words_perm, dim3((npad + 255) / 256, ((W + 3) / 4) * 4), dim3(256), 0, s, xf, perm, n, wf,
-                       W, npad, xws);
-    hipLaunchKernelGGL(k_layout_bits, dim3((nw64 * 64 + 255) / 256, W), dim3(256), 0, s, xw, npad, d, nw64, xt);
-}
-
 // ------------------------------------------------------------------------------------------
 // Kernels = the bodies above, twice: once with the argument block as a kernel parameter (one problem), once with an
 // array of argument blocks in device memory and the problem in blockIdx.z (B problems per launch).
@@ -3358,6 +3337,10 @@ __device__ __forceinline__ void copy_body(const CopyArgs& a)
 {
     for (int t = threadIdx.x; t < a.words; t += 256) a.dst[t] = a.src[t];                           // (one block)
 }
+__global__ __launch_bounds__(256) void k_layout_words(LayoutArgs a) { layout_words_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_layout_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(LayoutArgs) layout_words_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_layout_bits(LayoutArgs a) { layout_bits_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_layout_bits_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(LayoutArgs) layout_bits_body(a, blockIdx.x); }
 __global__ void k_copy_words(CopyArgs a) { copy_body(a); }
 __global__ void k_copy_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CopyArgs) copy_body(a); }
 
@@ -3449,6 +3432,17 @@ void launch_copy_words(const int* src, int* dst, int words, hipStream_t s)
     CopyArgs a{src, dst, words};
     if (record_op(OP_COPY, 0, dim3(1), 256, a)) return;
     hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, s, a);
+}
+
+// the device layouts of an uploaded matrix (recordable: nemgpu_solve_many leaves them to the group's run, one launch each
+// for all members instead of three small launches per engine next to the running group)
+void launch_layout(const uint32_t* xf, int n, int wf, int W, int npad, int d, int nw64, uint32_t* xw, uint64_t* xt,
+                   const int* perm, uint32_t* xws, hipStream_t s)
+{
+    const LayoutArgs a{xf, perm, n, wf, W, npad, d, nw64, xw, xws, xt};
+    const dim3 gw((npad + 255) / 256, ((W + 3) / 4) * 4), gb((nw64 * 64 + 255) / 256, W);
+    if (!record_op(OP_LAYOUT_WORDS, 0, gw, 256, a)) hipLaunchKernelGGL(k_layout_words, gw, dim3(256), 0, s, a);
+    if (!record_op(OP_LAYOUT_BITS, 0, gb, 256, a)) hipLaunchKernelGGL(k_layout_bits, gb, dim3(256), 0, s, a);
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t s)
@@ -3629,6 +3623,8 @@ void launch_zipped(int kind, int variant, int B, const void* arr, int stride, co
     case OP_CRIT_FINAL: hipLaunchKernelGGL(k_crit_final_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_FILL: hipLaunchKernelGGL(k_fill_b, grid, blk, 0, s, arr, stride, gx); break;
     case OP_COPY: hipLaunchKernelGGL(k_copy_words_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_LAYOUT_WORDS: hipLaunchKernelGGL(k_layout_words_b, grid, blk, 0, s, arr, stride, gx); break;
+    case OP_LAYOUT_BITS: hipLaunchKernelGGL(k_layout_bits_b, grid, blk, 0, s, arr, stride, gx); break;
     default: break;
     }
 }

@@ -111,6 +111,7 @@ struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const 
                   float* crit6; int hard; };
 struct FillArgs { int* ptr; int words; int value; };
 struct CopyArgs { const int* src; int* dst; int words; };
+struct LayoutArgs { const uint32_t* xf; const int* perm; int n, wf, W, npad, d, nw64; uint32_t* xw; uint32_t* xws; uint64_t* xt; };
 
 // ---- batched launches: B independent problems per launch ---------------------------------------------------------
 // Every loop kernel has a twin that takes an ARRAY of argument blocks in device memory and runs problem blockIdx.z
@@ -119,7 +120,7 @@ struct CopyArgs { const int* src; int* dst; int words; };
 // the sequences agree launch for launch, and issues each position once for all problems with launch_zipped.
 enum OpKind { OP_FINISH = 1, OP_DENSITY, OP_DENSITY_FUSED, OP_SWEEP, OP_COUNTS, OP_LABELS_POST, OP_CTRL, OP_FUZZY_A, OP_FUZZY_B,
               OP_CONV_FUZZY, OP_ONEHOT, OP_CRIT_TERMS, OP_CRIT_REDUCE, OP_CRIT_FINAL, OP_FILL, OP_COPY, OP_FUZZY_T, OP_FUZZY_SUMS, OP_FUZZY_MED,
-              OP_FUZZY_PC, OP_FUZZY_MED2 };
+              OP_FUZZY_PC, OP_FUZZY_MED2, OP_LAYOUT_WORDS, OP_LAYOUT_BITS };
 constexpr int kOpArgBytes = 512;
 struct OpRecord {
     int kind, variant;             // variant: template instance / block size, part of what must agree across problems
