@@ -54,7 +54,7 @@ def solve_many(problems, workers=8, group=32, device=0, algo="ncem", beta=0.5, d
     cfg = Config(ALGO[algo], beta, DISP[disper], PROP[propor], CVT[cvtest], cvthres, it_max, int(param_fix), TIE[tie], seed)
     arr = (Problem * len(problems))()
     keep, outs = [], []
-    addr = lambda a: a.ctypes.data
+    addr = lambda a: a.__array_interface__["data"][0]     # (a.ctypes.data builds a ctypes object per call: 1.6 us)
     for q, (x, nei, k, prop, center, disp) in zip(arr, problems):
         bits = x.dtype == np.uint32
         x = np.ascontiguousarray(x, np.uint32 if bits else np.uint8)
@@ -77,8 +77,10 @@ def solve_many(problems, workers=8, group=32, device=0, algo="ncem", beta=0.5, d
             q.nei_ptr, q.nei_idx, q.nei_w = addr(ptr), addr(idx), addr(w)
             keep += [ptr, idx, w]
         q.prop, q.center, q.disp = addr(prop), addr(center), addr(disp)
-        o = dict(prop=np.zeros(k, np.float32), center=np.zeros((k, d), np.float32), disp=np.zeros((k, d), np.float32),
-                 nbobs_k=np.zeros(k, np.float32), c=np.zeros((n, k), np.float32))
+        # (every element is written by the library when the call succeeds; zero-filling the memberships -- n x k floats --
+        # was 70 us per problem, 18 of the 25 ms this function spent outside the library on 256 problems of 20 000 x 500)
+        o = dict(prop=np.empty(k, np.float32), center=np.empty((k, d), np.float32), disp=np.empty((k, d), np.float32),
+                 nbobs_k=np.empty(k, np.float32), c=np.empty((n, k), np.float32))
         q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c = (addr(o[f]) for f in ("prop", "center", "disp", "nbobs_k", "c"))
         outs.append(o)
     if devices is None:

@@ -2510,7 +2510,25 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
 // engines (bit packing, uploads out of pinned blocks -- nothing waits for the device), the calling thread runs every
 // `group` of them in lock step as soon as it is complete (nemgpu_run_many), the workers fetch the results and recycle
 // the engines while later groups are being built.  What PPanGGOLiN's chunk loop is when its chunks are arrays.
+static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group);
+static thread_local bool tl_runner = false;                  // this thread is one of nemgpu_solve_many_devices' runners
+
+// Four groups and more, six workers and more: two runners on the device (nemgpu_solve_many_devices with the device named
+// twice), each with half of the workers.  Between the steps of a group its runner reads flags and records the next step
+// -- 0.1-0.3 ms in which its stream is empty; the other runner's group fills them (256 problems of 20 000 x 500,
+// 12 workers: 8 400 -> 9 900 problems/s).  NEM_MI355X_RUNNERS=n fixes the number (1: never split).
 int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group)
+{
+    if (!P || count <= 0 || !cfg) return NEMGPU_E_FUNCARG;
+    static const int fixed = [] { const char* g = getenv("NEM_MI355X_RUNNERS"); return g ? std::max(0, std::min(atoi(g), 4)) : 0; }();
+    const int g = std::max(1, std::min(group, 256));
+    const int runners = tl_runner ? 1 : fixed > 0 ? fixed : (count >= 4 * g && workers >= 6 ? 2 : 1);
+    if (runners <= 1 || count <= g) return solve_many_one(P, count, cfg, device, workers, group);
+    const int devs[4] = {device, device, device, device};
+    return nemgpu_solve_many_devices(P, count, cfg, devs, runners, workers, group);
+}
+
+static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group)
 {
     if (!P || count <= 0 || !cfg) return NEMGPU_E_FUNCARG;
     workers = std::max(1, std::min(workers, 64));
@@ -2758,6 +2776,7 @@ int nemgpu_solve_many_devices(nemgpu_problem* P, int count, const nemgpu_config*
     for (int s = 0; s < n_devices; s++) {
         if (sub[(size_t)s].empty()) continue;
         th.emplace_back([&, s] {
+            tl_runner = true;
             rcs[(size_t)s] = nemgpu_solve_many(sub[(size_t)s].data(), (int)sub[(size_t)s].size(), cfg, devices[s], wk, group);
             if (rcs[(size_t)s] != NEMGPU_OK) errs[(size_t)s] = g_last_error;       // (the error text is per thread)
         });

@@ -246,3 +246,18 @@ def test_solve_many_fuzzy_memberships_come_back_with_the_group(gpu_lib):
             assert got["iters"] == w["iters"] and got["status"] == w["status"]
             for f in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
                 assert np.array_equal(got[f], w[f]), f
+
+
+def test_solve_many_with_two_runners_on_the_device(gpu_lib):
+    """four groups and more with six workers and more: nemgpu_solve_many deals the groups to two runners on the one
+    device (the device list names it twice) -- every answer is still the problem's own solve()."""
+    from pangenomenem_amd.batch import solve_many
+    from pangenomenem_amd.engine import solve
+    probs = _problems(14, n=1800, d=70)
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", tie="hash", seed=3)
+    want = [solve(*p, **cfg) for p in probs]
+    for batch in (solve_many(probs, workers=6, group=3, **cfg), solve_many(probs, workers=8, group=2, devices=[0, 0, 0], **cfg)):
+        for got, w in zip(batch, want):
+            assert got["iters"] == w["iters"] and got["status"] == w["status"]
+            for f in ("c", "prop", "center", "disp", "nbobs_k", "crit"):
+                assert np.array_equal(got[f], w[f]), f
