@@ -58,6 +58,7 @@ echo "[collect] K sweep done"
 python3 profiles/batch_lockstep.py > $O/${R}_batch_lockstep.json 2> /dev/null
 python3 profiles/random_starts.py > $O/${R}_random_starts.json 2> /dev/null
 python3 profiles/batch_chunks.py > $O/${R}_batch_chunks.json 2> /dev/null
+python3 profiles/batch_chunks.py 256 > $O/${R}_batch_chunks_256.json 2> /dev/null
 python3 profiles/pcie_inclusive.py > $O/${R}_pcie_inclusive.json 2> /dev/null
 python3 profiles/fuzzy_mstep.py > $O/${R}_fuzzy_mstep.txt 2> /dev/null
 echo "[collect] batches done"

@@ -147,7 +147,7 @@ def main():
                  "bench_200000x5000.json", "bench_20000x500_latent3.json", "bench_20000x500_fuzzy.json",
                  "bench_20000x500_skd.json", "bench_dist_world1.json", "bench_2ranks_gloo_one_gpu.json", "dist_world1.json",
                  "dist_world1_20000x500.json", "dist_2ranks_gloo_strong.json", "dist_2ranks_gloo_replicas.json", "dist_2ranks_gloo_weak.json",
-                 "pcie_inclusive.json", "batch_chunks.json", "batch_lockstep.json", "random_starts.json",
+                 "pcie_inclusive.json", "batch_chunks.json", "batch_chunks_256.json", "batch_lockstep.json", "random_starts.json",
                  "dropin_whole_call.json", "dropin_logged.json", "fuzzy_mstep.txt", "fuzzy_mstep_lane_per_chain.txt", "fuzzy_mstep_wave_per_chain.txt"):
         b = os.path.join(OUT, "%s_%s" % (R, name))
         if os.path.isfile(b) and os.path.getsize(b) > 0:
