@@ -166,8 +166,12 @@ int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results);
 /* Many whole problems from host arrays to host arrays in ONE call -- PPanGGOLiN's chunk loop
    (ppanggolin.py:1045-1086) when the chunks are arrays: `workers` threads of the library build the engines (bit
    packing, asynchronous uploads), the calling thread runs each `group` of them in lock step (nemgpu_run_many) as soon
-   as it is complete, the workers fetch results and recycle engines while later groups are being built.  Every
-   problem's result equals its own nemgpu_run.  Returns the first failure (each problem's own status is in rc). */
+   as it is complete -- the run waits for its members' uploads by event, their device layouts ride in its first step,
+   their partitions and parameters come back in one block with it -- and the workers unpack the results and recycle the
+   engines while later groups are being built.  From four groups on (and six workers) the groups are dealt to two such
+   runners on the device (NEM_MI355X_RUNNERS=n: n runners; 1: never split).  Every problem's result equals its own
+   nemgpu_run; every element of a problem's out_* arrays is written when its rc is NEMGPU_OK.  Returns the first
+   failure (each problem's own status is in rc). */
 typedef struct {
     int n, d, k;
     const uint8_t*  x_bytes;     /* [n][d] values 0/1 ...                                   */
