@@ -3333,16 +3333,16 @@ __device__ __forceinline__ void fill_body(const FillArgs& a)
 __global__ void k_fill(FillArgs a) { fill_body(a); }
 __global__ void k_fill_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(FillArgs) fill_body(a); }
 
-__device__ __forceinline__ void copy_body(const CopyArgs& a)
+__device__ __forceinline__ void copy_body(const CopyArgs& a, int bx, int nblk)
 {
-    for (int t = threadIdx.x; t < a.words; t += 256) a.dst[t] = a.src[t];                           // (one block)
+    for (int t = bx * 256 + (int)threadIdx.x; t < a.words; t += nblk * 256) a.dst[t] = a.src[t];    // (one block per 4096 words, at most 64)
 }
 __global__ __launch_bounds__(256) void k_layout_words(LayoutArgs a) { layout_words_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_layout_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(LayoutArgs) layout_words_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_layout_bits(LayoutArgs a) { layout_bits_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_layout_bits_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(LayoutArgs) layout_bits_body(a, blockIdx.x); }
-__global__ void k_copy_words(CopyArgs a) { copy_body(a); }
-__global__ void k_copy_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CopyArgs) copy_body(a); }
+__global__ void k_copy_words(CopyArgs a) { copy_body(a, blockIdx.x, gridDim.x); }
+__global__ void k_copy_words_b(const void* arr, int stride, const int* gx) { NEM_B_HEAD(CopyArgs) copy_body(a, blockIdx.x, nblk); }
 
 // ---- the recorder ----
 static thread_local Recorder* g_recorder = nullptr;
@@ -3430,8 +3430,9 @@ void launch_fill(int* ptr, int words, int value, hipStream_t s)
 void launch_copy_words(const int* src, int* dst, int words, hipStream_t s)
 {
     CopyArgs a{src, dst, words};
-    if (record_op(OP_COPY, 0, dim3(1), 256, a)) return;
-    hipLaunchKernelGGL(k_copy_words, dim3(1), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)std::max(1, std::min(64, (words + 4095) / 4096)));   // (a fuzzy member's memberships: n x k words)
+    if (record_op(OP_COPY, 0, grid, 256, a)) return;
+    hipLaunchKernelGGL(k_copy_words, grid, dim3(256), 0, s, a);
 }
 
 // the device layouts of an uploaded matrix (recordable: nemgpu_solve_many leaves them to the group's run, one launch each
