@@ -2066,7 +2066,8 @@ static uint32_t* host_bits_reserve(nemgpu_engine* e, size_t words)
         pool_put(e->device, true, (char*)e->host_bits, e->host_bits_pin);
     }
     e->host_bits = nullptr; e->host_bits_pin = 0; e->host_bits_words = 0;
-    const size_t bytes = std::max<size_t>(words, 1) * sizeof(uint32_t);
+    // (behind the rows: room for the lanes' family order, npad ints -- upload_bits sends both in one copy)
+    const size_t bytes = (std::max<size_t>(words, 1) + (size_t)e->npad) * sizeof(uint32_t);
     if (bytes <= kStageMax) {
         char* p = nullptr; size_t got = 0;
         if (pool_get(e->device, true, bytes, &p, &got) == hipSuccess) { e->host_bits = (uint32_t*)p; e->host_bits_pin = got; }
@@ -2121,7 +2122,7 @@ static int upload_bits(nemgpu_engine* e, const int* pc_in)
     const size_t words = (size_t)e->n * e->wf;
     // lane order of the density kernels: inside each 256-family tile, families by popcount (stable)
     std::vector<int> perm_own;
-    int* perm = e->host_bits_pin ? (int*)stage(e, (size_t)e->npad * sizeof(int)) : nullptr;
+    int* perm = e->host_bits_pin ? reinterpret_cast<int*>(e->host_bits + words) : nullptr;   // (the tail of the pinned block)
     const bool async = perm != nullptr;
     if (!perm) { perm_own.resize((size_t)e->npad); perm = perm_own.data(); }
     for (int i = 0; i < e->npad; i++) perm[i] = i;
@@ -2148,14 +2149,24 @@ static int upload_bits(nemgpu_engine* e, const int* pc_in)
     // staging copy of the family-major bit rows: small ones live in the engine's chunk, large ones come and go
     const bool staged_in_chunk = words * sizeof(uint32_t) < kChunkOwn;
     if (staged_in_chunk) {
-        if (!e->xf_stage) { alloc_for(e); int r = dev_alloc(&e->xf_stage, words); if (r) return r; }
+        if (!e->xf_stage) { alloc_for(e); int r = dev_alloc(&e->xf_stage, words + (size_t)e->npad); if (r) return r; }
         xf = e->xf_stage;
     } else {
         HIPCHK(pool_get(e->device, false, words * sizeof(uint32_t), (char**)&xf, &xf_size));
     }
-    hipError_t err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
-    if (err == hipSuccess)
-        err = hipMemcpyAsync(e->perm, perm, (size_t)e->npad * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    hipError_t err;
+    if (async && staged_in_chunk) {
+        // rows and lane order in ONE copy (host: the pinned block and its tail; device: the staging rows and theirs): a
+        // copy's fixed cost on the copy engine -- 16 us median for the four copies of an engine in nemgpu_solve_many's
+        // trace -- is what bounds that job
+        int* dperm = reinterpret_cast<int*>(e->xf_stage + words);
+        if (e->perm != dperm) { e->perm = dperm; drop_graphs(e); }      // (captured batches hold the old address)
+        err = hipMemcpyAsync(xf, xbits_host, (words + (size_t)e->npad) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+    } else {
+        err = hipMemcpyAsync(xf, xbits_host, words * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(e->perm, perm, (size_t)e->npad * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    }
     e->layout_pending = false;
     if (err == hipSuccess && e->defer_layout && async && staged_in_chunk) e->layout_pending = true;   // (run_many: pending_layout)
     else if (err == hipSuccess) {
