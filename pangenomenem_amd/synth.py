@@ -71,11 +71,21 @@ def grouped_pa_matrix(n, d, seed, groups=10, p_in=0.95, p_out=0.05):
     return x, z
 
 
-def contiguity_graph(n, seed, chord_frac=0.05, wmax=8):
+def contiguity_graph(n, seed, chord_frac=0.05, wmax=8, weights="small", d=None):
     """Path i<->i+1 in index order plus n*chord_frac random chords, undirected, every edge listed
     from both endpoints, integer weights uniform in [1, wmax] (keeps beta*sum(w) far below the
     reference's exp overflow at 709, SURVEY.md §0-3).  Returns CSR (ptr int32[n+1], idx int32, w float32);
-    neighbour order inside a row = insertion order (the order a .nei line would list them)."""
+    neighbour order inside a row = insertion order (the order a .nei line would list them).
+    weights="coverage": the weights PPanGGOLiN itself writes (ppanggolin.py:866-878: the number of selected
+    organisms that carry the adjacency, the division by len(organisms) is commented out) -- integers uniform in
+    [1, d]; with them beta*sum(w) passes 88 (the float exp of criterion Z overflows: M = -inf) and, on sites whose
+    neighbours agree, 709 (the double exp of the site's own factor: NaN rows), as SURVEY.md Appendix B records."""
+    if weights == "coverage":
+        if d is None:
+            raise ValueError("weights='coverage' needs the number of organisms d")
+        wmax = int(d)
+    elif weights != "small":
+        raise ValueError("weights must be 'small' or 'coverage'")
     rng = np.random.Generator(np.random.PCG64(seed + 7919))
     src = [np.arange(n - 1, dtype=np.int64)]
     dst = [np.arange(1, n, dtype=np.int64)]
@@ -101,6 +111,27 @@ def contiguity_graph(n, seed, chord_frac=0.05, wmax=8):
     np.add.at(ptr, us + 1, 1)
     ptr = np.cumsum(ptr).astype(np.int32)
     return ptr, ut.astype(np.int32), uw.astype(np.float32)
+
+
+def ring_graph(n, seed, deg, wlo, whi):
+    """Every site linked to its deg/2 nearest sites on either side of a ring, symmetric integer weights uniform
+    in [wlo, whi]: every site's weight sum is about deg*(wlo+whi)/2, so beta*sum(w) can be placed on either side of
+    88 (float exp) and 709 (double exp) for ALL sites -- the heavy-weight cases of the golden fixtures and the fuzz
+    suite.  Neighbour order inside a row: offsets -deg/2 .. -1, +1 .. +deg/2."""
+    h = max(1, deg // 2)
+    offs = np.concatenate([np.arange(-h, 0), np.arange(1, h + 1)])
+    offs = offs[np.abs(offs) < n] if n > 1 else offs[:0]
+    idx = ((np.arange(n)[:, None] + offs[None, :]) % n).astype(np.int64)
+    keep = idx != np.arange(n)[:, None]
+    ptr = np.zeros(n + 1, np.int32)
+    ptr[1:] = np.cumsum(keep.sum(axis=1))
+    src = np.repeat(np.arange(n), keep.sum(axis=1))
+    dst = idx[keep]
+    key = np.minimum(src, dst) * n + np.maximum(src, dst)
+    uniq, inv = np.unique(key, return_inverse=True)
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    wu = rng.integers(wlo, whi + 1, size=len(uniq)).astype(np.float32)
+    return ptr, dst.astype(np.int32), wu[inv].astype(np.float32)
 
 
 def default_init(d, low_disp=0.1):

@@ -11,7 +11,12 @@ set of small seeded problems,
     (nem_exe.c:239) from the five ASCII input files.
 A fixture is data only: inputs and expected outputs.  No reference source text is stored.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                  # the cases that have no directory yet
+    python tests/golden/make_golden.py --only a,b       # (re)generate these
+    python tests/golden/make_golden.py --all            # everything (the round-1 cases were generated with that round's
+                                                        #  synth generators, whose streams have changed since: a fixture
+                                                        #  carries its own inputs, regenerating gives OTHER inputs)
+Every case is generated in a process of its own (the reference's "density = 0" warning is once per process).
 """
 import gzip
 import json
@@ -95,57 +100,122 @@ def case_list():
     pc, cc, dc = synth.default_init(15)
     add("c1_ushape_ncem_cvcrit", xc, neic, 3, pc, cc, dc, cvtest="crit", cvthres=1e-4, it_max=60)
     add("c1_ushape_nem_skd_cvcrit", xc, neic, 3, pc, cc, dc, algo="nem", disper="skd", cvtest="crit", cvthres=1e-4, it_max=60)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # Round 4: the edge weights the reference's own caller writes (ppanggolin.py:866-878: distance_score = coverage,
+    # the number of selected organisms that carry the adjacency -- up to D).  beta * sum(w) then passes 88 (criterion
+    # Z's float exp, nem_alg.c:2740-2751: M = -inf while the labels stay finite) and 709 (the site's own double exp,
+    # nem_alg.c:2581-2601: inf * (1 / inf) = NaN rows; under NCEM ComputeMAP's NaN rules nem_alg.c:603-637, under fuzzy
+    # NEM NaN class sizes -> "Class k empty" -> status 2, no output files, nem_exe.c:624-631).
+    # ------------------------------------------------------------------------------------------------------------
+    xh, _ = synth.ushaped_pa_matrix(1500, 60, 11)
+    neih = synth.contiguity_graph(1500, 11, weights="coverage", d=60)       # integer weights U[1, 60]
+    ph, ch, dh = synth.default_init(60)
+    add("cov60_ncem_sk", xh, neih, 3, ph, ch, dh, files=True)
+    add("cov60_ncem_skd", xh, neih, 3, ph, ch, dh, disper="skd")
+    add("cov60_nem_sk", xh, neih, 3, ph, ch, dh, algo="nem", it_max=20)
+    add("cov60_nem_skd", xh, neih, 3, ph, ch, dh, algo="nem", disper="skd", it_max=20)
+    # configs[1]'s D = 500 with N scaled down: U[1, 500], beta*sum(w) up to ~770 -> M = -inf, labels finite
+    xH, _ = synth.ushaped_pa_matrix(2000, 500, 12)
+    neiH = synth.contiguity_graph(2000, 12, weights="coverage", d=500)
+    pH, cH, dH = synth.default_init(500)
+    add("cov500_ncem_sk", xH, neiH, 3, pH, cH, dH, files=True)
+    add("cov500_ncem_skd", xH, neiH, 3, pH, cH, dH, disper="skd")
+    add("cov500_nem_sk", xH, neiH, 3, pH, cH, dH, algo="nem", it_max=12, files=True)
+    # three times heavier: many sites pass 709 -> NaN rows -> ComputeMAP ties broken by random() in every sweep; the
+    # run never converges (labels keep being redrawn) -- the NaN rules AND the tie stream, for 30 iterations
+    neiX = synth.contiguity_graph(2000, 12, wmax=1500)
+    add("cov500_w1500_ncem", xH, neiX, 3, pH, cH, dH, it_max=30)
+    add("cov500_w1500_ncem_beta1", xH, neiX, 3, pH, cH, dH, beta=1.0)
+    # every site far beyond 709: NaN -> a class empties (status 2; nem() returns 1 and writes no .uf / .mf)
+    xn, _ = synth.bernoulli_pa_matrix(300, 400, 21)
+    pn, cn, dn = synth.default_init(400)
+    nein = synth.ring_graph(300, 5, 10, 300, 400)                            # beta*sum(w) ~ 1600-1900
+    add("nan_ring_ncem", xn, nein, 3, pn, cn, dn, it_max=20, files=True)
+    add("nan_ring_nem", xn, nein, 3, pn, cn, dn, algo="nem", it_max=20, files=True)
+    # beta*sum(w) in 640-765: straddles 709 -- some sites' exp is finite, some inf
+    xs, _ = synth.bernoulli_pa_matrix(600, 100, 22)
+    ps, cs, ds = synth.default_init(100)
+    neis = synth.ring_graph(600, 6, 8, 150, 200)
+    add("straddle709_ncem", xs, neis, 3, ps, cs, ds, it_max=20)
+    add("straddle709_nem", xs, neis, 3, ps, cs, ds, algo="nem", it_max=20)
+    add("straddle709_ncem_skd", xs, neis, 3, ps, cs, ds, disper="skd", it_max=20)
+    # beta*sum(w) in 145-270: between 88 and 709 -- finite rows, M = -inf, under fuzzy NEM and NCEM
+    xm, _ = synth.bernoulli_pa_matrix(600, 100, 23)
+    neim = synth.ring_graph(600, 7, 6, 40, 100)
+    add("mid88_709_nem", xm, neim, 3, ps, cs, ds, algo="nem", it_max=20, files=True)
+    add("mid88_709_ncem", xm, neim, 3, ps, cs, ds, it_max=20)
+    # beta*sum(w) around 88 itself (84-92): criterion Z's float exp on either side of its overflow, site by site
+    neie = synth.ring_graph(600, 8, 4, 42, 46)
+    add("edge88_nem", xm, neie, 3, ps, cs, ds, algo="nem", it_max=10)
+    add("edge88_ncem", xm, neie, 3, ps, cs, ds, it_max=20)
     return cases
 
 
-def main():
-    pyoracle.build(ref=True)
+def generate(case):
+    """One case, in a process of its own: the reference's "density = 0" warning is printed once per PROCESS (`static
+    int first`, nem_alg.c:2560), and `zero_density` is read from it."""
     ref = pyoracle.Reference()
+    name, x, nei, k, cfg = case["name"], case["x"], case["nei"], case["k"], case["cfg"]
+    n, d = x.shape
+    out = os.path.join(HERE, name)
+    if os.path.isdir(out):
+        shutil.rmtree(out)
+    os.makedirs(out)
+    r = ref.classify(x, nei, k, case["prop"], case["center"], case["disp"], algo=cfg["algo"], beta=cfg["beta"],
+                     disper=cfg["disper"], propor=cfg["propor"], cvtest=cfg["cvtest"], cvthres=cfg["cvthres"],
+                     it_max=cfg["it_max"], param_fix=cfg["param_fix"], seed=SEED_LIBC)
+    ptr, idx, w = nei if nei is not None else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    np.savez_compressed(os.path.join(out, "inputs.npz"), xbits=np.packbits(x, axis=1, bitorder="little"), n=n, d=d,
+                        k=k, has_graph=nei is not None, nei_ptr=ptr, nei_idx=idx, nei_w=w, prop=case["prop"],
+                        center=case["center"], disp=case["disp"])
+    np.savez_compressed(os.path.join(out, "expected.npz"), c=r["c"], prop=r["prop"], center=r["center"],
+                        disp=r["disp"], nbobs_k=r["nbobs_k"], crit=r["crit"], iters=r["iters"],
+                        status=r["status"], converged=r["converged"], zero_density=r["zero_density"])
+    meta = dict(name=name, n=n, d=d, k=k, cfg=cfg, libc_seed=SEED_LIBC, status=int(r["status"]),
+                iters=int(r["iters"]), converged=bool(r["converged"]), files=case["files"])
+    if case["files"]:
+        tmp = tempfile.mkdtemp(prefix="nemgold_")
+        base = nemfiles.write_nem_inputs(tmp, x, nei, case["prop"], case["center"], case["disp"],
+                                         flag=2 if cfg["param_fix"] else 1)
+        rc = ref.nem(base, k, algo=cfg["algo"].encode(), beta=cfg["beta"], convergence=cfg["cvtest"].encode(),
+                     convergence_th=cfg["cvthres"], format=b"fuzzy", it_max=cfg["it_max"], dolog=1,
+                     proportion=cfg["propor"].encode(), dispersion=cfg["disper"].encode(), init_mode=2)
+        meta["nem_rc"] = int(rc)
+        meta["nem_wrote"] = sorted(ext for ext in ("uf", "mf") if os.path.isfile(base + "." + ext))
+        for ext in meta["nem_wrote"]:                     # (rc = 1, an emptied class: the reference writes neither)
+            with open(base + "." + ext, "rb") as f, open(os.path.join(out, "ref_%s.txt.gz" % ext), "wb") as raw:
+                with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as g:
+                    g.write(f.read())
+        shutil.rmtree(tmp)
+    with open(os.path.join(out, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("%-28s n=%5d d=%5d k=%2d status=%d iters=%3d converged=%s zero_density=%s" %
+          (name, n, d, k, r["status"], r["iters"], r["converged"], r["zero_density"]), flush=True)
+
+
+def main():
+    import multiprocessing as mp
+    pyoracle.build(ref=True)
     manifest = []
     only = None                                           # --only name,name: (re)generate these cases, keep the others
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         only = set(sys.argv[2].split(","))
+    elif "--all" not in sys.argv[1:]:
+        only = set(c["name"] for c in case_list() if not os.path.isdir(os.path.join(HERE, c["name"])))
+    if only is not None:
         with open(os.path.join(HERE, "manifest.json")) as f:
             manifest = [m for m in json.load(f) if m["name"] not in only]
     for case in case_list():
         if only is not None and case["name"] not in only:
             continue
-        name, x, nei, k, cfg = case["name"], case["x"], case["nei"], case["k"], case["cfg"]
-        n, d = x.shape
-        out = os.path.join(HERE, name)
-        if os.path.isdir(out):
-            shutil.rmtree(out)
-        os.makedirs(out)
-        r = ref.classify(x, nei, k, case["prop"], case["center"], case["disp"], algo=cfg["algo"], beta=cfg["beta"],
-                         disper=cfg["disper"], propor=cfg["propor"], cvtest=cfg["cvtest"], cvthres=cfg["cvthres"],
-                         it_max=cfg["it_max"], param_fix=cfg["param_fix"], seed=SEED_LIBC)
-        ptr, idx, w = nei if nei is not None else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
-        np.savez_compressed(os.path.join(out, "inputs.npz"), xbits=np.packbits(x, axis=1, bitorder="little"), n=n, d=d,
-                            k=k, has_graph=nei is not None, nei_ptr=ptr, nei_idx=idx, nei_w=w, prop=case["prop"],
-                            center=case["center"], disp=case["disp"])
-        np.savez_compressed(os.path.join(out, "expected.npz"), c=r["c"], prop=r["prop"], center=r["center"],
-                            disp=r["disp"], nbobs_k=r["nbobs_k"], crit=r["crit"], iters=r["iters"],
-                            status=r["status"], converged=r["converged"], zero_density=r["zero_density"])
-        meta = dict(name=name, n=n, d=d, k=k, cfg=cfg, libc_seed=SEED_LIBC, status=int(r["status"]),
-                    iters=int(r["iters"]), converged=bool(r["converged"]), files=case["files"])
-        if case["files"]:
-            tmp = tempfile.mkdtemp(prefix="nemgold_")
-            base = nemfiles.write_nem_inputs(tmp, x, nei, case["prop"], case["center"], case["disp"],
-                                             flag=2 if cfg["param_fix"] else 1)
-            rc = ref.nem(base, k, algo=cfg["algo"].encode(), beta=cfg["beta"], convergence=cfg["cvtest"].encode(),
-                         convergence_th=cfg["cvthres"], format=b"fuzzy", it_max=cfg["it_max"], dolog=1,
-                         proportion=cfg["propor"].encode(), dispersion=cfg["disper"].encode(), init_mode=2)
-            meta["nem_rc"] = int(rc)
-            for ext in ("uf", "mf"):
-                with open(base + "." + ext, "rb") as f, open(os.path.join(out, "ref_%s.txt.gz" % ext), "wb") as raw:
-                    with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as g:
-                        g.write(f.read())
-            shutil.rmtree(tmp)
-        with open(os.path.join(out, "meta.json"), "w") as f:
-            json.dump(meta, f, indent=1, sort_keys=True)
-        manifest.append(meta)
-        print("%-28s n=%5d d=%5d k=%2d status=%d iters=%3d converged=%s" % (name, n, d, k, r["status"], r["iters"],
-                                                                          r["converged"]))
+        child = mp.get_context("fork").Process(target=generate, args=(case,))
+        child.start()
+        child.join()
+        if child.exitcode != 0:
+            raise SystemExit("case %s: the generator exited with %s" % (case["name"], child.exitcode))
+        with open(os.path.join(HERE, case["name"], "meta.json")) as f:
+            manifest.append(json.load(f))
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 

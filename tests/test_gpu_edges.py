@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from pangenomenem_amd import synth
-from tests.util import maxdiff
+from tests.util import assert_crit_close, maxdiff
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -140,8 +140,7 @@ def test_random_starts_match_oracle(gpu_lib, oracle, n, d, k, algo, disper, star
     for key in ("disp", "prop"):
         assert maxdiff(got[key], want[key]) <= TOL, key
     assert np.array_equal(got["center"], want["center"])
-    rel = np.abs(got["crit"].astype(np.float64) - want["crit"]) / np.maximum(1.0, np.abs(want["crit"]))
-    assert np.all((rel <= 1e-6) | ~np.isfinite(want["crit"]))
+    assert_crit_close(got["crit"], want["crit"], 1e-6)
     eng.close()
 
 

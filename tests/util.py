@@ -23,6 +23,23 @@ def maxdiff(a, b):
     return float(np.nanmax(d)) if d.size else 0.0
 
 
+def assert_crit_close(got, want, tol=1e-6, what=None):
+    """The six criteria (D, G, U, M, L, Z as floats).  Where the reference's value is finite the engine's is within
+    `tol` relative; where it is NOT -- M and Z are -inf as soon as beta*sum(w) passes 88 on one site (the float exp of
+    nem_alg.c:2740-2751), everything is NaN once a NaN row entered the partition -- the engine's value must be the SAME
+    non-finite value: NaN for NaN, an infinity of the same sign for an infinity.  (Round 3 masked those entries.)"""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got, want, what)
+    for j, (g, w) in enumerate(zip(got.ravel(), want.ravel())):
+        if np.isnan(w):
+            assert np.isnan(g), (j, got, want, what)
+        elif np.isinf(w):
+            assert np.isinf(g) and (g > 0) == (w > 0), (j, got, want, what)
+        else:
+            assert np.isfinite(g) and abs(g - w) <= tol * max(1.0, abs(w)), (j, got, want, what)
+
+
 def ulp_diff64(a, b):
     """max distance in units in the last place between two float64 arrays (finite entries)."""
     a = np.ascontiguousarray(a, np.float64).view(np.int64)
