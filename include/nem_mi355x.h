@@ -434,6 +434,12 @@ int nemgpu_set_graph_policy(nemgpu_engine* e, int capture_on_first);
 /* out[0] batches sent as plain launches, out[1] batches captured + instantiated, out[2] graph replays,
    out[3] sweeps the host had to finish round by round */
 int nemgpu_graph_counters(const nemgpu_engine* e, int out[4]);
+/* The fused form of the E2 sweep (the reference's ComputePartitionNEM, nem_alg.c:2330-2405, as relaxation rounds): one
+   engine alone runs the first rounds of a sweep in ONE launch whose blocks meet between rounds (NCEM, hash / first tie
+   rule, at most one block per CU; NEM_MI355X_FUSED_SWEEP=0 turns it off, NEM_MI355X_FUSED_ROUNDS sets the rounds per
+   launch).  out[0] such launches issued or captured so far, out[1] launches whose blocks failed to meet (the sweep was
+   redone with one launch per round and the engine keeps to that form), out[2] 1 while the form is in use, out[3] 0. */
+int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4]);
 
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);

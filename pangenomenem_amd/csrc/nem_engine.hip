@@ -50,6 +50,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 namespace {
 constexpr int kRoundCap = 64;     // relaxation rounds per flag window
+// what is zeroed ahead of every sweep (by the density launch, or a fill): FLAG_MOVED, the round window, the meeting words
+constexpr int kSweepFlagWords = 1 + kRoundCap * (FLAG_ROUND_STRIDE + 1);
 constexpr int kRoundBatchMax = 4;
 }  // namespace
 
@@ -132,7 +134,7 @@ struct nemgpu_engine {
     int cur = 0;
     uint64_t* mask = nullptr;
     int* stats = nullptr;
-    int* flags_dev = nullptr;     // [C_WORDS loop control] [FLAG_ITER_STRIDE] [kRoundCap * FLAG_ROUND_STRIDE]
+    int* flags_dev = nullptr;     // [C_WORDS loop control] [FLAG_ITER_STRIDE] [kRoundCap * FLAG_ROUND_STRIDE] [kRoundCap meeting words of the fused sweep]
     int* flags_host = nullptr;    // pinned mirror
     const int* stop_ptr = nullptr;   // &ctrl[C_STOP] while the pipelined loop is being enqueued, else nullptr
 
@@ -162,6 +164,12 @@ struct nemgpu_engine {
     // then every later one gets round_batch.  (Labels are sticky: on the bench's pre-convergence data only the sweep
     // that starts from the blind partition needs a third round; an early-exit launch per iteration costs 2.5 us.)
     int rounds_iter = 2;
+    // k_sweep_fused (NEM_MI355X_FUSED_SWEEP=0 turns it off): the first rounds of a sweep in ONE launch, the blocks
+    // meeting between rounds (nem_sweep_dev.hpp).  fused_rounds: rounds per such launch (NEM_MI355X_FUSED_ROUNDS, at most
+    // kFusedMaxRounds; the pipelined loop takes min(4, .): its loop control looks at four slots).  fused_sweep goes off
+    // for good when a launch's blocks did not all meet (kFusedFailed: the grid was not resident as a whole).
+    bool fused_sweep = true; int fused_rounds = 4; int n_fused_failed = 0, n_fused = 0;
+    double* exp_tab = nullptr; float exp_beta = 0.0f; bool exp_ready = false;   // SweepArgs::exp_tab for cfg.beta
     // ... but not all iterations are alike: the first ones after a start move many labels and tend to need the
     // extra round, the later ones almost never do.  The first deep_iters iterations of a run get round_batch rounds;
     // an iteration further on whose sweep the host had to finish moves the mark (it is kept across restarts: the
@@ -232,7 +240,9 @@ struct nemgpu_engine {
     int* ctrl() const { return flags_dev; }
     int* iter_flags() const { return flags_dev + C_WORDS; }
     int* round_flags(int r) const { return flags_dev + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
-    size_t flag_words() const { return C_WORDS + FLAG_ITER_STRIDE + (size_t)kRoundCap * FLAG_ROUND_STRIDE; }
+    size_t flag_words() const { return C_WORDS + FLAG_ITER_STRIDE + (size_t)kRoundCap * (FLAG_ROUND_STRIDE + 1); }
+    // k_sweep_fused: where the blocks of a launch meet after its round r (zeroed with the round flags)
+    unsigned* round_bar(int r) const { return reinterpret_cast<unsigned*>(flags_dev + C_WORDS + FLAG_ITER_STRIDE + kRoundCap * FLAG_ROUND_STRIDE + (r % kRoundCap)); }
     const int* h_ctrl() const { return flags_host; }
     const int* h_iter() const { return flags_host + C_WORDS; }
     const int* h_round(int r) const { return flags_host + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
@@ -616,7 +626,7 @@ int do_tables(nemgpu_engine* e)
 int do_density(nemgpu_engine* e)
 {
     launch_density(finish_args(e, 0, nullptr), e->xws, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
-                   1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                   kSweepFlagWords, e->stream);
     HIPCHK(hipGetLastError());
     e->flags_clean = true;
     e->density_fresh = true;
@@ -641,8 +651,8 @@ struct SweepCtx {
 
 int clear_sweep_flags(nemgpu_engine* e)
 {
-    if (current_recorder()) launch_fill(e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, 0, e->stream);
-    else HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, (1 + kRoundCap * FLAG_ROUND_STRIDE) * sizeof(int), e->stream));
+    if (current_recorder()) launch_fill(e->iter_flags() + FLAG_MOVED, kSweepFlagWords, 0, e->stream);
+    else HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, kSweepFlagWords * sizeof(int), e->stream));
     e->flags_clean = true;
     return NEMGPU_OK;
 }
@@ -717,11 +727,67 @@ int publish_draw_ctl(nemgpu_engine* e)
     return NEMGPU_OK;
 }
 
+// May the first rounds of a sweep go out as ONE launch whose blocks meet between rounds (k_sweep_fused)?  NCEM without
+// the libc tie stream, the whole problem on this engine, issued for real (a lock-step batch zips the classic rounds), a
+// kernel instance for K, and a grid that is resident as a whole: at most one block per CU.
+bool sweep_fused_ok(const nemgpu_engine* e, bool use_nei)
+{
+    return e->fused_sweep && use_nei && e->ncem() && !e->libc() && e->sh_world == 1 && e->sh_stride == 0 && e->lo == 0 &&
+           e->n == e->n_total && e->parent == nullptr && current_recorder() == nullptr && sweep_fused_has_instance(e->k) &&
+           sweep_grid_blocks(e->n, e->k) <= kFusedMaxBlocks;
+}
+// rounds of a sweep's first batch: what the caller wants, or the fused launch's rounds (inside the pipelined loop at
+// most the four slots its loop control reads)
+int sweep_first_rounds(const nemgpu_engine* e, float beta, int wanted, int pipelined = -1)
+{
+    if (!sweep_fused_ok(e, e->has_graph && beta != 0.0f)) return wanted;
+    if (pipelined < 0) pipelined = e->stop_ptr != nullptr ? 1 : 0;
+    return std::max(wanted, pipelined ? std::min(e->fused_rounds, 4) : e->fused_rounds);
+}
+// SweepArgs::exp_tab for the configured beta (outside any capture / recording: loop_begin, init_partition)
+int ensure_exp_table(nemgpu_engine* e)
+{
+    if (current_recorder() != nullptr || !e->ncem() || !e->has_graph || e->cfg.beta == 0.0f) return NEMGPU_OK;
+    if (e->exp_ready && e->exp_beta == e->cfg.beta) return NEMGPU_OK;
+    if (e->exp_tab == nullptr) { alloc_for(e); int r = dev_alloc(&e->exp_tab, (size_t)kExpTabGlobal); if (r) return r; }
+    launch_exp_table(e->cfg.beta, e->exp_tab, kExpTabGlobal, e->stream);
+    HIPCHK(hipGetLastError());
+    e->exp_beta = e->cfg.beta; e->exp_ready = true;
+    return NEMGPU_OK;
+}
+
 int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
 {
     const bool ncem = e->ncem();
     const int P = e->cur, Q = (e->cur + 1) % 3, R = (e->cur + 2) % 3;
     const int r0 = c.r;
+    c.a.fused_rounds = 0;
+    if (r0 == 0 && count >= 2 && c.multi && sweep_fused_ok(e, c.use_nei) && c.slot_base + count <= kRoundCap) {
+        // the sweep's first `count` rounds in one launch: round t writes flag slot t and buffer Q (t even) / R (t odd),
+        // as `count` launches would -- whoever reads the flags afterwards goes on from there
+        count = std::min(count, kFusedMaxRounds);
+        SweepArgs& a = c.a;
+        a.lab_old = e->lab[P]; a.lab_guess = e->lab[P]; a.lab_out = e->lab[Q]; a.lab_out2 = e->lab[R];
+        a.tie_cnt_guess = e->tie_cnt[P]; a.tie_cnt_out = e->tie_cnt[Q];
+        a.flags = e->round_flags(c.slot_base);
+        a.bar = e->round_bar(c.slot_base);
+        a.fused_rounds = count;
+        a.exp_tab = (e->exp_ready && e->exp_beta == a.beta) ? e->exp_tab : nullptr; a.exp_tab_len = kExpTabGlobal;
+        a.fold_ticket = e->sweep_next + 32;
+        a.prev_changed = nullptr;
+        a.stop = e->stop_ptr;
+        a.post_on = 0;
+        if (c.post) {
+            a.post_on = 1; a.post_from_guess = 0; a.post_moved = c.post_moved ? 1 : 0; a.post_skip_guess = 0;
+            a.post_nw64 = e->nw64; a.post_mask = e->mask; a.post_flags = e->iter_flags(); a.post_ctrl = c.post_ctrl;
+        }
+        launch_sweep(a, true, e->stream);
+        HIPCHK(hipGetLastError());
+        e->n_fused++;
+        c.r += count;
+        a.fused_rounds = 0;
+        return NEMGPU_OK;
+    }
     for (int b = 0; b < count; b++, c.r++) {
         const int r = c.r;
         const int gb = (r == 0) ? P : ((r - 1) % 2 == 0 ? Q : R);
@@ -776,7 +842,25 @@ int sweep_enqueue(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value = 
     { int r = sweep_setup(e, beta, c, id_by_value); if (r) return r; }
     if (!e->flags_clean) { int r = clear_sweep_flags(e); if (r) return r; }
     e->flags_clean = false;
-    return sweep_launch_rounds(e, c, c.multi ? (rounds > 0 ? rounds : e->round_batch) : 1);
+    return sweep_launch_rounds(e, c, c.multi ? sweep_first_rounds(e, beta, rounds > 0 ? rounds : e->round_batch) : 1);
+}
+
+// Did a fused launch among the rounds [from, to) of this sweep fail to meet (kFusedFailed)?  Then its rounds are void.
+bool fused_failed_seen(const nemgpu_engine* e, int slot_base, int from, int to)
+{
+    for (int q = from; q < to; q++) if (e->h_round(slot_base + q)[FLAG_CHANGED] & kFusedFailed) return true;
+    return false;
+}
+// ... the sweep starts again from round 0, one launch per round from now on (the old partition and the densities are
+// untouched; the flag window is cleared)
+int fused_fallback(nemgpu_engine* e, SweepCtx& c)
+{
+    e->fused_sweep = false;
+    e->n_fused_failed++;
+    drop_graphs(e);                                      // (they hold fused launches)
+    HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * (FLAG_ROUND_STRIDE + 1) * sizeof(int), e->stream));
+    c.r = 0; c.checked = 0;
+    return NEMGPU_OK;
 }
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
@@ -795,6 +879,13 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, 
         { const int fr = check_fault(e); if (fr) return fr; }
         if (!c.multi) { done_at = 0; break; }
         bool tab_short = false;
+        if (fused_failed_seen(e, c.slot_base, c.checked, c.r)) {
+            int rr = fused_fallback(e, c);
+            if (rr) return rr;
+            if (extra) *extra = true;
+            if ((rr = sweep_launch_rounds(e, c, e->round_batch))) return rr;
+            continue;
+        }
         for (int q = c.checked; q < c.r; q++) {
             if (e->h_round(c.slot_base + q)[FLAG_CHANGED] == 0) { done_at = q; break; }
             if (e->h_round(c.slot_base + q)[FLAG_NTIES] & (1 << 30)) tab_short = true;
@@ -813,7 +904,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, 
         if (c.r % kRoundCap == 0 || c.r % kRoundCap + e->round_batch > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
-            HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * FLAG_ROUND_STRIDE * sizeof(int), e->stream));
+            HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * (FLAG_ROUND_STRIDE + 1) * sizeof(int), e->stream));
             while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
             c.checked = c.r;
         }
@@ -892,6 +983,7 @@ int init_partition(nemgpu_engine* e)
     if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
     if ((r = flush_reset(e))) return r;
     if ((r = ensure_state_buffers(e))) return r;
+    if ((r = ensure_exp_table(e))) return r;
     if ((r = do_tables(e))) return r;
     if ((r = do_density(e))) return r;
     // ClassifM starts as zeros (calloc, nem_exe.c:524-526): the blind beta = 0 sweep never reads it
@@ -975,7 +1067,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
                             e->ctrl_pending ? &e->ctrl_deferred : nullptr, e->stream);
         e->ctrl_pending = false;
         launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
-                             e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                             e->iter_flags() + FLAG_MOVED, kSweepFlagWords, e->stream);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { e->cur = saved; set_error(std::string("launch failed: ") + hipGetErrorString(le)); return NEMGPU_E_DEVICE; }
         e->flags_clean = true;
@@ -994,7 +1086,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     CtrlArgs ca{};
     // (members of a lock-step batch all take the same number of rounds: a member with a sequence of its own would
     //  need launches of its own)
-    const int it_rounds = (current_recorder() != nullptr || deep) ? e->round_batch : e->rounds_iter;
+    const int it_rounds = sweep_first_rounds(e, e->cfg.beta, (current_recorder() != nullptr || deep) ? e->round_batch : e->rounds_iter);
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = it_rounds;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
@@ -1034,7 +1126,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = e->round_batch;
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = sweep_first_rounds(e, e->cfg.beta, e->round_batch);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -1101,6 +1193,7 @@ int loop_begin(nemgpu_engine* e, LoopCursor& lc, int n_iters, bool with_init)
     if (with_init) {
         if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
         if ((r = ensure_state_buffers(e))) return r;
+        if ((r = ensure_exp_table(e))) return r;
         if ((r = clear_fault(e))) return r;
         e->reset_pending = false;                          // (the head of the first batch is the device half of a reset)
         e->run_deep_used = 0; e->run_tracked = true;
@@ -1186,7 +1279,9 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         e->cur = 1;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, 1u, e->round_batch))) return r;
+        const int launched = sweep_first_rounds(e, e->cfg.beta, e->round_batch, 1);
+        if ((r = host_rounds_ctx(e, sc, 1u, launched))) return r;
+        if (fused_failed_seen(e, 0, 0, launched)) { if ((r = fused_fallback(e, sc))) return r; }
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
         e->sweep_rounds += 1;                                  // + the blind sweep
@@ -1222,7 +1317,9 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
         e->n_host_rounds++;
         SweepCtx sc;
-        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), done - 1 < lc.deep ? e->round_batch : e->rounds_iter))) return r;
+        const int launched = sweep_first_rounds(e, e->cfg.beta, done - 1 < lc.deep ? e->round_batch : e->rounds_iter, 1);
+        if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), launched))) return r;
+        if (fused_failed_seen(e, 0, 0, launched)) { if ((r = fused_fallback(e, sc))) return r; }
         e->deep_iters = std::max(e->deep_iters, e->iters);          // from now on: one round more up to this iteration of a run
         e->run_deep_used = std::max(e->run_deep_used, e->iters);
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
@@ -1968,6 +2065,8 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_ROUNDS_ITER")) e->rounds_iter = std::max(2, std::min(e->round_batch, atoi(g)));
     e->rounds_iter = std::min(e->rounds_iter, e->round_batch);
+    if (const char* g = getenv("NEM_MI355X_FUSED_SWEEP")) e->fused_sweep = (g[0] != '0');   // 0: one launch per relaxation round
+    if (const char* g = getenv("NEM_MI355X_FUSED_ROUNDS")) e->fused_rounds = std::max(2, std::min(kFusedMaxRounds, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = std::max(0, std::min(2, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FAULT_INJECT")) e->fault_inject = !strcmp(g, "fuzzy_pc") ? 1 : 0;
     if (const char* g = getenv("NEM_MI355X_FF")) e->ff_mode = (g[0] == '0') ? 0 : (g[0] == '1') ? 1 : -1;   // 0 plain chain, 1 always
@@ -3459,7 +3558,7 @@ int nemgpu_shard_estep_round0(nemgpu_engine* e, const int32_t* stats_dev, float 
         FinishArgs t = finish_args(e, 1, stats_dev);
         t.stats_ranks = e->sh_world; t.stats_rank_stride = e->sh_stride / 4;
         launch_density_fused(t, e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
-                             e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                             e->iter_flags() + FLAG_MOVED, kSweepFlagWords, e->stream);
         HIPCHK(hipGetLastError());
         e->tables_fresh = false;
         e->density_fresh = true;
@@ -4131,7 +4230,7 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
         HIPCHK(hipEventRecord(e->ev0, e->stream));
         if (fused) {
             launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
-                                 e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                                 e->iter_flags() + FLAG_MOVED, kSweepFlagWords, e->stream);
             HIPCHK(hipGetLastError());
         } else if ((r = do_density(e))) return r;
         HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -4184,9 +4283,9 @@ int nemgpu_profile_kernels(nemgpu_engine* e, int reps, double avg_ms[3], double 
     if ((r = timed([&] { launch_mstep_counts(e->k, e->d, e->nw64, e->xt, e->mask, e->stats, nullptr, nullptr, e->stream); }, &avg_ms[2]))) return r;
     if ((r = timed([&] {
             if (fused) launch_density_fused(finish_args(e, 1, e->stats), e->xws, e->n, e->npad, e->pkfki, e->logpkfki,
-                                            e->iter_flags() + FLAG_MOVED, 1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                                            e->iter_flags() + FLAG_MOVED, kSweepFlagWords, e->stream);
             else launch_density(finish_args(e, 0, nullptr), e->xws, e->n, e->npad, e->pkfki, e->logpkfki, e->iter_flags() + FLAG_MOVED,
-                                1 + kRoundCap * FLAG_ROUND_STRIDE, e->stream);
+                                kSweepFlagWords, e->stream);
         }, &avg_ms[0]))) return r;
     e->density_fresh = true; e->flags_clean = true;
     if (fused) e->tables_fresh = false;
@@ -4287,6 +4386,13 @@ int nemgpu_graph_counters(const nemgpu_engine* e, int out[4])
 {
     if (!e || !out) return NEMGPU_E_FUNCARG;
     out[0] = e->n_plain; out[1] = e->n_captured; out[2] = e->n_replayed; out[3] = e->n_host_rounds;
+    return NEMGPU_OK;
+}
+
+int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4])
+{
+    if (!e || !out) return NEMGPU_E_FUNCARG;
+    out[0] = e->n_fused; out[1] = e->n_fused_failed; out[2] = e->fused_sweep ? 1 : 0; out[3] = 0;
     return NEMGPU_OK;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/nem_mi355x.h"
@@ -93,7 +95,26 @@ struct SweepArgs {
     const uint8_t* rank_tot_in; int rank_index; uint8_t* rank_tot_out;
     // sites per block of the large-shard kernel instances (set by launch_sweep; 0: the kernel's block size)
     int spb;
+    // ---- k_sweep_fused: up to `fused_rounds` relaxation rounds in ONE launch (NCEM, one engine, every block resident).
+    // Round t of the launch (t = 0: this block's `flags`, `lab_guess`, `lab_out` as above) writes flag slot t
+    // (FLAG_ROUND_STRIDE ints further on each) and the label buffer lab_out (t even) / lab_out2 (t odd) -- exactly what
+    // `fused_rounds` separate launches would have written, so that the loop control and the host go on from there if the
+    // rounds were not enough.  Between two rounds the blocks meet on bar[t] (arrivals in the low half, blocks that
+    // changed something in the high half; zero before the sweep) and re-read only the labels of their sites'
+    // lower-indexed neighbours in OTHER blocks; a site whose inputs did not change keeps its label without an evaluation.
+    int fused_rounds;
+    uint8_t* lab_out2;
+    unsigned* bar;
+    // exp((double)beta * (double)(float)m), m = 0 .. exp_tab_len - 1, made once per beta by k_exp_table with the device
+    // exp the sweep itself would call (nullptr: the block computes the first entries itself)
+    const double* exp_tab; int exp_tab_len;
 };
+// bits of a round's FLAG_CHANGED word besides bit 0
+constexpr int kFusedFailed = 1 << 28;   // k_sweep_fused: a block gave up waiting for the others (not every block resident?):
+                                        // the launch's rounds are void, the host redoes the sweep with one launch per round
+constexpr int kFusedMaxBlocks = 256;    // one block per CU at most: every block of a fused launch must be resident
+constexpr int kFusedMaxRounds = 16;     // (the pipelined loop uses 4: ctrl_logic's window)
+constexpr int kExpTabGlobal = 4096;     // entries of SweepArgs::exp_tab
 // argument blocks of the kernels whose launch wrappers take scalars (the batched launches need them as structs)
 struct LabelsPostArgs { int n_local, lo, K, nw64; const uint8_t* lab_new; const uint8_t* lab_old; uint64_t* mask; int* flags;
                         const int* stop; CtrlArgs ca; };
@@ -168,6 +189,10 @@ constexpr int kFusedMaxD = 1024;   // beyond this the per-block parameter deriva
 void launch_density_fused(const FinishArgs& t, const uint32_t* xw, int n, int npad, double* pkfki, float* logpkfki,
                           int* zero_flags, int n_zero_flags, hipStream_t s);
 void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
+// blocks a launch of launch_sweep would use for n_local sites (what decides whether the fused form may be used)
+int sweep_grid_blocks(int n_local, int K);
+bool sweep_fused_has_instance(int K);
+void launch_exp_table(float beta, double* tab, int len, hipStream_t s);   // SweepArgs::exp_tab (recordable)
 // one NCEM relaxation round and the M-step counts (of the partition whose class masks exist already) in ONE launch;
 // returns false when the shape has no such kernel (2 <= K <= 5, fewer than 65 536 families, not recordable)
 bool launch_sweep_counts(const SweepArgs& sw, int K, int D, int nw64, const uint64_t* xt, const uint64_t* mask, int* stats,
@@ -189,5 +214,29 @@ constexpr int kCritReduceThreads = 1024;   // block size of k_crit_reduce (CH_T 
 void launch_criteria(int n, int K, int npad, const int* nei_ptr, const int* nei_idx, const float* nei_w, int use_nei,
                      float beta, const float* c, const double* pkfki, const float* logpkfki, float* dik, float* gik,
                      double* lfi, double* lzi, float* crit6, int hard, hipStream_t s);   // hard: one-hot rows (NCEM)
+
+// the head of every batched kernel twin: problem = blockIdx.z, its own grid width, its argument block
+#define NEM_B_HEAD(Args)                                                   \
+    const int p__ = blockIdx.z;                                            \
+    const int nblk = gx[p__];                                              \
+    if ((int)blockIdx.x >= nblk) return;                                   \
+    const Args a = *reinterpret_cast<const Args*>(reinterpret_cast<const char*>(arr) + (size_t)p__ * stride);
+
+// a launch wrapper's first step: with a recorder set on this thread the launch is stored, not issued
+template <typename Args>
+inline bool record_op(int kind, int variant, dim3 grid, unsigned block, const Args& a)
+{
+    static_assert(sizeof(Args) <= kOpArgBytes, "argument block too large for an OpRecord");
+    static_assert(std::is_trivially_copyable<Args>::value, "argument blocks are copied byte for byte");
+    Recorder* r = current_recorder();
+    if (r == nullptr) return false;
+    r->ops.emplace_back();
+    OpRecord& o = r->ops.back();
+    o.kind = kind; o.variant = variant; o.gx = grid.x; o.gy = grid.y; o.block = block; o.nbytes = (int)sizeof(Args);
+    memcpy(o.args, &a, sizeof(Args));
+    return true;
+}
+// the batched twin of a recorded k_sweep position (nem_sweep.hip)
+void sweep_dispatch_batched(int variant, dim3 grid, unsigned bdim, hipStream_t s, const void* arr, int stride, const int* gx);
 
 }  // namespace nemk

@@ -101,6 +101,7 @@ def load_library():
     lib.nemgpu_set_fast_forward.argtypes = [vp, C.c_int]
     lib.nemgpu_set_graph_policy.argtypes = [vp, C.c_int]
     lib.nemgpu_graph_counters.argtypes = [vp, ip]
+    lib.nemgpu_sweep_counters.argtypes = [vp, ip]
     lib.nemgpu_rccl_ranks.argtypes = [vp]
     lib.nemgpu_rccl_selftest.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.nemgpu_ff_table.argtypes = [C.c_double, C.c_double, vp, vp]
@@ -429,6 +430,11 @@ class NemEngine:
         out = (C.c_int * 4)()
         self._chk(self.lib.nemgpu_graph_counters(self._h, out))
         return dict(plain=out[0], captured=out[1], replayed=out[2], host_finished_sweeps=out[3])
+
+    def sweep_counters(self):
+        out = (C.c_int * 4)()
+        self._chk(self.lib.nemgpu_sweep_counters(self._h, out))
+        return dict(fused_launches=out[0], fused_failed=out[1], fused_on=bool(out[2]))
 
     def rccl_ranks(self):
         return int(self.lib.nemgpu_rccl_ranks(self._h))

@@ -80,10 +80,11 @@ def test_product_never_imports_the_oracle():
                 assert not bad.search(text), os.path.join(dirpath, f)
 
 
-@pytest.mark.parametrize("name", case_names(files_only=True))
+@pytest.mark.parametrize("name", [n for n in case_names(files_only=True) if load_case(n)["meta"].get("nem_rc", 0) == 0])
 def test_writers_reproduce_reference_text(lib, tmp_path, name):
     """SaveResults' formats: given the reference's full-precision arrays, our writers emit the
-    reference's .uf and .mf byte for byte."""
+    reference's .uf and .mf byte for byte (the criteria line with M = -inf included: the cases with PPanGGOLiN's own
+    edge weights; the cases whose class empties have no files, nem_exe.c:624-631)."""
     from pangenomenem_amd import engine
     case = load_case(name)
     exp = case["expected"]
