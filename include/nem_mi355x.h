@@ -435,11 +435,14 @@ int nemgpu_set_graph_policy(nemgpu_engine* e, int capture_on_first);
    out[3] sweeps the host had to finish round by round */
 int nemgpu_graph_counters(const nemgpu_engine* e, int out[4]);
 /* The fused form of the E2 sweep (the reference's ComputePartitionNEM, nem_alg.c:2330-2405, as relaxation rounds): one
-   engine alone runs the first rounds of a sweep in ONE launch whose blocks meet between rounds (NCEM, hash / first tie
-   rule, at most one block per CU; NEM_MI355X_FUSED_SWEEP=0 turns it off, NEM_MI355X_FUSED_ROUNDS sets the rounds per
-   launch).  out[0] such launches issued or captured so far, out[1] launches whose blocks failed to meet (the sweep was
+   engine alone can run the first rounds of a sweep in ONE launch whose blocks meet between rounds (NCEM, hash / first tie
+   rule, at most one block per CU; NEM_MI355X_FUSED_SWEEP=1 turns it on -- measured slower than one launch per round
+   except at 200 000 x 5 000, DESIGN.md -- NEM_MI355X_FUSED_ROUNDS sets the rounds per launch).  out[0] such launches issued or captured so far, out[1] launches whose blocks failed to meet (the sweep was
    redone with one launch per round and the engine keeps to that form), out[2] 1 while the form is in use, out[3] 0. */
 int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4]);
+/* development probe (NEM_MI355X_SWEEP_PROF=1): the device's 100 MHz clock at the phase boundaries of the last fused
+   launch, first block in out[0..31], last block in out[32..63] (0: phase not reached) */
+int nemgpu_sweep_phases(unsigned long long out64[64]);
 
 /* Re-target the engine to another HIP stream (e.g. the capturing stream of a torch.cuda.graph). */
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream);

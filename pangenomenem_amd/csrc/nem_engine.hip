@@ -51,7 +51,8 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 namespace {
 constexpr int kRoundCap = 64;     // relaxation rounds per flag window
 // what is zeroed ahead of every sweep (by the density launch, or a fill): FLAG_MOVED, the round window, the meeting words
-constexpr int kSweepFlagWords = 1 + kRoundCap * (FLAG_ROUND_STRIDE + 1);
+constexpr int kMeetWords = 2 * kFusedMaxBlocks;
+constexpr int kSweepFlagWords = 1 + kRoundCap * FLAG_ROUND_STRIDE + kMeetWords;
 constexpr int kRoundBatchMax = 4;
 }  // namespace
 
@@ -134,7 +135,7 @@ struct nemgpu_engine {
     int cur = 0;
     uint64_t* mask = nullptr;
     int* stats = nullptr;
-    int* flags_dev = nullptr;     // [C_WORDS loop control] [FLAG_ITER_STRIDE] [kRoundCap * FLAG_ROUND_STRIDE] [kRoundCap meeting words of the fused sweep]
+    int* flags_dev = nullptr;     // [C_WORDS loop control] [FLAG_ITER_STRIDE] [kRoundCap * FLAG_ROUND_STRIDE] [2 * kFusedMaxBlocks meeting words of the fused sweep]
     int* flags_host = nullptr;    // pinned mirror
     const int* stop_ptr = nullptr;   // &ctrl[C_STOP] while the pipelined loop is being enqueued, else nullptr
 
@@ -164,12 +165,18 @@ struct nemgpu_engine {
     // then every later one gets round_batch.  (Labels are sticky: on the bench's pre-convergence data only the sweep
     // that starts from the blind partition needs a third round; an early-exit launch per iteration costs 2.5 us.)
     int rounds_iter = 2;
-    // k_sweep_fused (NEM_MI355X_FUSED_SWEEP=0 turns it off): the first rounds of a sweep in ONE launch, the blocks
-    // meeting between rounds (nem_sweep_dev.hpp).  fused_rounds: rounds per such launch (NEM_MI355X_FUSED_ROUNDS, at most
-    // kFusedMaxRounds; the pipelined loop takes min(4, .): its loop control looks at four slots).  fused_sweep goes off
-    // for good when a launch's blocks did not all meet (kFusedFailed: the grid was not resident as a whole).
-    bool fused_sweep = true; int fused_rounds = 4; int n_fused_failed = 0, n_fused = 0;
+    // k_sweep_fused (NEM_MI355X_FUSED_SWEEP=1 turns it on): the first rounds of a sweep in ONE launch, the blocks
+    // meeting between rounds (nem_sweep_dev.hpp).  OFF by default -- measured, round 4 (profiles/r04_fused_sweep_*.json):
+    // a meeting of 79-241 blocks costs 3-3.5 us on the in-kernel clock whichever way it is built (one counter: 79
+    // same-address atomics; one word per block + a wave-wide poll: a store's way to the other XCDs and two polls), a
+    // 2-round sweep needs two of them, and a launch boundary with its prologue is no dearer: 20 000 x 500 0.0391 vs
+    // 0.0370 ms per EM iteration, 50 000 x 1 000 0.0512 vs 0.0477, 200 000 x 5 000 0.1227 vs 0.1247.
+    // fused_rounds: rounds per such launch (NEM_MI355X_FUSED_ROUNDS, at most kFusedMaxRounds; the pipelined loop takes
+    // min(4, .): its loop control looks at four slots).  fused_sweep goes off for good when a launch's blocks did not all
+    // meet (kFusedFailed: the grid was not resident as a whole).
+    bool fused_sweep = false; int fused_rounds = 4; int n_fused_failed = 0, n_fused = 0;
     double* exp_tab = nullptr; float exp_beta = 0.0f; bool exp_ready = false;   // SweepArgs::exp_tab for cfg.beta
+    int exp_need = kExpTabGlobal;        // entries a context of this graph can index: 1 + the largest row sum of |weights| (set_graph)
     // ... but not all iterations are alike: the first ones after a start move many labels and tend to need the
     // extra round, the later ones almost never do.  The first deep_iters iterations of a run get round_batch rounds;
     // an iteration further on whose sweep the host had to finish moves the mark (it is kept across restarts: the
@@ -240,9 +247,11 @@ struct nemgpu_engine {
     int* ctrl() const { return flags_dev; }
     int* iter_flags() const { return flags_dev + C_WORDS; }
     int* round_flags(int r) const { return flags_dev + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
-    size_t flag_words() const { return C_WORDS + FLAG_ITER_STRIDE + (size_t)kRoundCap * (FLAG_ROUND_STRIDE + 1); }
-    // k_sweep_fused: where the blocks of a launch meet after its round r (zeroed with the round flags)
-    unsigned* round_bar(int r) const { return reinterpret_cast<unsigned*>(flags_dev + C_WORDS + FLAG_ITER_STRIDE + kRoundCap * FLAG_ROUND_STRIDE + (r % kRoundCap)); }
+    size_t flag_words() const { return C_WORDS + FLAG_ITER_STRIDE + (size_t)kRoundCap * FLAG_ROUND_STRIDE; }   // what the host mirrors
+    // k_sweep_fused: the words through which the blocks of a launch meet between rounds (behind the mirrored part;
+    // zeroed with the round flags ahead of every sweep)
+    size_t flag_alloc_words() const { return flag_words() + 2 * (size_t)kFusedMaxBlocks; }
+    unsigned* meet_words() const { return reinterpret_cast<unsigned*>(flags_dev + flag_words()); }
     const int* h_ctrl() const { return flags_host; }
     const int* h_iter() const { return flags_host + C_WORDS; }
     const int* h_round(int r) const { return flags_host + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
@@ -538,7 +547,7 @@ int alloc_model_buffers(nemgpu_engine* e)
     A(dev_alloc(&e->pkfki, (size_t)k * e->npad)); A(dev_alloc(&e->logpkfki, (size_t)k * e->npad));
     A(dev_alloc(&e->mask, (size_t)k * e->nw64));
     A(dev_alloc(&e->stats, (size_t)k + kd));
-    A(dev_alloc(&e->flags_dev, e->flag_words()));
+    A(dev_alloc(&e->flags_dev, e->flag_alloc_words()));
     return r;
 }
 
@@ -770,9 +779,9 @@ int sweep_launch_rounds(nemgpu_engine* e, SweepCtx& c, int count)
         a.lab_old = e->lab[P]; a.lab_guess = e->lab[P]; a.lab_out = e->lab[Q]; a.lab_out2 = e->lab[R];
         a.tie_cnt_guess = e->tie_cnt[P]; a.tie_cnt_out = e->tie_cnt[Q];
         a.flags = e->round_flags(c.slot_base);
-        a.bar = e->round_bar(c.slot_base);
+        a.bar = e->meet_words();
         a.fused_rounds = count;
-        a.exp_tab = (e->exp_ready && e->exp_beta == a.beta) ? e->exp_tab : nullptr; a.exp_tab_len = kExpTabGlobal;
+        a.exp_tab = (e->exp_ready && e->exp_beta == a.beta) ? e->exp_tab : nullptr; a.exp_tab_len = e->exp_need;
         a.fold_ticket = e->sweep_next + 32;
         a.prev_changed = nullptr;
         a.stop = e->stop_ptr;
@@ -858,7 +867,7 @@ int fused_fallback(nemgpu_engine* e, SweepCtx& c)
     e->fused_sweep = false;
     e->n_fused_failed++;
     drop_graphs(e);                                      // (they hold fused launches)
-    HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * (FLAG_ROUND_STRIDE + 1) * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->round_flags(0), 0, (kRoundCap * FLAG_ROUND_STRIDE + kMeetWords) * sizeof(int), e->stream));
     c.r = 0; c.checked = 0;
     return NEMGPU_OK;
 }
@@ -904,7 +913,7 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, 
         if (c.r % kRoundCap == 0 || c.r % kRoundCap + e->round_batch > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
-            HIPCHK(hipMemsetAsync(e->round_flags(0), 0, kRoundCap * (FLAG_ROUND_STRIDE + 1) * sizeof(int), e->stream));
+            HIPCHK(hipMemsetAsync(e->round_flags(0), 0, (kRoundCap * FLAG_ROUND_STRIDE + kMeetWords) * sizeof(int), e->stream));
             while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
             c.checked = c.r;
         }
@@ -2065,7 +2074,7 @@ int nemgpu_create(nemgpu_engine** out, int n_total, int d, int k, int site_lo, i
     if (const char* g = getenv("NEM_MI355X_ROUNDS")) e->round_batch = std::max(2, std::min(kRoundBatchMax, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_ROUNDS_ITER")) e->rounds_iter = std::max(2, std::min(e->round_batch, atoi(g)));
     e->rounds_iter = std::min(e->rounds_iter, e->round_batch);
-    if (const char* g = getenv("NEM_MI355X_FUSED_SWEEP")) e->fused_sweep = (g[0] != '0');   // 0: one launch per relaxation round
+    if (const char* g = getenv("NEM_MI355X_FUSED_SWEEP")) e->fused_sweep = (g[0] == '1');   // 1: the first rounds of a sweep in one launch
     if (const char* g = getenv("NEM_MI355X_FUSED_ROUNDS")) e->fused_rounds = std::max(2, std::min(kFusedMaxRounds, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FUZZY_CHAINS")) e->fuzzy_chains = std::max(0, std::min(2, atoi(g)));
     if (const char* g = getenv("NEM_MI355X_FAULT_INJECT")) e->fault_inject = !strcmp(g, "fuzzy_pc") ? 1 : 0;
@@ -2393,6 +2402,16 @@ int nemgpu_set_graph(nemgpu_engine* e, const int32_t* ptr, const int32_t* idx, c
     }
     e->nnz = nnz;
     e->has_graph = nnz > 0;
+    {
+        // how far a class context can reach: the largest row sum (what the fused sweep copies of its exp table)
+        double top = 0.0;
+        for (int i = 0; i < e->n; i++) {
+            double sum = 0.0;
+            for (int t = ptr[i]; t < ptr[i + 1]; t++) sum += std::fabs((double)w[t]);
+            if (!(sum <= top)) top = sum;                          // (a NaN weight: the whole table)
+        }
+        e->exp_need = (top < (double)(kExpTabGlobal - 1)) ? std::max(1, (int)top + 2) : kExpTabGlobal;
+    }
     drop_graphs(e);
     return NEMGPU_OK;
 }
@@ -4395,6 +4414,8 @@ int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4])
     out[0] = e->n_fused; out[1] = e->n_fused_failed; out[2] = e->fused_sweep ? 1 : 0; out[3] = 0;
     return NEMGPU_OK;
 }
+
+int nemgpu_sweep_phases(unsigned long long out64[64]) { return out64 && nemk::sweep_phases_read(out64) == 0 ? NEMGPU_OK : NEMGPU_E_FUNCARG; }
 
 int nemgpu_set_stream(nemgpu_engine* e, void* hip_stream)
 {

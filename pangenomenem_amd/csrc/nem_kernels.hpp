@@ -99,8 +99,8 @@ struct SweepArgs {
     // Round t of the launch (t = 0: this block's `flags`, `lab_guess`, `lab_out` as above) writes flag slot t
     // (FLAG_ROUND_STRIDE ints further on each) and the label buffer lab_out (t even) / lab_out2 (t odd) -- exactly what
     // `fused_rounds` separate launches would have written, so that the loop control and the host go on from there if the
-    // rounds were not enough.  Between two rounds the blocks meet on bar[t] (arrivals in the low half, blocks that
-    // changed something in the high half; zero before the sweep) and re-read only the labels of their sites'
+    // rounds were not enough.  Between two rounds the blocks meet through bar[2][kFusedMaxBlocks] (one word per block
+    // and round parity, see fused_meet; zero before the sweep) and re-read only the labels of their sites'
     // lower-indexed neighbours in OTHER blocks; a site whose inputs did not change keeps its label without an evaluation.
     int fused_rounds;
     uint8_t* lab_out2;
@@ -108,6 +108,9 @@ struct SweepArgs {
     // exp((double)beta * (double)(float)m), m = 0 .. exp_tab_len - 1, made once per beta by k_exp_table with the device
     // exp the sweep itself would call (nullptr: the block computes the first entries itself)
     const double* exp_tab; int exp_tab_len;
+    // development probe (NEM_MI355X_SWEEP_PROF=1): the 100 MHz clock at the phase boundaries of a fused launch, first and
+    // last block (nemgpu_sweep_phases)
+    unsigned long long* prof;
 };
 // bits of a round's FLAG_CHANGED word besides bit 0
 constexpr int kFusedFailed = 1 << 28;   // k_sweep_fused: a block gave up waiting for the others (not every block resident?):
@@ -192,6 +195,7 @@ void launch_sweep(const SweepArgs& a, bool ncem, hipStream_t s);
 // blocks a launch of launch_sweep would use for n_local sites (what decides whether the fused form may be used)
 int sweep_grid_blocks(int n_local, int K);
 bool sweep_fused_has_instance(int K);
+int sweep_phases_read(unsigned long long* out64);       // the probe's stamps of the last fused launch (64 words), or -1
 void launch_exp_table(float beta, double* tab, int len, hipStream_t s);   // SweepArgs::exp_tab (recordable)
 // one NCEM relaxation round and the M-step counts (of the partition whose class masks exist already) in ONE launch;
 // returns false when the shape has no such kernel (2 <= K <= 5, fewer than 65 536 families, not recordable)

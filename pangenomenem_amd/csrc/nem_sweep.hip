@@ -80,8 +80,20 @@ int sweep_grid_blocks(int n_local, int K)
     return (n_local + bs - 1) / bs;
 }
 
-static bool launch_sweep_fused(const SweepArgs& a, int bs, bool big, dim3 grid, hipStream_t s)
+static unsigned long long* g_prof_dev = nullptr;
+int sweep_phases_read(unsigned long long* out64)
 {
+    if (g_prof_dev == nullptr) return -1;
+    return hipMemcpy(out64, g_prof_dev, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+static bool launch_sweep_fused(const SweepArgs& a0, int bs, bool big, dim3 grid, hipStream_t s)
+{
+    SweepArgs a = a0;
+    static const bool prof = getenv("NEM_MI355X_SWEEP_PROF") && getenv("NEM_MI355X_SWEEP_PROF")[0] == '1';
+    if (prof && g_prof_dev == nullptr) { if (hipMalloc(&g_prof_dev, 64 * sizeof(unsigned long long)) != hipSuccess) g_prof_dev = nullptr; }
+    a.prof = prof ? g_prof_dev : nullptr;
+    if (a.prof != nullptr) (void)hipMemsetAsync(a.prof, 0, 64 * sizeof(unsigned long long), s);
 #define NEM_SF(KT_) case KT_:                                                                     \
         if (big) hipLaunchKernelGGL((k_sweep_fused<KT_, 1024>), grid, dim3(bs), 0, s, a);        \
         else hipLaunchKernelGGL((k_sweep_fused<KT_, 256>), grid, dim3(bs), 0, s, a);             \

@@ -267,6 +267,18 @@ constexpr int kTabShort = 1 << 30;                       // in a round's FLAG_NT
 constexpr int kFuzzyWaves = 4;                          // chains (waves) per block of the fuzzy M-step's chain kernels
 constexpr int kInnerCap = 64;                            // block-local iterations per round (any cap is exact)
 
+// sum over the 64 lanes, in every lane (data-parallel-primitive adds, no LDS)
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // A label byte of another block as that block published it between two rounds of ONE launch (k_sweep_fused): the
 // aligned word it sits in, by an agent-scope load that no cache of this CU answers (MI355X_MICROARCH.md, inter-workgroup
 // visibility: the producers' stores are agent-scope word stores, drained before their block's arrival on the barrier)
@@ -276,31 +288,41 @@ __device__ __forceinline__ int label_coherent(const uint8_t* buf, int j)
     return (int)((w >> (8 * (j & 3))) & 0xFFu);
 }
 
-// The meeting of a fused launch's blocks between two relaxation rounds.  Every wave of the block has waited for its
-// stores (vmcnt(0)); one lane adds the block's arrival -- and, in the high half, whether the block changed a label --
-// to the round's word and polls it until every block is in; bounded (100 MHz clock): a block that waits longer than
-// kFusedWaitTicks gives up and reports it (-1), so that the grid always drains.  Returns the number of blocks that
-// changed something, the same value in every block.
+// The meeting of a fused launch's blocks between two relaxation rounds.  No counter: 79 arrivals on one word are 79
+// same-address atomics, served one after the other (~45 ns each: 3-4.5 us per meeting, measured with the in-kernel
+// clock) -- every block has a word of its own instead, words[parity of the round][block] = (round + 1) << 1 | "this
+// block changed a label", written by one agent-scope store once every wave of the block has waited for its label
+// stores (vmcnt(0)) and the block has met; the block's first wave then polls ALL blocks' words, one load instruction
+// per 64 blocks, until every word carries this round.  Two parities: a block can reach the next meeting while a slow
+// one is still reading this one's words, never the one after (it would need the slow block's arrival).  The words are
+// zero before the sweep.  Bounded (100 MHz clock): a block that waits longer than kFusedWaitTicks gives up and
+// reports it (-1), so that the grid always drains.  Returns the number of blocks that changed something, the same
+// value in every block.
 constexpr unsigned long long kFusedWaitTicks = 400000ull;      // 4 ms
-__device__ __forceinline__ int fused_meet(unsigned* word, int nblk, bool blk_changed)
+__device__ __forceinline__ int fused_meet(unsigned* words, int nblk, int rnd, bool blk_changed, int bx)
 {
     __shared__ int s_meet;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned mine = 1u | (blk_changed ? 0x10000u : 0u);
-        unsigned v = __hip_atomic_fetch_add(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
-        int res = 0;
-        if ((int)(v & 0xFFFFu) != nblk) {
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                __builtin_amdgcn_s_sleep(2);
-                v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(v & 0xFFFFu) == nblk) break;
-                if (wall_clock64() - t0 > kFusedWaitTicks) { res = -1; break; }
+    if (threadIdx.x < 64) {
+        unsigned* w = words + (rnd & 1) * kFusedMaxBlocks;
+        const unsigned want = (unsigned)(rnd + 1);
+        if (threadIdx.x == 0) __hip_atomic_store(&w[bx], (want << 1) | (blk_changed ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        int total = 0;
+        for (;;) {
+            bool ok = true;
+            int chg = 0;
+            for (int b = threadIdx.x; b < nblk; b += 64) {
+                const unsigned v = __hip_atomic_load(&w[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (v >> 1) == want;
+                chg += (int)(v & 1u);
             }
+            if (__all(ok)) { total = wave_sum_i32(chg); break; }
+            if (__any(wall_clock64() - t0 > kFusedWaitTicks)) { total = -1; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        s_meet = res < 0 ? -1 : (int)(v >> 16);
+        if (threadIdx.x == 0) s_meet = total;
     }
     __syncthreads();
     return s_meet;
@@ -314,6 +336,9 @@ template <int KT, bool NCEM, int BS, bool LIBC = false, bool FUSED = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, const int nblk)
 {
     static_assert(!FUSED || (NCEM && !LIBC), "the fused rounds exist for NCEM without the libc tie stream");
+#define NEM_SWEEP_STAMP(i_) do { if (FUSED && a.prof != nullptr && threadIdx.x == 0 && (bx == 0 || bx == nblk - 1) && (i_) < 32) \
+        a.prof[(bx == 0 ? 0 : 32) + (i_)] = wall_clock64(); } while (0)
+    NEM_SWEEP_STAMP(0);
     int fold_hint = 0;
     if (a.stop != nullptr) {
         static_assert(C_STOP == 0 && C_FOLD == 1, "one 8-byte load");
@@ -369,6 +394,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     } else if (NCEM && a.use_nei && !skip && threadIdx.x < 64) s_exp[threadIdx.x] = exp((double)a.beta * (double)(float)threadIdx.x);
     int* rflags = a.flags;                               // this round's flag slot (a fused launch moves on slot by slot)
     __syncthreads();
+    NEM_SWEEP_STAMP(1);
 
     if (NCEM) {
     // ------------------------------------------------------------------------------------------
@@ -534,6 +560,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         if (tab_short) atomicOr(&rflags[FLAG_NTIES], kTabShort);
     }
     if (!FUSED) break;
+    NEM_SWEEP_STAMP(2 + 4 * rnd);
     // ---- fused launch: publish this round's labels, meet the other blocks, look at what they changed
     // (the block's labels go out as whole words by agent-scope stores: what label_coherent reads on the other side)
     if ((int)threadIdx.x < spb / 4 && bx * spb + 4 * (int)threadIdx.x < a.n_local)
@@ -542,7 +569,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     if (rnd == n_rounds - 1) break;                      // the launch's last round reports like a round of its own (below)
     {
         const int blk_changed = __syncthreads_or(changed ? 1 : 0);
-        const int total = fused_meet(a.bar + rnd, nblk, blk_changed != 0);
+        NEM_SWEEP_STAMP(3 + 4 * rnd);
+        const int total = fused_meet(a.bar, nblk, rnd, blk_changed != 0, bx);
+        NEM_SWEEP_STAMP(4 + 4 * rnd);
         if (total < 0) { fused_failed = true; break; }
         if (total == 0) break;                           // nothing changed anywhere: this round's output is the fixed point
         // the round changed something: its slot says so; the next one takes the next slot and the other buffer
@@ -561,6 +590,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
                 if (nl != fl[u]) { fl[u] = nl; dirty = true; }
             }
         }
+        NEM_SWEEP_STAMP(1 + 4 * rnd);                    // (rnd has moved on: the slot behind the meeting's)
     }
     }
     if (FUSED && fused_failed) {
@@ -678,6 +708,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
             if (post_ctrl) ctrl_logic(a.post_ctrl);
         }
     }
+    NEM_SWEEP_STAMP(31);
+#undef NEM_SWEEP_STAMP
 }
 
 }  // namespace nemk
