@@ -74,12 +74,18 @@ def parse_args(argv=None):
     ap.add_argument("--algo", default="ncem")
     ap.add_argument("--disper", default=None, help="dispersion model (default sk_, BASELINE's; skd for --k != 3)")
     ap.add_argument("--spectrum", default="ushape", choices=["ushape", "latent3"])
+    ap.add_argument("--weights", default="small", choices=["small", "coverage", "adjacency"],
+                    help="edge weights of the contiguity graph: small = integers 1..8 (SURVEY.md 8d); coverage = integers "
+                         "uniform in 1..D, the range of what PPanGGOLiN itself writes (ppanggolin.py:866-878: the organisms "
+                         "carrying the adjacency); adjacency = such counts with a pangenome graph's structure (a family's "
+                         "weights add up to at most twice its organisms: synth.contiguity_graph)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak", "replicas"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: host-staged collectives, several ranks may share one GPU (rehearsal only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the `also` block (replicas, 200 000 x 5 000)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `also` block (N = 1: coverage weights, 64 problems in lock "
+                    "step, 200 000 x 5 000, 256 whole chunks; N > 1: replicas, 200 000 x 5 000)")
     ap.add_argument("--extras-strong-shape", default="200000x5000", help="families x organisms of the `also` block's strong-scaling problem")
     ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
     ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
@@ -115,14 +121,16 @@ def self_launch(args):
 # ----------------------------------------------------------------------------------------------------------------
 # workloads
 # ----------------------------------------------------------------------------------------------------------------
-def make_workload(n, d, k, spectrum, seed, ksweep=False):
+def make_workload(n, d, k, spectrum, seed, ksweep=False, weights="small"):
     """(x, nei, prop, center, disp, disper, description)"""
     from pangenomenem_amd import synth
-    nei = synth.contiguity_graph(n, seed)
+
+    def graph(x):
+        return synth.contiguity_graph(n, seed, weights=weights, d=d, counts=x.sum(axis=1) if weights == "adjacency" else None)
     if ksweep:
         x, _ = synth.grouped_pa_matrix(n, d, 5, groups=10)
         prop, center, disp = synth.kclass_init(x, k)
-        return x, nei, prop, center, disp, "skd", "10-latent-group matrix (SURVEY.md 8d, C5), deterministic K-class .m"
+        return x, graph(x), prop, center, disp, "skd", "10-latent-group matrix (SURVEY.md 8d, C5), deterministic K-class .m"
     if spectrum == "ushape":
         x, _ = synth.ushaped_pa_matrix(n, d, seed)
         what = "U-shaped family-frequency spectrum (Beta(0.3, 0.3) per family)"
@@ -130,7 +138,7 @@ def make_workload(n, d, k, spectrum, seed, ksweep=False):
         x, _ = synth.bernoulli_pa_matrix(n, d, seed)
         what = "3 latent classes P/S/C 0.30/0.20/0.50 at p = 0.97/0.5/0.03 (SURVEY.md 8d)"
     prop, center, disp = synth.default_init(d)
-    return x, nei, prop, center, disp, "sk_", what + ", default .m init"
+    return x, graph(x), prop, center, disp, "sk_", what + ", default .m init"
 
 
 def whole_iteration_bytes(n, d, k, nnz):
@@ -252,7 +260,7 @@ def pmc_traffic(kernel, n_loc, d):
     (profiles/r0N_pmc_density.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this very command,
     FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, checked with a known-size read).  Only valid
     for the workload it was measured on; null otherwise."""
-    for name in ("r03_pmc_density.json", "r02_pmc_density.json", "r01_pmc_density.json"):
+    for name in ("r04_pmc_kernels.json", "r03_pmc_density.json", "r02_pmc_density.json", "r01_pmc_density.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -268,7 +276,8 @@ def rocprof_average_ms(kernel, n_loc, d):
     """the committed `rocprofv3 --kernel-trace --stats` average of this kernel on this workload (profiles/
     r03_kernel_averages.json, written by profiles/summarize.py from the kernel-stats CSVs), or null"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_kernel_averages.json")) as f:
+        name = "r04_kernel_averages.json" if os.path.isfile(os.path.join(ROOT, "profiles", "r04_kernel_averages.json")) else "r03_kernel_averages.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             rec = json.load(f)
         for w in rec.get("workloads", []):
             if w.get("families") == n_loc and w.get("organisms") == d:
@@ -317,6 +326,145 @@ def kernel_probe(eng, reps=50):
         p = eng.profile_density(reps)
         return [dict(kernel=p["kernel"], what="E1: Bernoulli log-density chains", avg_launch_ms=p["density_ms_avg"],
                      algorithmic_bytes_per_launch=p["algorithmic_bytes_per_launch"], launches_timed=p["density_launches"])]
+
+
+def graph_facts(nei, beta):
+    """what the sweep's exp(beta * context) table can serve on this graph: a site whose weight sum is below 64 can only
+    have contexts the 64-entry table holds; the others take it when their three contexts happen to be small integers"""
+    import numpy as np
+    ptr, idx, w = nei
+    rows = np.add.reduceat(np.concatenate([w, [0.0]]), ptr[:-1])[: len(ptr) - 1] if len(w) else np.zeros(len(ptr) - 1)
+    rows = np.where(np.diff(ptr) > 0, rows, 0.0)
+    return dict(max_weight=float(w.max()) if len(w) else 0.0, max_site_weight_sum=float(rows.max()) if len(rows) else 0.0,
+                max_beta_times_weight_sum=float(beta * rows.max()) if len(rows) else 0.0,
+                sites_with_weight_sum_below_64=float((rows < 64).mean()) if len(rows) else 1.0,
+                sites_with_beta_weight_sum_above_88=float((beta * rows > 88.72).mean()) if len(rows) else 0.0)
+
+
+def also_single_gpu(args, k, beta):
+    """The regimes of this path besides the headline's, measured in the same run: the edge weights the
+    reference's caller writes, many problems per launch, the shape where the kernels approach a bandwidth regime, whole
+    chunks host arrays -> host arrays.  Each entry is its own try: a failure is reported, the line still prints."""
+    import numpy as np
+    from pangenomenem_amd import synth
+    also = {}
+    reps = min(args.repeats, 7)
+    # (1) configs[1] with the edge weights the reference's caller writes: counts of organisms, up to D.  Two forms:
+    # "adjacency" (a family's weights add up to at most twice its organisms, as in a pangenome graph: beta * sum(w) stays
+    # below 709, the rows stay finite, the run converges, M = -inf) and "coverage" (uniform in 1..D on every edge: the
+    # sites with three or four heavy edges pass 709, their rows are NaN, ComputeMAP's ties are redrawn in every sweep and
+    # the run never converges -- in the reference as here, tests/golden/cov500_w1500_ncem).
+    for key, wk, what in (("adjacency_weights", "adjacency", "weights = 60-100 % (path) / 1-15 % (chords) of the smaller organism count of the two families"),
+                          ("coverage_weights", "coverage", "weights uniform in 1..500 on every edge")):
+        try:
+            x, nei, prop, center, disp, disper, _ = make_workload(20000, 500, k, "ushape", 2, weights=wk)
+            run = EngineRun(x, nei, k, prop, center, disp, "ncem", beta, "sk_")
+            steps = max(run.cycle, (140 // run.cycle) * run.cycle)
+            blocks, info = run.timed(steps, run.cycle, reps)
+            tf, med = timing_fields(blocks, steps)
+            kern = kernel_probe(run.eng)
+            sweep = [r for r in kern if r["kernel"] == "k_sweep"]
+            also[key] = dict(
+                workload="BASELINE configs[1] shape, " + what + " (ppanggolin.py:866-878)",
+                ms_per_step=tf["ms_per_step"], ms_per_step_min=tf["ms_per_step_min"], ms_per_step_max=tf["ms_per_step_max"],
+                steps=steps, repeats=tf["repeats"], cells_per_sec=20000 * 500 * steps / med, iters_to_converge=info["iters_to_converge"],
+                converged=bool(run.first["converged"]), zero_density_sites=int(run.first["n_zero_density"]),
+                sweep_rounds_per_iteration=info["sweep_rounds_per_iteration"], host_finished_sweeps_timed=info["host_finished_sweeps_timed"],
+                sweep_round_avg_ms=sweep[0]["avg_launch_ms"] if sweep else None, e1_avg_ms=kern[0]["avg_launch_ms"],
+                final_criteria_M_is_minus_inf=bool(np.isneginf(run.first["crit"][3])), graph=graph_facts(nei, beta))
+            run.eng.close()
+        except Exception as exc:
+            also[key] = {"error": repr(exc)}
+    # (2) 64 configs[1]-sized problems in lock step (one launch per EM step for all of them)
+    try:
+        from pangenomenem_amd.engine import NemEngine, Result, profile_density_many
+        import ctypes as C
+        B = 64
+        x0, _ = synth.ushaped_pa_matrix(20000, 500, 100)
+        nei0 = synth.contiguity_graph(20000, 100)
+        prop, center, disp = synth.default_init(500)
+        rng = np.random.default_rng(0)
+        engs = []
+        for p in range(B):                                     # (another sample of organisms per problem: a column shuffle)
+            e = NemEngine(20000, 500, 3)
+            e.set_matrix(np.ascontiguousarray(x0[:, rng.permutation(500)])); e.set_graph(nei0); e.set_params(prop, center, disp)
+            e.configure(algo="ncem", beta=beta, disper="sk_", tie="hash", seed=1)
+            engs.append(e)
+        lib = engs[0].lib
+        handles = (C.c_void_p * B)(*[e._h for e in engs])
+        res = (Result * B)()
+        best = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rc = lib.nemgpu_run_many(handles, B, res)
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError("nemgpu_run_many: status %d" % rc)
+            best = dt if best is None else min(best, dt)
+        iters = sum(r.iters for r in res)
+        e1_ms, e1_bytes = profile_density_many(engs, 30)
+        nnz = int(nei0[0][-1])
+        also["lockstep_64_configs1"] = dict(
+            problems=B, em_iterations=iters, batch_seconds=best, us_per_problem_iteration=best * 1e6 / max(iters, 1),
+            whole_problems_per_sec=B / best, cells_per_sec=iters * 20000 * 500 / best,
+            whole_iteration_algorithmic_GBps=whole_iteration_bytes(20000, 500, 3, nnz) * iters / best / 1e9,
+            e1_launch_ms=e1_ms, e1_algorithmic_bytes_per_launch=e1_bytes, e1_achieved_GBps=e1_bytes / (e1_ms * 1e-3) / 1e9,
+            e1_frac=e1_bytes / (e1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            note="EM only (start + iterations to convergence + final criteria), inputs resident, best of 5 calls of "
+                 "nemgpu_run_many; E1: the 64 members' density kernels in one launch, 30 launches between one pair of HIP events")
+        for e in engs:
+            e.close()
+    except Exception as exc:
+        also["lockstep_64_configs1"] = {"error": repr(exc)}
+    # (3) 200 000 x 5 000 on this one GPU (BASELINE configs[3]'s matrix)
+    try:
+        x, nei, prop, center, disp, disper, _ = make_workload(200000, 5000, k, "ushape", 2)
+        run = EngineRun(x, nei, k, prop, center, disp, "ncem", beta, "sk_")
+        del x
+        steps = max(run.cycle, (40 // run.cycle) * run.cycle)
+        blocks, info = run.timed(steps, run.cycle, min(reps, 5))
+        tf, med = timing_fields(blocks, steps)
+        kern = kernel_probe(run.eng, 20)
+        rows = roofline_block(kern, 200000, 5000, profiled_workload=False)["kernels"]
+        also["single_gpu_200000x5000"] = dict(
+            ms_per_step=tf["ms_per_step"], ms_per_step_min=tf["ms_per_step_min"], ms_per_step_max=tf["ms_per_step_max"], steps=steps,
+            repeats=tf["repeats"], cells_per_sec=200000.0 * 5000 * steps / med,
+            whole_iteration_algorithmic_GBps=whole_iteration_bytes(200000, 5000, 3, int(nei[0][-1])) * steps / med / 1e9,
+            kernels=[{kk: r[kk] for kk in ("kernel", "avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "frac")} for r in rows],
+            e1_frac=rows[0]["frac"], counts_frac=rows[2]["frac"] if len(rows) > 2 else None)
+        run.eng.close()
+    except Exception as exc:
+        also["single_gpu_200000x5000"] = {"error": repr(exc)}
+    # (4) 256 whole chunks, host arrays in, host arrays out (uploads included)
+    try:
+        from pangenomenem_amd.batch import solve_many
+        P = 256
+        x0, _ = synth.ushaped_pa_matrix(20000, 500, 2)
+        nei0 = synth.contiguity_graph(20000, 2)
+        prop, center, disp = synth.default_init(500)
+        rng = np.random.default_rng(1)
+        probs = []
+        for p in range(P):
+            bits = np.packbits(np.ascontiguousarray(x0[:, rng.permutation(500)]), axis=1, bitorder="little")   # 63 bytes per row -> 64
+            rows = np.zeros((bits.shape[0], (bits.shape[1] + 3) // 4 * 4), np.uint8)
+            rows[:, :bits.shape[1]] = bits
+            probs.append((rows.view(np.uint32), nei0, 3, prop, center, disp))
+        solve_many(probs[:64], 8, algo="ncem", beta=beta, disper="sk_")                         # (fills the library's pools)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = solve_many(probs, 8, algo="ncem", beta=beta, disper="sk_")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        if not all(r["status"] == 0 for r in res):
+            raise RuntimeError("a chunk did not solve")
+        also["chunks_256"] = dict(problems=P, workers=8, seconds=best, whole_problems_per_sec=P / best,
+                                  em_iterations=int(sum(r["iters"] for r in res)), cells_per_sec=sum(r["iters"] for r in res) * 1e7 / best,
+                                  note="nemgpu_solve_many: bit rows + graph + parameters uploaded, solved in lock-step groups, labels "
+                                       "and parameters fetched; best of 3 jobs")
+    except Exception as exc:
+        also["chunks_256"] = {"error": repr(exc)}
+    return also
 
 
 def north_star_target(args):
@@ -475,7 +623,8 @@ def main():
         n_tot, d = args.families or 20000, args.organisms or 500
         # (50 000 x 1 000 is BASELINE configs[2]'s problem: the same matrix -- seed 3 -- as the sharded runs and the
         #  north-star block time)
-        x, nei, prop, center, disp, _, what = make_workload(n_tot, d, k, args.spectrum, 3 if (n_tot, d) == (50000, 1000) else 2, ksweep)
+        x, nei, prop, center, disp, _, what = make_workload(n_tot, d, k, args.spectrum, 3 if (n_tot, d) == (50000, 1000) else 2, ksweep,
+                                                            weights=args.weights)
         run = EngineRun(x, nei, k, prop, center, disp, args.algo, beta, args.disper)
         blocks, extra = run.timed(args.steps, args.warmup, args.repeats)
         # kernel durations: HIP events on the engine's stream around strings of launches, on the state the timed region
@@ -584,13 +733,15 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d families x %d organisms, K=%d, beta=0.5, contiguity graph (path + 5%% chords, "
-                            "weights 1..8), %s/%s/pk; %s" % (shape, n_tot, d, k, args.algo, args.disper, what),
+                            "weights %s), %s/%s/pk; %s" % (shape, n_tot, d, k, "1..8" if args.weights == "small" else "1..%d (coverage)" % d,
+                                                           args.algo, args.disper, what),
                 "families_total": n_tot, "families_per_gpu": n_loc, "organisms": d, "K": k, "beta": beta,
                 "cycle_iterations": extra["cycle_iterations"],
                 "parallelism": parallelism,
             },
             "roofline": roofline_block(kernels, n_loc, d, profiled_workload=(args.algo == "ncem" and args.disper == "sk_" and not ksweep
-                                                                              and args.spectrum == "ushape" and not multi)),
+                                                                              and args.spectrum == "ushape" and not multi
+                                                                              and args.weights == "small")),
         }
         out["roofline"]["whole_iteration_algorithmic_GBps"] = whole_iteration_bytes(n_tot, d, k, nnz) * steps_total / med / 1e9
         out.update(extra)
@@ -610,6 +761,14 @@ def main():
                 out["north_star_target"] = north_star_target(args)
             except Exception as exc:
                 out["north_star_target"] = {"error": repr(exc)}
+        if not multi and not args.no_extras and not ksweep and args.algo == "ncem":
+            try:
+                run.eng.close()
+            except Exception:
+                pass
+            t_also = time.perf_counter()
+            out["also"] = also_single_gpu(args, k, beta)
+            out["also"]["seconds"] = time.perf_counter() - t_also
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 

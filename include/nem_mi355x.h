@@ -382,6 +382,10 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
    much as the shorter kernels).  avg_ms[3], bytes[3]; which[0] = 1 when E1 is the fused kernel.  The engine's partition
    is not advanced. */
 int nemgpu_profile_kernels(nemgpu_engine* e, int reps, double avg_ms[3], double bytes[3], int which[1]);
+/* E1 (DensBernoulli over the whole matrix, nem_mod.c:619-690) as a lock-step batch launches it: the density kernels of
+   `count` same-shaped engines of one device in ONE launch, `reps` launches back to back between one pair of HIP events.
+   avg_ms: one launch (all members); algorithmic_bytes_per_launch: all members' bit-packed matrices, tables and outputs. */
+int nemgpu_profile_density_many(nemgpu_engine** engines, int count, int reps, double* avg_ms, double* algorithmic_bytes_per_launch);
 /* `reps` in-place all-gathers of the sharded EM's label blocks through the engine's own communicator between one pair
    of HIP events: the cost of ONE of an iteration's two collectives.  Collective over the job's ranks. */
 int nemgpu_rccl_time_allgather(nemgpu_engine* e, uint8_t* buf_dev, int reps, double* avg_ms);

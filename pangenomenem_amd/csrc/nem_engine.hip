@@ -4268,6 +4268,64 @@ int nemgpu_profile_density(nemgpu_engine* e, int reps, double* avg_ms, double* a
     return NEMGPU_OK;
 }
 
+// E1 as a lock-step batch launches it: the density kernels of `count` engines (same shape) zipped into ONE launch
+// (k_density_b, problem = blockIdx.z), `reps` such launches back to back between one pair of HIP events on the first
+// engine's stream.  avg_ms: per launch (all members); bytes: algorithmic bytes of one launch (all members).  The engines
+// must have run (their parameters and tables are what the last M-step left).
+int nemgpu_profile_density_many(nemgpu_engine** engines, int count, int reps, double* avg_ms, double* algorithmic_bytes_per_launch)
+{
+    if (!engines || count <= 0 || reps <= 0) return NEMGPU_E_FUNCARG;
+    nemgpu_engine* lead = engines[0];
+    HIPCHK(hipSetDevice(lead->device));
+    int r;
+    std::vector<Recorder> recs((size_t)count);
+    double bytes = 0.0;
+    for (int m = 0; m < count; m++) {
+        nemgpu_engine* e = engines[m];
+        if (!e || e->device != lead->device) { set_error("profile_density_many: engines of one device"); return NEMGPU_E_FUNCARG; }
+        if ((r = flush_reset(e)) || (r = do_tables(e))) return r;
+        HIPCHK(hipStreamSynchronize(e->stream));
+        set_recorder(&recs[m]);
+        r = do_density(e);
+        set_recorder(nullptr);
+        if (r) return r;
+        if (recs[m].ops.size() != 1) { set_error("profile_density_many: one density launch per engine expected"); return NEMGPU_E_INTERNAL; }
+        const OpRecord& o = recs[m].ops[0]; const OpRecord& o0 = recs[0].ops[0];
+        if (o.kind != o0.kind || o.variant != o0.variant || o.block != o0.block || o.gy != o0.gy || o.nbytes != o0.nbytes) {
+            set_error("profile_density_many: the engines' density launches differ in shape"); return NEMGPU_E_FUNCARG;
+        }
+        bytes += (double)e->n * e->wf * 4.0 + (double)e->k * e->d * 24.0 + (double)e->n * e->k * 12.0;
+    }
+    const OpRecord& o0 = recs[0].ops[0];
+    const int stride = (o0.nbytes + 15) & ~15;
+    const size_t gx_off = (size_t)count * stride, total = gx_off + (((size_t)count * sizeof(int) + 15) & ~(size_t)15);
+    if ((r = zip_reserve(lead, total))) return r;
+    nemgpu_engine::ZipContext* z = zip_context(lead);
+    unsigned max_gx = 0;
+    for (int m = 0; m < count; m++) {
+        memcpy(z->zip_host + (size_t)m * stride, recs[m].ops[0].args, (size_t)o0.nbytes);
+        reinterpret_cast<int*>(z->zip_host + gx_off)[m] = (int)recs[m].ops[0].gx;
+        max_gx = std::max(max_gx, recs[m].ops[0].gx);
+    }
+    HIPCHK(hipMemcpyAsync(z->zip_dev, z->zip_host, total, hipMemcpyHostToDevice, lead->stream));
+    if (!lead->ev0) { HIPCHK(hipEventCreate(&lead->ev0)); HIPCHK(hipEventCreate(&lead->ev1)); }
+    auto once = [&]() {
+        launch_zipped(o0.kind, o0.variant, count, z->zip_dev, stride, reinterpret_cast<const int*>(z->zip_dev + gx_off), max_gx, o0.gy,
+                      o0.block, lead->stream);
+    };
+    once();                                                    // (warm)
+    HIPCHK(hipEventRecord(lead->ev0, lead->stream));
+    for (int i = 0; i < reps; i++) once();
+    HIPCHK(hipEventRecord(lead->ev1, lead->stream));
+    HIPCHK(hipEventSynchronize(lead->ev1));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, lead->ev0, lead->ev1));
+    if (avg_ms) *avg_ms = (double)ms / reps;
+    if (algorithmic_bytes_per_launch) *algorithmic_bytes_per_launch = bytes;
+    return NEMGPU_OK;
+}
+
 // Kernel-duration probe for bench.py's roofline.kernels[]: the three kernels of a solo NCEM iteration -- E1 (with the
 // parameter update when the loop launches it that way), one relaxation round of the E-step sweep, the M-step counts --
 // each launched `reps` times back to back between ONE pair of HIP events on the engine's stream (an event pair per

@@ -101,6 +101,7 @@ def load_library():
     lib.nemgpu_set_fast_forward.argtypes = [vp, C.c_int]
     lib.nemgpu_set_graph_policy.argtypes = [vp, C.c_int]
     lib.nemgpu_graph_counters.argtypes = [vp, ip]
+    lib.nemgpu_profile_density_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.nemgpu_sweep_counters.argtypes = [vp, ip]
     lib.nemgpu_rccl_ranks.argtypes = [vp]
     lib.nemgpu_rccl_selftest.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -467,6 +468,18 @@ def calibrate_fetch(nbytes=1 << 30, reps=3):
     rc = load_library().nemgpu_calibrate_fetch(int(nbytes), int(reps))
     if rc != 0:
         raise NemGpuError("nemgpu_calibrate_fetch failed (status %d)" % rc)
+
+
+def profile_density_many(engines, reps=30):
+    """E1 of a lock-step batch: the engines' density kernels in ONE launch, `reps` launches between one pair of HIP
+    events.  Returns (ms per launch, algorithmic bytes per launch)."""
+    lib = engines[0].lib
+    handles = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    ms, by = C.c_double(0), C.c_double(0)
+    rc = lib.nemgpu_profile_density_many(handles, len(engines), int(reps), C.byref(ms), C.byref(by))
+    if rc != 0:
+        raise NemGpuError("nemgpu_profile_density_many failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
+    return ms.value, by.value
 
 
 def solve(x, nei, k, prop, center, disp, device=0, fast_forward=None, **cfg):

@@ -71,7 +71,7 @@ def grouped_pa_matrix(n, d, seed, groups=10, p_in=0.95, p_out=0.05):
     return x, z
 
 
-def contiguity_graph(n, seed, chord_frac=0.05, wmax=8, weights="small", d=None):
+def contiguity_graph(n, seed, chord_frac=0.05, wmax=8, weights="small", d=None, counts=None):
     """Path i<->i+1 in index order plus n*chord_frac random chords, undirected, every edge listed
     from both endpoints, integer weights uniform in [1, wmax] (keeps beta*sum(w) far below the
     reference's exp overflow at 709, SURVEY.md §0-3).  Returns CSR (ptr int32[n+1], idx int32, w float32);
@@ -79,13 +79,21 @@ def contiguity_graph(n, seed, chord_frac=0.05, wmax=8, weights="small", d=None):
     weights="coverage": the weights PPanGGOLiN itself writes (ppanggolin.py:866-878: the number of selected
     organisms that carry the adjacency, the division by len(organisms) is commented out) -- integers uniform in
     [1, d]; with them beta*sum(w) passes 88 (the float exp of criterion Z overflows: M = -inf) and, on sites whose
-    neighbours agree, 709 (the double exp of the site's own factor: NaN rows), as SURVEY.md Appendix B records."""
+    neighbours agree, 709 (the double exp of the site's own factor: NaN rows), as SURVEY.md Appendix B records.
+    weights="adjacency": coverage weights with the structure a pangenome graph gives them -- an adjacency is carried by
+    at most the organisms that carry BOTH families, and an occurrence of a family has one neighbour on either side, so a
+    family's weights add up to at most twice its number of organisms: a path edge gets 60-100 % of min(count_i, count_j),
+    a chord 1-15 % of it (counts = the families' organism counts, the matrix's row sums).  beta * sum(w) then stays
+    below 709 for up to ~600 organisms at beta = 0.5 (finite rows, the run converges) and far above 88 (M = -inf)."""
     if weights == "coverage":
         if d is None:
             raise ValueError("weights='coverage' needs the number of organisms d")
         wmax = int(d)
+    elif weights == "adjacency":
+        if counts is None:
+            raise ValueError("weights='adjacency' needs the families' organism counts")
     elif weights != "small":
-        raise ValueError("weights must be 'small' or 'coverage'")
+        raise ValueError("weights must be 'small', 'coverage' or 'adjacency'")
     rng = np.random.Generator(np.random.PCG64(seed + 7919))
     src = [np.arange(n - 1, dtype=np.int64)]
     dst = [np.arange(1, n, dtype=np.int64)]
@@ -102,6 +110,11 @@ def contiguity_graph(n, seed, chord_frac=0.05, wmax=8, weights="small", d=None):
     first.sort()
     s, t = s[first], t[first]
     w = rng.integers(1, wmax + 1, size=len(s)).astype(np.float32)
+    if weights == "adjacency":
+        cmin = np.minimum(np.asarray(counts)[s], np.asarray(counts)[t]).astype(np.float64)
+        u = rng.random(len(s))
+        share = np.where(np.abs(s - t) == 1, 0.6 + 0.4 * u, 0.01 + 0.14 * u)
+        w = np.maximum(1.0, np.floor(share * cmin)).astype(np.float32)
     # both directions, stable by insertion order
     us = np.concatenate([s, t]); ut = np.concatenate([t, s]); uw = np.concatenate([w, w])
     order = np.concatenate([np.arange(len(s)) * 2, np.arange(len(s)) * 2 + 1])
