@@ -91,6 +91,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
     ap.add_argument("--ns-cpu-iters", type=int, default=4, help="reference iterations timed at 50 000 x 1 000")
     ap.add_argument("--ns-steps", type=int, default=220, help="GPU iterations per block at 50 000 x 1 000")
+    ap.add_argument("--phase-timeout", type=float, default=300.0,
+                    help="N > 1: seconds a phase (a mode's measurement) may take before the job's watchdog ends it and rank 0 "
+                         "prints the record it has")
+    ap.add_argument("--watchdog-selftest", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -505,6 +509,54 @@ def north_star_target(args):
 # ----------------------------------------------------------------------------------------------------------------
 # multi-rank pieces
 # ----------------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """First-run safety of the multi-rank modes: every phase of an N > 1 run has a deadline.  A phase
+    that passes it -- a collective that never completes, a wedged replay -- ends the job from a helper thread: rank 0
+    prints the line it has (what was measured before the phase, or a line that says what hung) and every rank leaves
+    with os._exit, so that the launcher returns and the driver has a record.  The main thread is not needed for any of
+    it: it may be stuck inside a C call."""
+
+    def __init__(self, json_fd, rank, enabled=True):
+        import threading
+        self.json_fd, self.rank = json_fd, rank
+        self.deadline, self.name = None, ""
+        self.fallback = None
+        self.lock = threading.Lock()
+        if enabled:
+            t = threading.Thread(target=self._watch, daemon=True)
+            t.start()
+
+    def phase(self, name, seconds):
+        with self.lock:
+            self.name, self.deadline = name, (time.monotonic() + seconds if seconds else None)
+
+    def done(self):
+        self.phase("", None)
+
+    def set_fallback(self, line):
+        with self.lock:
+            self.fallback = dict(line) if line is not None else None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                name, line = self.name, self.fallback
+            if not late:
+                continue
+            if self.rank == 0:
+                if line is None:
+                    line = {"metric": "em_family_x_organism_cells_per_sec", "value": None, "unit": "cells/s", "higher_is_better": True,
+                            "data": "synthetic", "vs_baseline": None}
+                line["error"] = "phase %r did not finish within its deadline; the job was ended by its watchdog" % name
+                try:
+                    os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+                except OSError:
+                    pass
+            os._exit(0)
+
+
 class Ranks:
     """barrier + device synchronisation + maximum over ranks, the bracket of every timed block"""
 
@@ -593,8 +645,54 @@ def replicas_run(args, ranks, n, d, k, beta, steps, warmup, repeats):
     return blocks, info, kernels, solves, what
 
 
+def assemble_line(args, world, k, beta, n_tot, n_loc, d, nnz, blocks, extra, kernels, scaling, parallelism, what, ksweep, multi):
+    """the JSON record of a finished measurement (rank 0)"""
+    tf, med = timing_fields(blocks, args.steps)
+    cells_per_s = n_tot * d * args.steps / med
+    shape = ("BASELINE configs[4] (K sweep)" if (n_tot, d) == (20000, 500) and args.disper == "skd" else "custom model") \
+        if ksweep else (SHAPES.get((n_tot, d), "custom shape") if args.disper == "sk_" else "custom model")
+    out = {
+        "metric": "em_family_x_organism_cells_per_sec",
+        "value": cells_per_s,
+        "unit": "cells/s",
+        "em_iterations_per_sec": args.steps / med,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": tf["ms_per_step"],
+        "repeats": tf["repeats"], "ms_per_step_min": tf["ms_per_step_min"], "ms_per_step_max": tf["ms_per_step_max"],
+        "timed_region_s": tf["timed_region_s"],
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": "f32 chains with f64 intermediates (reference arithmetic); int32 popcounts in the M-step",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d families x %d organisms, K=%d, beta=0.5, contiguity graph (path + 5%% chords, "
+                        "weights %s), %s/%s/pk; %s" % (shape, n_tot, d, k, "1..8" if args.weights == "small" else
+                                                       ("1..%d (%s)" % (d, args.weights)), args.algo, args.disper, what),
+            "families_total": n_tot, "families_per_gpu": n_loc, "organisms": d, "K": k, "beta": beta,
+            "cycle_iterations": extra.get("cycle_iterations"),
+            "parallelism": parallelism,
+        },
+        "roofline": roofline_block(kernels, n_loc, d, profiled_workload=(args.algo == "ncem" and args.disper == "sk_" and not ksweep
+                                                                          and args.spectrum == "ushape" and not multi
+                                                                          and args.weights == "small")),
+    }
+    out["roofline"]["whole_iteration_algorithmic_GBps"] = whole_iteration_bytes(n_tot, d, k, nnz) * args.steps / med / 1e9
+    out.update(extra)
+    return out, cells_per_s
+
+
 def main():
     args = parse_args()
+    if args.watchdog_selftest:                    # (tests/test_bench_guard.py: a phase that never ends)
+        json_fd = os.dup(1)
+        wd = Watchdog(json_fd, 0)
+        wd.set_fallback({"metric": "em_family_x_organism_cells_per_sec", "value": 1.0, "fallback_reason": "selftest"})
+        wd.phase("selftest", 1.0)
+        time.sleep(60)
+        raise SystemExit(9)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     # stdout carries exactly ONE line, the JSON record: libraries that print banners to fd 1 (RCCL prints its
@@ -617,6 +715,8 @@ def main():
     if multi and ksweep:
         raise SystemExit("the multi-GPU modes benchmark K = 3")
     extra, also = {}, None
+    x = nei = prop = center = disp = run = None
+    wd = Watchdog(json_fd, rank, enabled=multi and world > 1)
 
     if not multi:
         nem_build.build()                          # no-op when the in-tree library is up to date
@@ -632,7 +732,6 @@ def main():
         kernels = kernel_probe(run.eng)
         n_loc, nnz = n_tot, int(nei[0][-1])
         scaling, parallelism = "weak", "1 GPU"
-        steps_total = args.steps
     else:
         import torch
         import torch.distributed as dist
@@ -641,6 +740,7 @@ def main():
         torch.cuda.set_device(device)
         if "RANK" not in os.environ:              # plain `python bench.py --dist`: a 1-rank group
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        wd.phase("process group", args.phase_timeout)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -650,26 +750,75 @@ def main():
         dist.barrier()
         ranks = Ranks(args, rank, world, device)
         what = make_workload(64, 32, 3, args.spectrum, 1)[6]
+        replicas_line = None
+
+        def replicas_measure(steps, warmup, repeats):
+            n_r, d_r = args.families or 20000, args.organisms or 500
+            if args.scaling != "replicas":
+                n_r, d_r = 20000, 500
+            b, info, kern, solves, w = replicas_run(args, ranks, n_r, d_r, k, beta, steps, warmup, repeats)
+            info = dict(info)
+            info.update(whole_solves_per_block=solves, rccl_ranks=0, backend=args.backend,
+                        collective=dict(what="none on the data path (independent problems); a barrier brackets each timed block",
+                                        per_iteration=0, per_iteration_ms=0.0))
+            par = ("%d independent %d x %d problems, one per GPU, no collective on the data path (the reference's own "
+                   "parallel form: one NEM problem per organism chunk, ppanggolin.py:1039-1095)" % (world, n_r, d_r))
+            return n_r, d_r, b, info, kern, solves, w, par
+
         if args.scaling == "replicas":
-            n_loc, d = args.families or 20000, args.organisms or 500
+            wd.phase("replicas", args.phase_timeout)
+            n_loc, d, blocks, extra, kernels, solves, what, parallelism = replicas_measure(args.steps, args.warmup, args.repeats)
             n_tot = n_loc * world
-            blocks, extra, kernels, solves, what = replicas_run(args, ranks, n_loc, d, k, beta, args.steps, args.warmup, args.repeats)
             nnz = int(2.1 * n_tot)
-            extra.update(whole_solves_per_block=solves, rccl_ranks=0, backend=args.backend,
-                         collective=dict(what="none on the data path (independent problems); a barrier brackets each timed block",
-                                         per_iteration=0, per_iteration_ms=0.0))
             scaling = "weak"
-            parallelism = ("%d independent %d x %d problems, one per GPU, no collective on the data path (the reference's own "
-                           "parallel form: one NEM problem per organism chunk, ppanggolin.py:1039-1095)" % (world, n_loc, d))
         else:
+            # The mode with NO collective on the data path goes first (N > 1): it cannot hang on a collective, and its
+            # record is what rank 0 prints if the sharded mode -- whose native RCCL path has never run with more than one
+            # rank on the development box -- fails or passes its deadline.
+            if world > 1 and not args.no_extras:
+                saved = args.steps
+                try:
+                    wd.phase("replicas (also)", args.phase_timeout)
+                    st2 = max(args.steps, 140)
+                    args.steps = st2
+                    n_r, d_r, b2, i2, kern2, solves, w2, par2 = replicas_measure(st2, 14, min(args.repeats, 9))
+                    tf2, med2 = timing_fields(b2, st2)
+                    also = {"replicas_20000x500_per_gpu": dict(
+                        value=world * n_r * d_r * st2 / med2, unit="cells/s", ms_per_step=tf2["ms_per_step"],
+                        whole_solves_per_sec=solves / med2, scaling="weak", collectives_per_iteration=0,
+                        repeats=tf2["repeats"], ms_per_step_min=tf2["ms_per_step_min"], ms_per_step_max=tf2["ms_per_step_max"],
+                        note="N independent configs[1]-sized problems, one per GPU; the N = 1 default line of this script is the one-GPU figure")}
+                    if rank == 0:
+                        replicas_line, _ = assemble_line(args, world, k, beta, n_r * world, n_r, d_r, int(2.1 * n_r * world), b2, i2, kern2,
+                                                         "weak", par2, w2, False, True)
+                        replicas_line["fallback_reason"] = ("the sharded mode (--scaling %s) did not finish: this is the replicas "
+                                                            "measurement of the same run" % args.scaling)
+                        wd.set_fallback(replicas_line)
+                except Exception as exc:
+                    also = {"replicas_20000x500_per_gpu": {"error": repr(exc)}}
+                finally:
+                    args.steps = saved
             if args.scaling == "strong":
                 n_tot, d = args.families or 50000, args.organisms or 1000
                 seed = 3 if (n_tot, d) == (50000, 1000) else 2
             else:
                 d = args.organisms or 500
                 n_tot, seed = (args.families or 20000) * world, 2
-            blocks, extra, kernels, n_loc, solo = sharded_run(args, ranks, n_tot, d, k, beta, seed, args.steps, args.warmup,
-                                                              args.repeats, want_solo=(world > 1 and args.scaling == "strong"))
+            wd.phase("sharded EM (%s scaling)" % args.scaling, args.phase_timeout)
+            fallback_reason = None
+            try:
+                blocks, extra, kernels, n_loc, solo = sharded_run(args, ranks, n_tot, d, k, beta, seed, args.steps, args.warmup,
+                                                                  args.repeats, want_solo=(world > 1 and args.scaling == "strong"))
+            except Exception as exc:
+                # every rank that got an exception here takes the same second route: all collectives through
+                # torch.distributed (a rank that did NOT get one is stuck in a collective; the deadline ends the job)
+                fallback_reason = "native RCCL path failed (%r): collectives through torch.distributed" % (exc,)
+                os.environ["NEM_DIST_NATIVE"] = "0"
+                wd.phase("sharded EM (%s scaling), torch collectives" % args.scaling, args.phase_timeout)
+                blocks, extra, kernels, n_loc, solo = sharded_run(args, ranks, n_tot, d, k, beta, seed, args.steps, args.warmup,
+                                                                  args.repeats, want_solo=(world > 1 and args.scaling == "strong"))
+            if fallback_reason:
+                extra["fallback_reason"] = fallback_reason
             nnz = int(2.1 * n_tot)
             scaling = args.scaling if world > 1 else "weak"
             if solo is not None:
@@ -679,74 +828,38 @@ def main():
             parallelism = ("families sharded over %d GPUs in contiguous blocks (%s scaling); per EM iteration two RCCL "
                            "all-gathers of the label blocks, the second also carrying the ranks' int32 M-step statistics"
                            % (world, scaling)) if world > 1 else "1 GPU through the sharded driver"
-            # ---- what else N GPUs can do with this path, in the same run
-            if world > 1 and not args.no_extras:
-                also = {}
-                try:
-                    b2, i2, _, solves, _ = replicas_run(args, ranks, 20000, 500, k, beta, max(args.steps, 140), 14, min(args.repeats, 9))
-                    st2 = max(args.steps, 140)
-                    tf2, med2 = timing_fields(b2, st2)
-                    also["replicas_20000x500_per_gpu"] = dict(
-                        value=world * 20000 * 500 * st2 / med2, unit="cells/s", ms_per_step=tf2["ms_per_step"],
-                        whole_solves_per_sec=solves / med2, scaling="weak", collectives_per_iteration=0,
-                        repeats=tf2["repeats"], ms_per_step_min=tf2["ms_per_step_min"], ms_per_step_max=tf2["ms_per_step_max"],
-                        note="N independent configs[1]-sized problems, one per GPU; the N = 1 default line of this script is the one-GPU figure")
-                except Exception as exc:
-                    also["replicas_20000x500_per_gpu"] = {"error": repr(exc)}
-                n3, d3 = (int(v) for v in args.extras_strong_shape.lower().split("x"))
-                if (n_tot, d) != (n3, d3):
-                    try:
-                        st3 = 60
-                        b3, f3, _, _, solo3 = sharded_run(args, ranks, n3, d3, k, beta, 2, st3, 6, min(args.repeats, 7), want_solo=True)
-                        tf3, med3 = timing_fields(b3, st3)
-                        rec = dict(value=float(n3) * d3 * st3 / med3, unit="cells/s", ms_per_step=tf3["ms_per_step"], scaling="strong",
-                                   families=n3, organisms=d3,
-                                   repeats=tf3["repeats"], ms_per_step_min=tf3["ms_per_step_min"], ms_per_step_max=tf3["ms_per_step_max"],
-                                   collective=f3["collective"], rccl_ranks=f3["rccl_ranks"], single_gpu_same_workload=solo3)
-                        if solo3 and "ms_per_step" in solo3:
-                            rec["speedup_vs_single_gpu_same_workload"] = solo3["ms_per_step"] / tf3["ms_per_step"]
-                        also["strong_%dx%d" % (n3, d3)] = rec
-                    except Exception as exc:
-                        also["strong_%dx%d" % (n3, d3)] = {"error": repr(exc)}
-        steps_total = args.steps
+
+    out = None
+    if rank == 0:
+        out, cells_per_s = assemble_line(args, world, k, beta, n_tot, n_loc, d, nnz, blocks, extra, kernels, scaling, parallelism,
+                                         what, ksweep, multi)
+        if also is not None:
+            out["also"] = dict(also)
+        wd.set_fallback(out)                      # from here on a phase that hangs costs its own entry only
+
+    # ---- what else N GPUs can do with this path, in the same run: the strong-scaling figure of the shape where it can pay
+    if multi and world > 1 and not args.no_extras and args.scaling != "replicas":
+        n3, d3 = (int(v) for v in args.extras_strong_shape.lower().split("x"))
+        if (n_tot, d) != (n3, d3):
+            key3 = "strong_%dx%d" % (n3, d3)
+            try:
+                wd.phase(key3, args.phase_timeout)
+                st3 = 60
+                b3, f3, _, _, solo3 = sharded_run(args, ranks, n3, d3, k, beta, 2, st3, 6, min(args.repeats, 7), want_solo=True)
+                tf3, med3 = timing_fields(b3, st3)
+                rec = dict(value=float(n3) * d3 * st3 / med3, unit="cells/s", ms_per_step=tf3["ms_per_step"], scaling="strong",
+                           families=n3, organisms=d3,
+                           repeats=tf3["repeats"], ms_per_step_min=tf3["ms_per_step_min"], ms_per_step_max=tf3["ms_per_step_max"],
+                           collective=f3["collective"], rccl_ranks=f3["rccl_ranks"], single_gpu_same_workload=solo3)
+                if solo3 and "ms_per_step" in solo3:
+                    rec["speedup_vs_single_gpu_same_workload"] = solo3["ms_per_step"] / tf3["ms_per_step"]
+            except Exception as exc:
+                rec = {"error": repr(exc)}
+            if rank == 0:
+                out.setdefault("also", {})[key3] = rec
+    wd.done()
 
     if rank == 0:
-        tf, med = timing_fields(blocks, steps_total)
-        cells_per_s = n_tot * d * steps_total / med
-        shape = ("BASELINE configs[4] (K sweep)" if (n_tot, d) == (20000, 500) and args.disper == "skd" else "custom model") \
-            if ksweep else (SHAPES.get((n_tot, d), "custom shape") if args.disper == "sk_" else "custom model")
-        out = {
-            "metric": "em_family_x_organism_cells_per_sec",
-            "value": cells_per_s,
-            "unit": "cells/s",
-            "em_iterations_per_sec": steps_total / med,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": tf["ms_per_step"],
-            "repeats": tf["repeats"], "ms_per_step_min": tf["ms_per_step_min"], "ms_per_step_max": tf["ms_per_step_max"],
-            "timed_region_s": tf["timed_region_s"],
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "f32 chains with f64 intermediates (reference arithmetic); int32 popcounts in the M-step",
-            "data": "synthetic",
-            "config": {
-                "workload": "%s: %d families x %d organisms, K=%d, beta=0.5, contiguity graph (path + 5%% chords, "
-                            "weights %s), %s/%s/pk; %s" % (shape, n_tot, d, k, "1..8" if args.weights == "small" else "1..%d (coverage)" % d,
-                                                           args.algo, args.disper, what),
-                "families_total": n_tot, "families_per_gpu": n_loc, "organisms": d, "K": k, "beta": beta,
-                "cycle_iterations": extra["cycle_iterations"],
-                "parallelism": parallelism,
-            },
-            "roofline": roofline_block(kernels, n_loc, d, profiled_workload=(args.algo == "ncem" and args.disper == "sk_" and not ksweep
-                                                                              and args.spectrum == "ushape" and not multi
-                                                                              and args.weights == "small")),
-        }
-        out["roofline"]["whole_iteration_algorithmic_GBps"] = whole_iteration_bytes(n_tot, d, k, nnz) * steps_total / med / 1e9
-        out.update(extra)
-        if also is not None:
-            out["also"] = also
         if not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(x, nei, k, prop, center, disp, beta, args.algo, args.disper,
@@ -774,8 +887,10 @@ def main():
 
     if multi:
         import torch.distributed as dist
+        wd.phase("leaving the process group", 60)
         dist.barrier()
         dist.destroy_process_group()
+        wd.done()
 
 
 if __name__ == "__main__":

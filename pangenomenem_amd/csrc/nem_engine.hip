@@ -240,7 +240,9 @@ struct nemgpu_engine {
     ZipContext* zc = nullptr;
     // a rank alone in the sharded EM (no collective inside a batch): its batches as hipGraphs of the library's own,
     // captured the second time a shape is enqueued (nemgpu_shard_enqueue_batch)
-    struct ShardGraph { uint64_t key; std::vector<uint64_t> desc; int asked; hipGraphExec_t exec; };
+    // (post_*: the host flags the captured body left behind -- a replay launches the graph only, so it sets them itself)
+    struct ShardGraph { uint64_t key; std::vector<uint64_t> desc; int asked; hipGraphExec_t exec;
+                        bool post_tables_fresh = false, post_density_fresh = false, post_flags_clean = false, post_masks_valid = false; };
     std::vector<ShardGraph> shard_graphs;
 
     bool ncem() const { return cfg.algo == NEMGPU_ALGO_NCEM; }
@@ -4063,8 +4065,15 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
     nemgpu_engine::ShardGraph* slot = nullptr;
     if (e->sh_world == 1 && e->use_graphs && !e->libc()) {        // (TIE_LIBC: the stream's position is a launch argument)
         uint32_t bb; memcpy(&bb, &beta, 4);
+        //  Everything that decides WHICH launches the body issues is part of the key: besides the call's
+        // arguments, the host state the body branches on.  A batch that does not start with the restart launch first
+        // flushes a pending reset -- outside the capture, below -- so that state is the same at capture and at replay.
+        if (with_init == 0) { const int fr = flush_reset(e); if (fr) return fr; }
+        else { HIPCHK(hipSetDevice(e->device)); const int cf = clear_fault(e); if (cf) return cf; }   // (a restart clears a reported fault: not inside a capture)
         const std::vector<uint64_t> desc = {(uint64_t)with_init, (uint64_t)n_iters, (uint64_t)base, (uint64_t)bb, (uint64_t)want_stats,
-                                            (uint64_t)(uintptr_t)lab0, (uint64_t)(uintptr_t)lab1, (uint64_t)(uintptr_t)lab2, (uint64_t)stats_off};
+                                            (uint64_t)(uintptr_t)lab0, (uint64_t)(uintptr_t)lab1, (uint64_t)(uintptr_t)lab2, (uint64_t)stats_off,
+                                            (uint64_t)((with_init ? 0 : ((e->tables_fresh ? 1 : 0) | (e->density_fresh ? 2 : 0) | (e->flags_clean ? 4 : 0) |
+                                                                         (e->masks_valid ? 8 : 0))))};
         uint64_t key = 1469598103934665603ull;
         for (uint64_t v : desc) key = (key ^ v) * 1099511628211ull;
         for (auto& g : e->shard_graphs) if (g.key == key && g.desc == desc) { slot = &g; break; }
@@ -4076,14 +4085,24 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
         if (slot->exec != nullptr) {
             { const int cr = shard_check(e); if (cr) return cr; }
             HIPCHK(hipSetDevice(e->device));
+            // the host half of what the captured body did (nemgpu_shard_begin_restart / the round functions): a replay
+            // only launches the graph -- a reset left pending here would later copy the initial parameters over the
+            // estimated ones
+            if (with_init) {
+                if (!e->have_matrix || !e->have_params) { set_error("matrix and parameters must be set first"); return NEMGPU_E_FUNCARG; }
+                const int rr = reset_state(e, true);
+                if (rr) return rr;
+                e->reset_pending = false;                          // (the device half is the graph's first launch)
+            }
             HIPCHK(hipGraphLaunch(slot->exec, e->stream));
+            e->tables_fresh = slot->post_tables_fresh; e->density_fresh = slot->post_density_fresh;
+            e->flags_clean = slot->post_flags_clean; e->masks_valid = slot->post_masks_valid;
             e->n_replayed++;
             e->stop_ptr = nullptr;
             return NEMGPU_OK;
         }
         if (slot->asked++ >= 1 || e->capture_first) {
             HIPCHK(hipSetDevice(e->device));
-            if (with_init == 0) { const int fr = flush_reset(e); if (fr) return fr; }      // (nothing pending may be captured)
             HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             const int r = shard_batch_body(e, with_init, n_iters, base, beta, want_stats, lab0, lab1, lab2, stats_off);
             hipGraph_t graph = nullptr;
@@ -4092,6 +4111,8 @@ int nemgpu_shard_enqueue_batch(nemgpu_engine* e, int with_init, int n_iters, int
             if (r == NEMGPU_OK && cerr == hipSuccess && graph != nullptr && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                 if (graph) (void)hipGraphDestroy(graph);
                 slot->exec = exec;
+                slot->post_tables_fresh = e->tables_fresh; slot->post_density_fresh = e->density_fresh;
+                slot->post_flags_clean = e->flags_clean; slot->post_masks_valid = e->masks_valid;
                 e->n_captured++;
                 HIPCHK(hipGraphLaunch(exec, e->stream));
                 return NEMGPU_OK;

@@ -178,3 +178,59 @@ def test_bench_sharded_driver_agrees_with_single_engine(gpu_lib):
     # (a rank alone skips the all-gathers; the sharded iteration keeps one launch more than the single engine's, its
     #  loop control: round 3 brought the ratio from 1.5-1.6 to under 1.2 at 50 000 x 1 000)
     assert 0.5 < dist1["ms_per_step"] / long_["ms_per_step"] < 1.3, (dist1["ms_per_step"], long_["ms_per_step"])
+
+
+def _replay_worker(rank, world, initfile, outdir):
+    """a 1-rank sharded job whose restart batch has been captured, then set_params (a lazy reset), then the
+    batch REPLAYED: the host half of the restart must run on a replay too, or the next look at the parameters copies
+    the initial ones over the estimated ones."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from pangenomenem_amd import synth
+    from pangenomenem_amd.distributed import Comm, GpuStepper, ShardedNem, slice_graph, slot_layout
+    from pangenomenem_amd.engine import solve
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="file://" + initfile, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        n, d = 6000, 40
+        x, _ = synth.ushaped_pa_matrix(n, d, 9)
+        nei = synth.contiguity_graph(n, 9)
+        prop, center, disp = synth.default_init(d)
+        blk, stride = slot_layout(n, 1, 3 + 3 * d)
+        cfg = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", cvtest="clas", seed=11)
+        st = GpuStepper(x, slice_graph(nei, 0, n, blk, stride), 3, n, 1, 0, prop, center, disp, 0, cfg)
+        job = ShardedNem(st, Comm(), n, 0.5, cvtest="clas", cvthres=1e-8)
+        runs = []
+        for _ in range(3):                                   # plain, captured, replayed
+            res = job.run(100)
+            runs.append((res["iters"], job.global_labels().copy(), {k: v.copy() for k, v in st.params().items()}))
+        counters = st.eng.graph_counters()
+        # other initial parameters: a lazy reset is pending when the (replayed) restart batch starts
+        disp2 = disp.copy(); disp2[0] = 0.2; disp2[2] = 0.05
+        st.eng.set_params(prop, center, disp2)
+        res2 = job.run(100)
+        got = (res2["iters"], job.global_labels().copy(), {k: v.copy() for k, v in st.params().items()})
+        want = solve(x, nei, 3, prop, center, disp2, **dict(cfg, tie="hash"))
+        first = solve(x, nei, 3, prop, center, disp, **dict(cfg, tie="hash"))
+        np.savez(os.path.join(outdir, "replay.npz"), replayed=counters["replayed"], captured=counters["captured"],
+                 iters=[r[0] for r in runs], same_labels=all(np.array_equal(r[1], runs[0][1]) for r in runs),
+                 same_disp=all(np.array_equal(r[2]["disp"], runs[0][2]["disp"]) for r in runs),
+                 first_ok=bool(first["iters"] == runs[0][0] and np.array_equal(first["c"].argmax(1), runs[0][1]) and np.array_equal(first["disp"], runs[0][2]["disp"])),
+                 iters2=got[0], want_iters2=want["iters"], labels2_ok=bool(np.array_equal(got[1], want["c"].argmax(1))),
+                 disp2_ok=bool(np.array_equal(got[2]["disp"], want["disp"])), prop2_ok=bool(np.array_equal(got[2]["prop"], want["prop"])),
+                 changed=bool(not np.array_equal(want["disp"], first["disp"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replayed_restart_batch_runs_its_host_half(gpu_lib):
+    import torch.multiprocessing as mp
+    outdir = tempfile.mkdtemp(prefix="nemgreplay_")
+    mp.spawn(_replay_worker, args=(1, os.path.join(outdir, "rdv"), outdir), nprocs=1, join=True)
+    o = np.load(os.path.join(outdir, "replay.npz"))
+    assert int(o["replayed"]) > 0 and int(o["captured"]) > 0            # (the third run did replay a captured batch)
+    assert bool(o["same_labels"]) and bool(o["same_disp"]) and bool(o["first_ok"])
+    assert bool(o["changed"])                                            # (the second parameter set gives another answer)
+    assert int(o["iters2"]) == int(o["want_iters2"]) and bool(o["labels2_ok"]) and bool(o["disp2_ok"]) and bool(o["prop2_ok"])
