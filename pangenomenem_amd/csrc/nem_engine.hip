@@ -2011,6 +2011,14 @@ int nemgpu_default_device(int* device)
     g_hip_used.store(true);
     const char* s = getenv("NEM_MI355X_DEVICE");
     if (s == nullptr || s[0] == '\0') {
+        // unset: a launcher's LOCAL_RANK when there is one (one process per GPU), else the calling thread's current HIP
+        // device -- the embedding application's choice.  A pool of workers that selects nothing lands on device 0:
+        // NEM_MI355X_DEVICE=auto spreads it (INTEGRATION.md says so first thing in its multi-GPU paragraph)
+        if (const char* lr = getenv("LOCAL_RANK")) {
+            char* end = nullptr;
+            const long v = strtol(lr, &end, 10);
+            if (end != lr && *end == '\0' && v >= 0) { *device = (int)((unsigned long)v % (unsigned long)ndev); return NEMGPU_OK; }
+        }
         int cur = 0;
         if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
         *device = cur;
@@ -2116,6 +2124,9 @@ void nemgpu_destroy(nemgpu_engine* e)
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](int j) { auto t1 = std::chrono::steady_clock::now(); g_destroy_ns[j] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(); t0 = t1; };
     (void)hipSetDevice(e->device);
+    // (nemgpu_solve_many: an engine whose group never ran -- a failed job -- may still have uploads queued on its
+    //  builder's stream, out of pinned blocks that go back to the pool below: wait for them)
+    if (e->ready_pending && e->ready_ev) { (void)hipEventSynchronize(e->ready_ev); e->ready_pending = false; }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     lap(0);
     std::vector<PoolBlock> blocks;

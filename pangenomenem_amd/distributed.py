@@ -120,8 +120,8 @@ class GpuStepper:
         self.torch = torch
         self.device = torch.device("cuda", device)
         d = x_local.shape[1]
-        if x_local.shape[0] == 0:
-            raise ValueError("rank %d would own no family (n_total=%d over %d ranks): use fewer ranks" % (rank, n_total, world))
+        if shard_bounds(n_total, world, world - 1)[0] >= n_total:      # (the same answer on every rank: all raise together)
+            raise ValueError("the last of %d ranks would own no family (n_total=%d): use fewer ranks" % (world, n_total))
         blk, stride = slot_layout(n_total, world, k + k * d)
         self.rank, self.blk, self.stride = rank, blk, stride
         # one dedicated (non-default) stream carries this rank's kernels AND the collectives torch issues for
@@ -636,9 +636,11 @@ class FuzzyGpuStepper:
         self.k, self.d, self.n_total, self.world, self.rank = k, d, n_total, world, rank
         lo, hi, blk = shard_bounds(n_total, world, rank)
         dlo, dhi, dblk = organism_bounds(d, world, rank)
-        if hi <= lo or dhi <= dlo:
-            raise ValueError("rank %d would own no family or no organism (%d x %d over %d ranks): use fewer ranks"
-                             % (rank, n_total, d, world))
+        # (decided from global quantities, so that EVERY rank raises -- a rank that went on alone would wait for the others
+        #  in its first collective for good)
+        if shard_bounds(n_total, world, world - 1)[0] >= n_total or organism_bounds(d, world, world - 1)[0] >= d:
+            raise ValueError("the last of %d ranks would own no family or no organism (%d x %d): use fewer ranks"
+                             % (world, n_total, d))
         assert x_rows.shape == (hi - lo, d) and x_cols.shape == (n_total, dhi - dlo)
         self.blk, self.dblk, self.n_pad, self.dlo, self.dhi = blk, dblk, world * blk, dlo, dhi
         self.stream = torch.cuda.Stream(self.device)

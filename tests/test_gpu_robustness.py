@@ -131,7 +131,11 @@ def test_dropin_reports_a_kernel_fault_as_an_internal_error(gpu_lib, tmp_path):
 def test_default_device_selection(gpu_lib, monkeypatch):
     from pangenomenem_amd import engine
     monkeypatch.delenv("NEM_MI355X_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
     assert engine.default_device() == 0                    # the current HIP device of a process that chose none
+    monkeypatch.setenv("LOCAL_RANK", "3")                  # ... a launcher's LOCAL_RANK when there is one
+    assert engine.default_device() == 3 % engine.device_count()
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
     monkeypatch.setenv("NEM_MI355X_DEVICE", "0")
     assert engine.default_device() == 0
     monkeypatch.setenv("NEM_MI355X_DEVICE", "auto")
