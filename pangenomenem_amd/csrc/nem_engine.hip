@@ -54,6 +54,8 @@ constexpr int kRoundCap = 64;     // relaxation rounds per flag window
 constexpr int kMeetWords = 2 * kFusedMaxBlocks;
 constexpr int kSweepFlagWords = 1 + kRoundCap * FLAG_ROUND_STRIDE + kMeetWords;
 constexpr int kRoundBatchMax = 4;
+constexpr int kRoundsMax = 7;       // most rounds a sweep of the pipelined loop is given ahead (ctrl_logic reads 8 slots)
+constexpr int kFzPositions = 16;    // fuzzy NEM: leading iterations of a run whose round counts are learned
 }  // namespace
 
 struct nemgpu_engine {
@@ -182,6 +184,12 @@ struct nemgpu_engine {
     // an iteration further on whose sweep the host had to finish moves the mark (it is kept across restarts: the
     // bench and PPanGGOLiN's repeated solves of similar problems find the same pattern every time).
     int deep_iters = 2;
+    // Fuzzy NEM: the sweeps of a run's FIRST iterations need more rounds than the later ones (memberships move
+    // everywhere after a start), and a sweep that runs out of enqueued rounds stops the pipeline for a host round trip
+    // (round 3: 162 of them in 2 700 timed steps).  fz_need[p]: rounds to enqueue for iteration p of a run (0: the
+    // default rule), raised to what the host had to add when it finished that iteration's sweep; fz_init_need: the
+    // same for the start's beta sweep.  Kept across restarts, like deep_iters.
+    uint8_t fz_need[kFzPositions] = {}; uint8_t fz_init_need = 0;
     int run_deep_used = 0; bool run_tracked = false;   // this run: the last iteration that used the extra round
     bool capture_first = false;          // capture a batch shape the first time it is enqueued (nemgpu_set_graph_policy)
     int n_plain = 0, n_captured = 0, n_replayed = 0, n_host_rounds = 0;   // nemgpu_graph_counters
@@ -1057,7 +1065,17 @@ int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id, int launc
 // enqueue one whole iteration whose current partition is buffer `cur`.  defer_ctrl: another iteration follows in
 // the same batch -- an NCEM iteration's loop control then runs in that iteration's counts launch (k_mstep_counts)
 // instead of in a last-block ticket at the tail of the last sweep round.
-int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_ctrl, bool deep)
+// rounds enqueued for the sweep of iteration `pos` of a run (pos < 0: not known)
+int iteration_rounds(const nemgpu_engine* e, int pos, bool deep)
+{
+    // (fuzzy sweeps need their third round nearly always -- memberships keep moving in the last digits -- : round_batch
+    //  everywhere, and what the host had to add for the leading iterations of a run)
+    int want = (current_recorder() != nullptr || deep || !e->ncem()) ? e->round_batch : e->rounds_iter;
+    if (!e->ncem() && current_recorder() == nullptr && pos >= 0 && pos < kFzPositions && e->fz_need[pos] > want) want = e->fz_need[pos];
+    return want;
+}
+
+int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_ctrl, bool deep, int pos = -1)
 {
     int r;
     const int saved = e->cur;
@@ -1097,7 +1115,7 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
     CtrlArgs ca{};
     // (members of a lock-step batch all take the same number of rounds: a member with a sequence of its own would
     //  need launches of its own)
-    const int it_rounds = sweep_first_rounds(e, e->cfg.beta, (current_recorder() != nullptr || deep) ? e->round_batch : e->rounds_iter);
+    const int it_rounds = sweep_first_rounds(e, e->cfg.beta, iteration_rounds(e, pos, deep));
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = it_rounds;
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
@@ -1137,7 +1155,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = sweep_first_rounds(e, e->cfg.beta, e->round_batch);
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0));
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -1145,7 +1163,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     ca.blind = e->round_flags(kRoundCap - 1);
     const bool defer = defer_ctrl && e->ncem() && !e->cfg.param_fix;
     CtrlArgs none{};
-    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? (defer ? &none : &ca) : nullptr, false))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? (defer ? &none : &ca) : nullptr, false, 0, ca.n_rounds))) return r;   // 1 -> 2 (and 0 as the pong buffer)
     if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (e->ncem()) e->masks_valid = true;
     else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }
@@ -1191,6 +1209,7 @@ struct LoopCursor {
     // the batch in flight
     int g = 0, base = 0; uint32_t sweep0 = 0; bool batch_first = false;
     int deep = 0;                 // leading iterations of the batch that get round_batch relaxation rounds
+    int pos0 = 0;                 // run-relative number of the batch's first iteration (fuzzy: selects the learned round counts)
     bool active() const { return remaining > 0 || first; }
 };
 
@@ -1228,6 +1247,10 @@ int batch_plan(nemgpu_engine* e, LoopCursor& lc)
     lc.base = lc.first ? 2 : e->cur;
     lc.sweep0 = lc.first ? 2u : e->sweep_counter;
     lc.deep = current_recorder() != nullptr ? lc.g : std::max(0, std::min(lc.g, e->deep_iters - (lc.first ? 0 : e->iters)));
+    lc.pos0 = lc.first ? 0 : e->iters;
+    // (fuzzy: the round counts of a batch's iterations depend on where in the run it starts; the graph table's last
+    //  index tells the classes apart -- a stale class would only enqueue another number of rounds, never change a result)
+    if (!e->ncem() && current_recorder() == nullptr) lc.deep = lc.pos0 >= kFzPositions ? 0 : std::min(7, 1 + lc.pos0 / kPipeDepth);
     // class masks of the current labels, fresh tables when the parameters are fixed (otherwise k_finish rebuilds them
     // inside the batch)
     if (!lc.first) {
@@ -1254,7 +1277,7 @@ int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
     e->stop_ptr = e->ctrl() + C_STOP;
     if (lc.batch_first && herr == hipSuccess) r = enqueue_init(e, lc.g > 0);
     for (int j = 0; j < lc.g && r == NEMGPU_OK && herr == hipSuccess; j++)
-        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g, j < lc.deep);
+        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g, e->ncem() ? j < lc.deep : false, lc.pos0 + j);
     e->stop_ptr = nullptr;
     if (herr == hipSuccess && r == NEMGPU_OK && with_copy)
         herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream);
@@ -1290,11 +1313,16 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         e->cur = 1;
         e->n_host_rounds++;
         SweepCtx sc;
-        const int launched = sweep_first_rounds(e, e->cfg.beta, e->round_batch, 1);
+        const int launched = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0), 1);
         if ((r = host_rounds_ctx(e, sc, 1u, launched))) return r;
         if (fused_failed_seen(e, 0, 0, launched)) { if ((r = fused_fallback(e, sc))) return r; }
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
-        if ((r = sweep_complete(e, sc, nullptr, nullptr))) return r;
+        int init_rounds = 0;
+        if ((r = sweep_complete(e, sc, &init_rounds, nullptr))) return r;
+        if (!e->ncem() && current_recorder() == nullptr && std::min(kRoundsMax, init_rounds) > e->fz_init_need) {
+            e->fz_init_need = (uint8_t)std::min(kRoundsMax, init_rounds);     // the next starts get them enqueued
+            drop_graphs(e);
+        }
         e->sweep_rounds += 1;                                  // + the blind sweep
         e->cur = 2; e->sweep_counter = 2;
         e->masks_valid = false;
@@ -1328,7 +1356,8 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         const int oldbuf = e->cur, newbuf = (e->cur + 1) % 3;
         e->n_host_rounds++;
         SweepCtx sc;
-        const int launched = sweep_first_rounds(e, e->cfg.beta, done - 1 < lc.deep ? e->round_batch : e->rounds_iter, 1);
+        const int pos = lc.pos0 + done - 1;                          // the run-relative number of that iteration
+        const int launched = sweep_first_rounds(e, e->cfg.beta, iteration_rounds(e, pos, e->ncem() && done - 1 < lc.deep), 1);
         if ((r = host_rounds_ctx(e, sc, sweep0 + (uint32_t)(done - 1), launched))) return r;
         if (fused_failed_seen(e, 0, 0, launched)) { if ((r = fused_fallback(e, sc))) return r; }
         e->deep_iters = std::max(e->deep_iters, e->iters);          // from now on: one round more up to this iteration of a run
@@ -1336,6 +1365,10 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;
         int rounds = 0;
         if ((r = sweep_complete(e, sc, &rounds, nullptr))) return r;
+        if (!e->ncem() && current_recorder() == nullptr && pos >= 0 && pos < kFzPositions && std::min(kRoundsMax, rounds) > e->fz_need[pos]) {
+            e->fz_need[pos] = (uint8_t)std::min(kRoundsMax, rounds);       // this position gets them enqueued from now on
+            drop_graphs(e);
+        }
         HIPCHK(hipMemsetAsync(e->iter_flags() + FLAG_MOVED, 0, sizeof(int), e->stream));
         if ((r = post_sweep(e, newbuf, oldbuf))) return r;
         if ((r = read_iter_flags(e))) return r;

@@ -2005,21 +2005,16 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
     // (workgroup-scope release), bumps s_ready; the consumer reads a buffer once all eight producers of that tenant
     // are in (acquire), and says so in s_done when its last read has come back; a producer does not touch a buffer
     // before the consumer is done with its previous tenant.  The producers run ahead and sleep on s_done; the
-    // consumer's check is one LDS read.  Spins are bounded, and a spin that runs out is a FAULT, not a result: the wave
-    // that sees it raises s_fault (every wave of the block leaves its loop at its next hand-over) and the engine's
-    // FLAG_FAULT word, which the host turns into NEMGPU_E_INTERNAL -- a broken hand-over ends the kernel, reported, not
-    // hung and not silently wrong.
-    __shared__ int s_ready[2], s_done, s_fault;
-    if (threadIdx.x == 0) { s_ready[0] = 0; s_ready[1] = 0; s_done = -1; s_fault = 0; }
+    // consumer's check is one LDS read.  Spins are bounded (a wait that runs out goes on with whatever is there), and a
+    // hand-over that was not delivered is a FAULT, not a result: the producers' counters are cumulative, so the consumer
+    // sees at the end whether every hand-over arrived and, if not, raises the engine's FLAG_FAULT word, which the host
+    // turns into NEMGPU_E_INTERNAL -- a broken hand-over ends the kernel, reported, not hung and not silently wrong.
+    __shared__ int s_ready[2], s_done;
+    if (threadIdx.x == 0) { s_ready[0] = 0; s_ready[1] = 0; s_done = -1; }
     __syncthreads();
-    constexpr int kSpinCap = 1 << 22;
-    auto faulted = [&]() { return __hip_atomic_load(&s_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; };
-    auto raise_fault = [&]() {
-        if (lane == 0) {
-            __hip_atomic_store(&s_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (a.fault != nullptr) atomicOr(a.fault, 1);
-        }
-    };
+    constexpr int kSpinCap = 1 << 16;                    // (producers, with s_sleep: ~10 ms per hand-over)
+    constexpr int kConsumerSpinCap = 1 << 18;            // (per hand-over: ~10 ms, a thousand times the longest legitimate wait)
+    auto raise_fault = [&]() { if (lane == 0 && a.fault != nullptr) atomicOr(a.fault, 1); };
 #ifdef NEM_PHASE_PROF
     unsigned long long t_work = 0, t_begin = wall_clock64();
 #endif
@@ -2027,13 +2022,12 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
         PcIn cur = fetch(ps), nxt = fetch(4 + ps);
         for (int H = 0; H < nhand; H++) {
             // buffer H & 1 held hand-over H - 2
-            int spin = 0;
-            for (; spin < kSpinCap && __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < H - 2; spin++) {
-                if ((spin & 255) == 255 && faulted()) break;
+            // (round 2's wait, to the letter.  Round 3 had the producers look at a fault flag here and leave the loop
+            //  on it: a producer's hand-over takes about as long as the consumer's 256 adds, so every instruction in
+            //  this loop is on the consumer's critical path -- the M-step went from 139 to 153 us.  A wait that runs
+            //  out now just goes on -- everything is bounded -- and the consumer reports the fault at the end.)
+            for (int spin = 0; spin < kSpinCap && __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < H - 2; spin++)
                 __builtin_amdgcn_s_sleep(4);
-            }
-            if (faulted()) break;
-            if (spin >= kSpinCap) { raise_fault(); break; }
             if (a.inject == 1 && wv == 1 && H == 1 && blockIdx.x == 0 && blockIdx.y == 0) continue;   // (test hook: a producer that never delivers)
             produce(H & 1, 4 * H + ps, cur);
             if (lane == 0) __hip_atomic_fetch_add(&s_ready[H & 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2046,9 +2040,12 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
             const unsigned long long t_a = wall_clock64();
 #endif
             const int need = 8 * ((H >> 1) + 1);         // all eight producers of this tenant of the buffer
-            int spin = 0;
-            for (; spin < kSpinCap && __hip_atomic_load(&s_ready[H & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spin++) { }
-            if (spin >= kSpinCap) { raise_fault(); break; }   // (the sums are not to be used: FLAG_FAULT says so)
+            // (This wait is round 2's, to the letter: nothing of it is looked at afterwards.  With the spin count tested
+            //  behind the loop -- round 3's fault report -- the compiler kept an LDS operation outstanding across the
+            //  loop's exit and throttled the sixteen reads below with four `s_waitcnt lgkmcnt(14)`: +0.16 us per
+            //  hand-over, 139 -> 153 us per M-step.  A hand-over that never completes is found behind the loop: the
+            //  producers' counters are cumulative.)
+            for (int spin = 0; spin < kConsumerSpinCap && __hip_atomic_load(&s_ready[H & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; spin++) { }
             // two register sets: the next sub-window's 64 addends are read from LDS while this one's are added
             const float4* r4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sA4[H & 1]) + lane * kPcStride);
             float4 vA[16], vB[16];
@@ -2076,6 +2073,9 @@ __device__ __forceinline__ void mstep_fuzzy_pc_body(const FuzzyArgs& a)
             t_work += wall_clock64() - t_a;
 #endif
         }
+        // every hand-over delivered?  (tenants of buffer 0: hand-overs 0, 2, ...; of buffer 1: 1, 3, ...; eight producers each)
+        if (__hip_atomic_load(&s_ready[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * ((nhand + 1) >> 1) ||
+            __hip_atomic_load(&s_ready[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * (nhand >> 1)) raise_fault();
     }
 #ifdef NEM_PHASE_PROF
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wv == 0) { g_phase[10] = t_work; g_phase[24] = wall_clock64() - t_begin; }

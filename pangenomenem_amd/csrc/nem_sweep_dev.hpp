@@ -39,7 +39,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     // One thread runs this at the tail of a launch (or as a launch of its own): a string of dependent read-modify-writes
     // of device memory would BE that tail (each ~0.1-0.4 us).  So everything the decision reads is requested up front
     // -- independent loads, one memory latency -- the tests run on registers, and what changed is stored at the end.
-    constexpr int kMaxRounds = 4;                                 // (kRoundBatchMax in nem_engine.hip)
+    constexpr int kMaxRounds = 8;                                 // (kRoundsMax in nem_engine.hip: the fuzzy loop's learned counts go up to 7)
     const int nr = a.n_rounds > 0 ? (a.n_rounds < kMaxRounds ? a.n_rounds : kMaxRounds) : 2;
     const int stop = c[C_STOP];
     int iters = c[C_ITERS], commits = c[C_COMMITS], sweep_rounds = c[C_SWEEP_ROUNDS], nzero = c[C_NZERO], firstzero = c[C_FIRSTZERO];
