@@ -196,6 +196,44 @@ int nemgpu_solve_many_devices(nemgpu_problem* problems, int count, const nemgpu_
 /* slot_of_problem[i] = index into the device list of the device that solves problem i (host arithmetic only) */
 int nemgpu_deal_groups(int count, int group, int n_devices, int* slot_of_problem);
 
+/* ---- The chunks of partition()'s voting loop, formed on the device ----------------------------------------------
+   The reference solves a pangenome of more than 500 organisms as many NEM problems, each on a random sample of the
+   organisms (ppanggolin.py:1045-1086: `orgs = sample(organisms, chunck_size)`), and writes every sample's input files
+   from ONE graph (__write_nem_input_files, ppanggolin.py:821-930): columns = the sampled organisms in sample order
+   (:850); families without a sampled organism dropped, the others numbered in the graph's order (:849-852); an edge's
+   weight = the number of sampled organisms that carry the adjacency, an edge none carries dropped (:866-878), a
+   family's neighbours in the order the master lists them.  nemgpu_master_create puts that ONE pangenome on the device:
+   the presence/absence bit rows xbits[n][ceil(d/32)] (family-major, bit o of a row = organism o), the graph in CSR
+   (nei_ptr[n + 1], nei_idx[nnz]) and, per directed edge, the bit set of the organisms that carry it
+   (edge_bits[nnz][ceil(d/32)]).  HOST memory, copied once. */
+typedef struct nemgpu_master nemgpu_master;
+int nemgpu_master_create(nemgpu_master** out, int device, int n, int d, const uint32_t* xbits, const int32_t* nei_ptr,
+                         const int32_t* nei_idx, const uint32_t* edge_bits);
+void nemgpu_master_destroy(nemgpu_master* m);
+/* One sample.  in: organisms[dc] (indices into the master's, the chunk's column order).  out: n = families with at least
+   one sampled organism, nnz = directed edges of the chunk's graph; optional arrays (NULL: not wanted): keep[ceil(n_master
+   / 64)] (bit i: master family i is in the chunk -- the chunk's family j is the j-th set bit), labels[n] (NCEM: class of
+   the chunk's family j; room for n_master bytes), out_prop[k], out_center[k][dc], out_disp[k][dc], out_nbobs_k[k]. */
+typedef struct {
+    const int32_t* organisms;
+    int dc;
+    int n, nnz;
+    uint64_t* keep;
+    uint8_t* labels;
+    float *out_prop, *out_center, *out_disp, *out_nbobs_k;
+    nemgpu_result result;
+    int rc;
+} nemgpu_chunk;
+/* All samples in ONE call: the device decides which families and edges each sample keeps (one pass over all samples,
+   one wait), then every sample goes through nemgpu_solve_many's pipeline -- `workers` builder threads, lock-step groups
+   of `group` problems, results unpacked while later groups are built -- with its matrix rows, lane order and graph
+   written by the device straight into its engine's buffers: per sample only the initial parameters (k values per kind:
+   prop[k], and ONE centre and ONE dispersion per class for every organism, as PPanGGOLiN's default .m has them,
+   ppanggolin.py:893-901) and the results cross PCIe.  Every sample's result equals nemgpu_solve_many on the same
+   sample formed on the host (tests/test_gpu_chunks.py). */
+int nemgpu_solve_chunks(nemgpu_master* m, nemgpu_chunk* chunks, int count, int k, const float* prop, const float* center_k,
+                        const float* disp_k, const nemgpu_config* cfg, int workers, int group);
+
 /* Whole run from random starts (the reference's init_mode = INIT_RANDOM, RandNemAlgo nem_alg.c:1574-1742): n_starts
    starts (the reference uses 50), centres drawn from the data with the reference's generator -- glibc random()
    after srandom(seed), restated in csrc/nem_rng.hpp -- best start by criterion M, EstimPara on the best partition.

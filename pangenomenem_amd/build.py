@@ -13,7 +13,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-UNITS = ("nem_kernels.hip", "nem_sweep.hip", "nem_engine.hip", "nem_io.cpp", "nem_capi.cpp")
+UNITS = ("nem_kernels.hip", "nem_sweep.hip", "nem_chunks.hip", "nem_engine.hip", "nem_io.cpp", "nem_capi.cpp")
 SRC = [os.path.join(HERE, "csrc", f) for f in UNITS]
 HDR = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".hpp")) + \
       [os.path.join(HERE, "..", "include", "nem_mi355x.h")]
@@ -76,7 +76,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=max(1, min(len(stale), os.cpu_count() or 1, 5))) as pool:
+    with ThreadPoolExecutor(max_workers=max(1, min(len(stale), os.cpu_count() or 1, 6))) as pool:
         list(pool.map(compile_one, stale))
     with open(_flags_file(), "w") as f:
         f.write(" ".join(CFLAGS + _extra()))

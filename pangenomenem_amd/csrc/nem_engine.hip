@@ -31,6 +31,7 @@
 #include "nem_halfsum.hpp"
 #include "nem_rng.hpp"
 #include "nem_kernels.hpp"
+#include "nem_chunks.hpp"
 
 using namespace nemk;
 
@@ -265,6 +266,22 @@ struct nemgpu_engine {
     const int* h_ctrl() const { return flags_host; }
     const int* h_iter() const { return flags_host + C_WORDS; }
     const int* h_round(int r) const { return flags_host + C_WORDS + FLAG_ITER_STRIDE + (r % kRoundCap) * FLAG_ROUND_STRIDE; }
+};
+
+// A master pangenome on the device (nemgpu_master_create): what the chunks of PPanGGOLiN's voting loop are formed from
+// (nem_chunks.hpp).  One allocation; the stream carries the formation's phase 1.
+struct nemgpu_master {
+    int device = 0, n = 0, d = 0, wf = 0, nw64 = 0, nnz = 0;
+    hipStream_t stream = nullptr;
+    char* block = nullptr;
+    nemk::MasterDev dev{};
+};
+// what nemgpu_solve_chunks hands to the builders of nemgpu_solve_many's pipeline instead of host matrices and graphs
+struct ChunkSource {
+    const nemgpu_master* master = nullptr;
+    const nemk::ChunkPlan* plans = nullptr;           // host copies (device pointers inside), one per problem
+    const int* nnz = nullptr;                         // directed edges of each chunk's graph
+    uint8_t* const* labels = nullptr;                 // per problem: where the NCEM labels go (or null)
 };
 
 namespace {
@@ -2685,7 +2702,8 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
 // engines (bit packing, uploads out of pinned blocks -- nothing waits for the device), the calling thread runs every
 // `group` of them in lock step as soon as it is complete (nemgpu_run_many), the workers fetch the results and recycle
 // the engines while later groups are being built.  What PPanGGOLiN's chunk loop is when its chunks are arrays.
-static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group);
+static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group, const ChunkSource* src = nullptr);
+static int adopt_chunk(nemgpu_engine* e, const nemgpu_master* M, const nemk::ChunkPlan& plan, int nnz_c);
 static thread_local bool tl_runner = false;                  // this thread is one of nemgpu_solve_many_devices' runners
 
 // Four groups and more, six workers and more: two runners on the device (nemgpu_solve_many_devices with the device named
@@ -2703,7 +2721,7 @@ int nemgpu_solve_many(nemgpu_problem* P, int count, const nemgpu_config* cfg, in
     return nemgpu_solve_many_devices(P, count, cfg, devs, runners, workers, group);
 }
 
-static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group)
+static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg, int device, int workers, int group, const ChunkSource* src)
 {
     if (!P || count <= 0 || !cfg) return NEMGPU_E_FUNCARG;
     workers = std::max(1, std::min(workers, 64));
@@ -2711,7 +2729,7 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
     for (int i = 0; i < count; i++) {
         nemgpu_problem& q = P[i];
         q.rc = NEMGPU_OK; q.result = nemgpu_result{};
-        if (q.n <= 0 || q.d <= 0 || q.k <= 0 || (!q.x_bytes == !q.x_bits) || !q.prop || !q.center || !q.disp ||
+        if (q.n <= 0 || q.d <= 0 || q.k <= 0 || (src == nullptr && (!q.x_bytes == !q.x_bits)) || !q.prop || !q.center || !q.disp ||
             (q.nei_ptr && q.nei_ptr[q.n] > 0 && (!q.nei_idx || !q.nei_w))) {
             set_error("nemgpu_solve_many: problem " + std::to_string(i) + " is incomplete (sizes, exactly one of x_bytes / x_bits, parameters)");
             return NEMGPU_E_FUNCARG;
@@ -2751,6 +2769,12 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
         int r = nemgpu_create(&e, q.n, q.d, q.k, 0, q.n, device, st);
         if (r == NEMGPU_OK && st != nullptr) e->defer_layout = true;
         t[1] = since(t0);
+        if (src != nullptr) {
+            // a chunk of a master that lives on the device: matrix rows, lane order and graph are made THERE, into this
+            // engine's own buffers (nem_chunks.hip) -- nothing of them crosses PCIe
+            if (r == NEMGPU_OK) r = adopt_chunk(e, src->master, src->plans[i], src->nnz[i]);
+            t[2] = t[3] = since(t0);
+        } else {
         if (r == NEMGPU_OK) r = q.x_bits ? nemgpu_set_matrix_bits(e, q.x_bits) : nemgpu_set_matrix_bytes(e, q.x_bytes);
         t[2] = since(t0);
         if (r == NEMGPU_OK) {
@@ -2758,6 +2782,7 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
             else { std::vector<int32_t> z((size_t)q.n + 1, 0); r = nemgpu_set_graph(e, z.data(), nullptr, nullptr); }
         }
         t[3] = since(t0);
+        }
         if (r == NEMGPU_OK) r = nemgpu_set_params(e, q.prop, q.center, q.disp);
         if (r == NEMGPU_OK) r = nemgpu_configure(e, cfg);
         t[4] = since(t0);
@@ -2782,6 +2807,16 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
         // its builder's stream has taken in the meantime)
         if (!e->own_stream && fstream != nullptr) e->stream = fstream;
         GroupSlab& gs = gslab[(size_t)(i / group)];
+        uint8_t* lab_out = (src != nullptr && src->labels != nullptr) ? src->labels[i] : nullptr;
+        if (q.rc == NEMGPU_OK && lab_out != nullptr && e->ncem()) {        // (chunks: the class of every kept family)
+            if (gs.host != nullptr && gslot[(size_t)i] >= 0) {
+                const uint8_t* lab = (const uint8_t*)(gs.host + gs.stride * (size_t)gslot[(size_t)i]);
+                for (int f = 0; f < e->n; f++) lab_out[f] = lab[f] & 0x7F;
+            } else {
+                q.rc = nemgpu_get_labels(e, lab_out);
+                if (q.rc != NEMGPU_OK) errs[(size_t)i] = g_last_error;
+            }
+        }
         if (q.rc == NEMGPU_OK && (q.out_prop || q.out_center || q.out_disp || q.out_nbobs_k || q.out_c)) {
             if (gs.host != nullptr && gslot[(size_t)i] >= 0)
                 result_unpack(e, gs.host + gs.stride * (size_t)gslot[(size_t)i], result_part_bytes(e), q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k, q.out_c);
@@ -2848,7 +2883,8 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
                 for (nemgpu_engine* e : E) gf.stride = std::max(gf.stride, (result_block_bytes(e) + 63) & ~(size_t)63);
                 const size_t total = gf.stride * E.size();
                 bool want = false;
-                for (int i : who) want = want || P[i].out_prop || P[i].out_center || P[i].out_disp || P[i].out_nbobs_k || P[i].out_c;
+                for (int i : who) want = want || P[i].out_prop || P[i].out_center || P[i].out_disp || P[i].out_nbobs_k || P[i].out_c ||
+                                         (src != nullptr && src->labels != nullptr && src->labels[i] != nullptr);
                 if (want && total <= kStageMax) {
                     if (pool_get(device, false, total, &gf.dev, &dev_size) != hipSuccess) { (void)hipGetLastError(); gf.dev = nullptr; }
                     if (gf.dev && pool_get(device, true, total, &gf.host, &host_size) != hipSuccess) { (void)hipGetLastError(); gf.host = nullptr; }
@@ -2911,6 +2947,186 @@ static int solve_many_one(nemgpu_problem* P, int count, const nemgpu_config* cfg
     for (int i = 0; i < count; i++)
         if (P[i].rc != NEMGPU_OK && rc == NEMGPU_OK) { rc = P[i].rc; first_err = errs[(size_t)i]; }
     if (rc != NEMGPU_OK && !first_err.empty()) set_error(first_err);
+    return rc;
+}
+
+
+// ============================================================================================
+// Chunks of a master pangenome, formed on the device (nem_chunks.hpp / nem_chunks.hip): the samples of partition()'s
+// voting loop (ppanggolin.py:1045-1086), each the input files of __write_nem_input_files (ppanggolin.py:821-930) for
+// that sample -- without the files, and without a matrix or a graph crossing PCIe per sample.
+// ============================================================================================
+int nemgpu_master_create(nemgpu_master** out, int device, int n, int d, const uint32_t* xbits, const int32_t* nei_ptr,
+                         const int32_t* nei_idx, const uint32_t* edge_bits)
+{
+    if (!out) return NEMGPU_E_FUNCARG;
+    *out = nullptr;
+    if (n <= 0 || d <= 0 || !xbits || !nei_ptr) { set_error("nemgpu_master_create: sizes, bit rows and row pointers are needed"); return NEMGPU_E_FUNCARG; }
+    const int wf = (d + 31) / 32, nw64 = (n + 63) / 64;
+    if (wf > nemk::chunk_mask_words_max()) { set_error("nemgpu_master_create: more than 131 072 organisms"); return NEMGPU_E_ARG; }
+    const long long nnz_ll = (long long)nei_ptr[n] - nei_ptr[0];
+    if (nei_ptr[0] != 0 || nnz_ll < 0 || nnz_ll > 0x7fffffff) { set_error("graph: ptr[0] must be 0 and ptr non-decreasing"); return NEMGPU_E_ARG; }
+    const int nnz = (int)nnz_ll;
+    for (int i = 0; i < n; i++) if (nei_ptr[i + 1] < nei_ptr[i]) { set_error("graph: ptr not monotone"); return NEMGPU_E_ARG; }
+    if (nnz > 0 && (!nei_idx || !edge_bits)) { set_error("nemgpu_master_create: a graph needs neighbour indices and edge organism sets"); return NEMGPU_E_FUNCARG; }
+    for (int t = 0; t < nnz; t++) if (nei_idx[t] < 0 || nei_idx[t] >= n) { set_error("graph: neighbour index out of range"); return NEMGPU_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no usable HIP device: this library has no CPU fallback"); return NEMGPU_E_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("nemgpu_master_create: bad device index"); return NEMGPU_E_ARG; }
+    g_hip_used.store(true);
+    HIPCHK(hipSetDevice(device));
+    nemgpu_master* m = new nemgpu_master();
+    m->device = device; m->n = n; m->d = d; m->wf = wf; m->nw64 = nw64; m->nnz = nnz;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_xt = a256((size_t)d * nw64 * 8), b_ptr = a256(((size_t)n + 1) * 4), b_idx = a256((size_t)std::max(nnz, 1) * 4),
+                 b_eb = a256((size_t)std::max(nnz, 1) * wf * 4), b_xf = a256((size_t)n * wf * 4);
+    uint32_t* xf_tmp = nullptr;
+    auto fail = [&](const char* what) { if (xf_tmp) (void)hipFree(xf_tmp); if (m->block) (void)hipFree(m->block);
+                                        if (m->stream) (void)hipStreamDestroy(m->stream); delete m; set_error(what); return NEMGPU_E_DEVICE; };
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipMalloc(&m->block, b_xt + b_ptr + b_idx + b_eb) != hipSuccess) return fail("nemgpu_master_create: device memory");
+    if (hipMalloc(&xf_tmp, b_xf) != hipSuccess) return fail("nemgpu_master_create: device memory");
+    uint64_t* xt = (uint64_t*)m->block;
+    int* dptr = (int*)(m->block + b_xt);
+    int* didx = (int*)(m->block + b_xt + b_ptr);
+    uint32_t* deb = (uint32_t*)(m->block + b_xt + b_ptr + b_idx);
+    // the bits above organism d - 1 in a row's last word are not data
+    std::vector<uint32_t> rows(xbits, xbits + (size_t)n * wf);
+    if (d & 31) { const uint32_t keep = (1u << (d & 31)) - 1u; for (int i = 0; i < n; i++) rows[(size_t)i * wf + wf - 1] &= keep; }
+    hipError_t err = hipMemcpyAsync(xf_tmp, rows.data(), (size_t)n * wf * 4, hipMemcpyHostToDevice, m->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(dptr, nei_ptr, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, m->stream);
+    if (err == hipSuccess && nnz > 0) err = hipMemcpyAsync(didx, nei_idx, (size_t)nnz * 4, hipMemcpyHostToDevice, m->stream);
+    if (err == hipSuccess && nnz > 0) err = hipMemcpyAsync(deb, edge_bits, (size_t)nnz * wf * 4, hipMemcpyHostToDevice, m->stream);
+    if (err == hipSuccess) { nemk::launch_master_transpose(xf_tmp, n, wf, d, nw64, xt, m->stream); err = hipGetLastError(); }
+    if (err == hipSuccess) err = hipStreamSynchronize(m->stream);
+    if (err != hipSuccess) return fail("nemgpu_master_create: upload failed");
+    (void)hipFree(xf_tmp);
+    m->dev = nemk::MasterDev{n, d, wf, nw64, nnz, xt, dptr, didx, deb};
+    *out = m;
+    return NEMGPU_OK;
+}
+
+void nemgpu_master_destroy(nemgpu_master* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->block) (void)hipFree(m->block);
+    delete m;
+}
+
+// the engine's matrix staging rows, lane order and graph block filled by the device from the master (the engine was
+// created with n = the chunk's kept families, d = the sample's organisms)
+static int adopt_chunk(nemgpu_engine* e, const nemgpu_master* M, const nemk::ChunkPlan& plan, int nnz_c)
+{
+    if (e->device != M->device) { set_error("a chunk's engine lives on its master's device"); return NEMGPU_E_ARG; }
+    HIPCHK(hipSetDevice(e->device));
+    alloc_for(e);
+    int r;
+    const size_t words = (size_t)e->n * e->wf;
+    if ((r = dev_alloc(&e->xf_stage, words + (size_t)e->npad))) return r;
+    e->perm = reinterpret_cast<int*>(e->xf_stage + words);
+    const int nnz = std::max(nnz_c, 0);
+    const size_t b_ptr = sizeof(int) * ((size_t)e->n + 1), b_nz = sizeof(int) * (size_t)std::max(nnz, 1);
+    const size_t o_idx = (b_ptr + 255) & ~(size_t)255, o_w = (o_idx + b_nz + 255) & ~(size_t)255, total = o_w + b_nz;
+    char* dev = nullptr;
+    if ((r = dev_alloc(&dev, total))) return r;
+    e->nei_ptr = (int*)dev; e->nei_idx = (int*)(dev + o_idx); e->nei_w = (float*)(dev + o_w);
+    nemk::ChunkFill f{e->n, e->d, e->wf, e->npad, e->xf_stage, e->perm, e->nei_ptr, e->nei_idx, e->nei_w};
+    nemk::launch_chunk_fill(M->dev, plan, f, e->stream);
+    HIPCHK(hipGetLastError());
+    e->nnz = nnz; e->has_graph = nnz > 0; e->exp_need = kExpTabGlobal;
+    e->host_bits = nullptr; e->host_bits_words = 0;              // (no host copy of the rows: random starts are not for chunk engines)
+    if (e->defer_layout) e->layout_pending = true;               // (the group's first step carries the layouts, zipped)
+    else { launch_layout(e->xf_stage, e->n, e->wf, e->W, e->npad, e->d, e->nw64, e->xw, e->xt, e->perm, e->xws, e->stream); HIPCHK(hipGetLastError()); }
+    e->have_matrix = true;
+    return NEMGPU_OK;
+}
+
+int nemgpu_solve_chunks(nemgpu_master* M, nemgpu_chunk* chunks, int count, int k, const float* prop, const float* center_k,
+                        const float* disp_k, const nemgpu_config* cfg, int workers, int group)
+{
+    if (!M || !chunks || count <= 0 || k <= 0 || k > kMaxKernelK || !prop || !center_k || !disp_k || !cfg) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(M->device));
+    const int n = M->n, nw64 = M->nw64, wf = M->wf, nnz = M->nnz;
+    size_t org_total = 0;
+    int max_dc = 0;
+    for (int c = 0; c < count; c++) {
+        nemgpu_chunk& q = chunks[c];
+        q.rc = NEMGPU_OK; q.n = 0; q.nnz = 0; q.result = nemgpu_result{};
+        if (!q.organisms || q.dc <= 0 || q.dc > M->d) { set_error("nemgpu_solve_chunks: chunk " + std::to_string(c) + ": 1 .. d organisms are needed"); return NEMGPU_E_FUNCARG; }
+        for (int t = 0; t < q.dc; t++)
+            if (q.organisms[t] < 0 || q.organisms[t] >= M->d) { set_error("nemgpu_solve_chunks: chunk " + std::to_string(c) + ": organism index out of range"); return NEMGPU_E_ARG; }
+        org_total += ((size_t)q.dc + 63) & ~(size_t)63;
+        max_dc = std::max(max_dc, q.dc);
+    }
+    // ---- phase 1, all chunks: which families, which edges, how many of each
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_mask = a256((size_t)wf * 4), b_keep = a256((size_t)nw64 * 8), b_list = a256((size_t)n * 4), b_cov = a256((size_t)std::max(nnz, 1) * 2),
+                 b_ptr = a256(((size_t)n + 1) * 4), b_cnt = 256;
+    const size_t per = b_mask + b_keep + 2 * b_list + b_cov + b_ptr + b_cnt;
+    const size_t b_plans = a256((size_t)count * sizeof(nemk::ChunkPlan)), b_org = a256(org_total * 4);
+    char* slab = nullptr;
+    if (hipMalloc(&slab, b_plans + b_org + per * (size_t)count) != hipSuccess) { (void)hipGetLastError(); set_error("nemgpu_solve_chunks: device memory for the chunk plans"); return NEMGPU_E_MEMORY; }
+    struct SlabFree { char* p; ~SlabFree() { if (p) (void)hipFree(p); } } slab_free{slab};
+    std::vector<nemk::ChunkPlan> plans((size_t)count);
+    std::vector<int> org_host(org_total, 0);
+    {
+        size_t oo = 0;
+        for (int c = 0; c < count; c++) {
+            char* b = slab + b_plans + b_org + per * (size_t)c;
+            nemk::ChunkPlan& p = plans[(size_t)c];
+            p.organisms = reinterpret_cast<const int*>(slab + b_plans) + oo; p.dc = chunks[c].dc;
+            memcpy(org_host.data() + oo, chunks[c].organisms, (size_t)chunks[c].dc * 4);
+            oo += ((size_t)chunks[c].dc + 63) & ~(size_t)63;
+            p.mask = (uint32_t*)b; b += b_mask;
+            p.keep = (uint64_t*)b; b += b_keep;
+            p.list = (int*)b; b += b_list;
+            p.map = (int*)b; b += b_list;
+            p.cov = (uint16_t*)b; b += b_cov;
+            p.ptr = (int*)b; b += b_ptr;
+            p.counts = (int*)b;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(slab, plans.data(), (size_t)count * sizeof(nemk::ChunkPlan), hipMemcpyHostToDevice, M->stream));
+    HIPCHK(hipMemcpyAsync(slab + b_plans, org_host.data(), org_total * 4, hipMemcpyHostToDevice, M->stream));
+    nemk::launch_chunk_plan(M->dev, reinterpret_cast<const nemk::ChunkPlan*>(slab), count, max_dc, M->stream);
+    HIPCHK(hipGetLastError());
+    std::vector<int> counts((size_t)count * 2);
+    for (int c = 0; c < count; c++) {
+        HIPCHK(hipMemcpyAsync(&counts[(size_t)c * 2], plans[(size_t)c].counts, 8, hipMemcpyDeviceToHost, M->stream));
+        if (chunks[c].keep) HIPCHK(hipMemcpyAsync(chunks[c].keep, plans[(size_t)c].keep, (size_t)nw64 * 8, hipMemcpyDeviceToHost, M->stream));
+    }
+    HIPCHK(hipStreamSynchronize(M->stream));
+    // ---- the problems: sizes from phase 1, PPanGGOLiN-style initial parameters (one value per class and kind)
+    std::vector<nemgpu_problem> P((size_t)count);
+    std::vector<int> nnzc((size_t)count);
+    std::vector<uint8_t*> labels((size_t)count, nullptr);
+    std::map<int, std::vector<float>> init;                   // sample size -> prop | center | disp
+    for (int c = 0; c < count; c++) {
+        nemgpu_chunk& q = chunks[c];
+        q.n = counts[(size_t)c * 2]; q.nnz = counts[(size_t)c * 2 + 1];
+        if (q.n <= 0) { set_error("nemgpu_solve_chunks: chunk " + std::to_string(c) + " holds no family"); q.rc = NEMGPU_E_ARG; return NEMGPU_E_ARG; }
+        nnzc[(size_t)c] = q.nnz;
+        labels[(size_t)c] = q.labels;
+        std::vector<float>& v = init[q.dc];
+        if (v.empty()) {
+            v.resize((size_t)k + 2 * (size_t)k * q.dc);
+            for (int h = 0; h < k; h++) {
+                v[(size_t)h] = prop[h];
+                for (int o = 0; o < q.dc; o++) { v[(size_t)k + (size_t)h * q.dc + o] = center_k[h]; v[(size_t)k + (size_t)k * q.dc + (size_t)h * q.dc + o] = disp_k[h]; }
+            }
+        }
+        nemgpu_problem& p = P[(size_t)c];
+        p = nemgpu_problem{};
+        p.n = q.n; p.d = q.dc; p.k = k;
+        p.prop = v.data(); p.center = v.data() + k; p.disp = v.data() + k + (size_t)k * q.dc;
+        p.out_prop = q.out_prop; p.out_center = q.out_center; p.out_disp = q.out_disp; p.out_nbobs_k = q.out_nbobs_k; p.out_c = nullptr;
+    }
+    ChunkSource src;
+    src.master = M; src.plans = plans.data(); src.nnz = nnzc.data(); src.labels = labels.data();
+    const int rc = solve_many_one(P.data(), count, cfg, M->device, workers, group, &src);
+    for (int c = 0; c < count; c++) { chunks[c].rc = P[(size_t)c].rc; chunks[c].result = P[(size_t)c].result; }
     return rc;
 }
 

@@ -147,6 +147,33 @@ def ring_graph(n, seed, deg, wlo, whi):
     return ptr, dst.astype(np.int32), wu[inv].astype(np.float32)
 
 
+def master_pangenome(n, d, seed, chord_frac=0.05, carry_path=0.8, carry_chord=0.08):
+    """A whole pangenome for the chunk voting loop (ppanggolin.py:995-1097): the U-shaped presence/absence matrix over ALL
+    d organisms, the contiguity graph's structure, and per directed edge the organisms that carry the adjacency -- a
+    subset of those where both families are present (a path edge in most of them, a chord in few), the same set in both
+    directions.  Returns x uint8 [n][d], (ptr, idx), edge_bits uint32 [nnz][ceil(d/32)]."""
+    x, _ = ushaped_pa_matrix(n, d, seed)
+    ptr, idx, _ = contiguity_graph(n, seed, chord_frac=chord_frac)
+    rng = np.random.Generator(np.random.PCG64(seed + 15485863))
+    src = np.repeat(np.arange(n), np.diff(ptr)).astype(np.int64)
+    dst = idx.astype(np.int64)
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    uniq, inv = np.unique(lo * n + hi, return_inverse=True)
+    ulo, uhi = uniq // n, uniq % n
+    wf = (d + 31) // 32
+    ebits_u = np.zeros((len(uniq), wf * 4), np.uint8)
+    step = max(1, (1 << 24) // max(d, 1))
+    for e0 in range(0, len(uniq), step):
+        e1 = min(len(uniq), e0 + step)
+        both = x[ulo[e0:e1]] & x[uhi[e0:e1]]
+        p = np.where(np.abs(uhi[e0:e1] - ulo[e0:e1]) == 1, carry_path, carry_chord)[:, None]
+        carry = (both.astype(bool) & (rng.random((e1 - e0, d), dtype=np.float32) < p)).astype(np.uint8)
+        packed = np.packbits(carry, axis=1, bitorder="little")
+        ebits_u[e0:e1, :packed.shape[1]] = packed
+    edge_bits = ebits_u.view(np.uint32)[inv]
+    return x, (ptr, idx), np.ascontiguousarray(edge_bits)
+
+
 def default_init(d, low_disp=0.1):
     """PPanGGOLiN's default .m (ppanggolin.py:893-901): pi 0.33333/0.33333/rest, mu 1/0.5/0,
     eps low/0.5/low.  pi_K is computed as ReadParamFile does (float 1 - p0 - p1, nem_exe.c:1022-1034)."""
