@@ -468,6 +468,39 @@ def also_single_gpu(args, k, beta):
                                        "and parameters fetched; best of 3 jobs")
     except Exception as exc:
         also["chunks_256"] = {"error": repr(exc)}
+    # (5) the same kind of job the way partition()'s voting loop poses it (ppanggolin.py:1045-1086): 256 samples of 500
+    # organisms out of ONE 20 000 x 5 000 pangenome that lives on the device -- every sample's problem (kept families,
+    # columns, coverage-weighted graph) is formed there, nothing but initial parameters and results crosses PCIe
+    try:
+        from pangenomenem_amd.chunks import Master
+        P = 256
+        x, (ptr, idx), eb = synth.master_pangenome(20000, 5000, 2)
+        rng = np.random.default_rng(0)
+        subs = [rng.permutation(5000)[:500] for _ in range(P)]
+        m = Master(x, ptr, idx, eb)
+        del x
+        kw = dict(workers=8, group=64, want_params=False, algo="ncem", beta=beta, disper="sk_", tie="hash", seed=1)
+        m.solve_chunks(subs[:64], **kw)
+        best, res = None, None
+        for _ in range(3):
+            res = m.solve_chunks(subs, **kw)
+            best = m.last_call_seconds if best is None else min(best, m.last_call_seconds)
+        short = None
+        for _ in range(3):
+            m.solve_chunks(subs, **dict(kw, it_max=1))
+            short = m.last_call_seconds if short is None else min(short, m.last_call_seconds)
+        m.close()
+        iters = int(sum(r["iters"] for r in res))
+        also["chunks_256_from_resident_master"] = dict(
+            problems=P, master=[20000, 5000], sample_organisms=500, workers=8, group=64, seconds=best, whole_problems_per_sec=P / best,
+            em_iterations=iters, us_per_problem_iteration=best * 1e6 / max(iters, 1),
+            mean_families=float(np.mean([r["n"] for r in res])), mean_directed_edges=float(np.mean([r["nnz"] for r in res])),
+            one_iteration_whole_problems_per_sec=P / short,
+            note="nemgpu_solve_chunks (library call alone, best of 3): coverage weights as the reference computes them (a chunk needs "
+                 "~16 EM iterations on them, against 7 on chunks_256's weights 1..8); one_iteration: the same job cut off after one "
+                 "EM iteration = the pipeline around the EM (formation, start, results)")
+    except Exception as exc:
+        also["chunks_256_from_resident_master"] = {"error": repr(exc)}
     return also
 
 

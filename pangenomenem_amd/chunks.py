@@ -143,8 +143,11 @@ class Master:
                 q.out_prop, q.out_center, q.out_disp, q.out_nbobs_k = (o[f].ctypes.data for f in ("prop", "center", "disp", "nbobs_k"))
             hold.append(org)
             outs.append(o)
+        import time
+        t0 = time.perf_counter()
         rc = lib.nemgpu_solve_chunks(self._h, arr, len(samples), int(k), prop.ctypes.data, center_k.ctypes.data, disp_k.ctypes.data,
                                      C.byref(cfg), int(workers), int(group))
+        self.last_call_seconds = time.perf_counter() - t0     # (the library call alone: what follows is numpy bookkeeping)
         if rc != STATUS_OK:
             raise NemGpuError("nemgpu_solve_chunks failed (status %d): %s" % (rc, lib.nemgpu_last_error().decode()))
         res = []

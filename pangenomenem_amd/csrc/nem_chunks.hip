@@ -148,25 +148,44 @@ __global__ __launch_bounds__(1024) void k_chunk_ptr(const ChunkPlan* __restrict_
 // ---- phase 2: the engine's own buffers
 // One block per 256-family tile: the tile's bit rows (column t = organism organisms[t]: ppanggolin.py:850) and, from
 // their popcounts, the tile's lane order for the density kernels (stable by popcount, as upload_bits sorts on the host).
+// The tile's 256 kept families are consecutive set bits of the master's order: they span a few 64-family words of every
+// organism row.  Those words go through LDS, kChunkOrgs organisms at a time (coalesced loads, one per thread and word),
+// and every thread picks its family's bit out of them -- instead of one global load per family and organism.
+constexpr int kChunkOrgs = 256;              // organisms staged per pass
+constexpr int kChunkSpan = 12;               // 64-family words of a row a pass can stage (768 master families under the tile)
 __global__ __launch_bounds__(256) void k_chunk_rows(ChunkPlan p, ChunkFill f, const uint64_t* __restrict__ xt, int nw64)
 {
     __shared__ int s_pc[256];
+    __shared__ uint64_t s_rows[kChunkOrgs][kChunkSpan + 1];
     const int tile0 = blockIdx.x * 256;
     const int j = tile0 + threadIdx.x;
-    int pc = 0x7fffffff;
-    if (j < f.nc) {
-        const int i = p.list[j];
-        const int g = i >> 6, bit = i & 63;
-        pc = 0;
-        for (int w = 0; w < f.wfc; w++) {
-            uint32_t word = 0;
-            const int t1 = min(32, f.dc - 32 * w);
-            for (int b = 0; b < t1; b++) {
-                const uint64_t v = xt[(size_t)p.organisms[32 * w + b] * nw64 + g];
-                word |= (uint32_t)((v >> bit) & 1ull) << b;
+    const int jlast = min(tile0 + 255, f.nc - 1);
+    const int g0 = p.list[tile0] >> 6, g1 = p.list[jlast] >> 6;   // (tile0 < nc: the grid has a block per started tile)
+    const bool staged = g1 - g0 < kChunkSpan;
+    const int i = j < f.nc ? p.list[j] : 0;
+    const int g = i >> 6, bit = i & 63;
+    int pc = j < f.nc ? 0 : 0x7fffffff;
+    for (int t0 = 0; t0 < f.dc; t0 += kChunkOrgs) {              // (kChunkOrgs is a multiple of 32: passes start on a word)
+        const int tn = min(kChunkOrgs, f.dc - t0);
+        if (staged) {
+            __syncthreads();
+            if ((int)threadIdx.x < tn) {
+                const uint64_t* __restrict__ row = xt + (size_t)p.organisms[t0 + threadIdx.x] * nw64 + g0;
+                for (int q = 0; q <= g1 - g0; q++) s_rows[threadIdx.x][q] = row[q];
             }
-            f.xf[(size_t)j * f.wfc + w] = word;
-            pc += __popc(word);
+            __syncthreads();
+        }
+        if (j < f.nc) {
+            for (int w = 0; 32 * w < tn; w++) {
+                uint32_t word = 0;
+                const int b1 = min(32, tn - 32 * w);
+                for (int b = 0; b < b1; b++) {
+                    const uint64_t v = staged ? s_rows[32 * w + b][g - g0] : xt[(size_t)p.organisms[t0 + 32 * w + b] * nw64 + g];
+                    word |= (uint32_t)((v >> bit) & 1ull) << b;
+                }
+                f.xf[(size_t)j * f.wfc + (t0 >> 5) + w] = word;
+                pc += __popc(word);
+            }
         }
     }
     s_pc[threadIdx.x] = pc;

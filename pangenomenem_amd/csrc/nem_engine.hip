@@ -3064,28 +3064,34 @@ int nemgpu_solve_chunks(nemgpu_master* M, nemgpu_chunk* chunks, int count, int k
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b_mask = a256((size_t)wf * 4), b_keep = a256((size_t)nw64 * 8), b_list = a256((size_t)n * 4), b_cov = a256((size_t)std::max(nnz, 1) * 2),
                  b_ptr = a256(((size_t)n + 1) * 4), b_cnt = 256;
-    const size_t per = b_mask + b_keep + 2 * b_list + b_cov + b_ptr + b_cnt;
-    const size_t b_plans = a256((size_t)count * sizeof(nemk::ChunkPlan)), b_org = a256(org_total * 4);
+    (void)b_cnt;
+    const size_t per = b_mask + 2 * b_list + b_cov + b_ptr;
+    // (every chunk's two counters and kept-family bits sit together: two copies bring them all to the host)
+    const size_t b_plans = a256((size_t)count * sizeof(nemk::ChunkPlan)), b_org = a256(org_total * 4), b_counts = a256((size_t)count * 8),
+                 b_keeps = b_keep * (size_t)count;
+    const size_t o_counts = b_plans + b_org, o_keeps = o_counts + b_counts, o_per = o_keeps + b_keeps;
+    static const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     char* slab = nullptr;
-    if (hipMalloc(&slab, b_plans + b_org + per * (size_t)count) != hipSuccess) { (void)hipGetLastError(); set_error("nemgpu_solve_chunks: device memory for the chunk plans"); return NEMGPU_E_MEMORY; }
+    if (hipMalloc(&slab, o_per + per * (size_t)count) != hipSuccess) { (void)hipGetLastError(); set_error("nemgpu_solve_chunks: device memory for the chunk plans"); return NEMGPU_E_MEMORY; }
     struct SlabFree { char* p; ~SlabFree() { if (p) (void)hipFree(p); } } slab_free{slab};
     std::vector<nemk::ChunkPlan> plans((size_t)count);
     std::vector<int> org_host(org_total, 0);
     {
         size_t oo = 0;
         for (int c = 0; c < count; c++) {
-            char* b = slab + b_plans + b_org + per * (size_t)c;
+            char* b = slab + o_per + per * (size_t)c;
             nemk::ChunkPlan& p = plans[(size_t)c];
             p.organisms = reinterpret_cast<const int*>(slab + b_plans) + oo; p.dc = chunks[c].dc;
             memcpy(org_host.data() + oo, chunks[c].organisms, (size_t)chunks[c].dc * 4);
             oo += ((size_t)chunks[c].dc + 63) & ~(size_t)63;
             p.mask = (uint32_t*)b; b += b_mask;
-            p.keep = (uint64_t*)b; b += b_keep;
+            p.keep = (uint64_t*)(slab + o_keeps + b_keep * (size_t)c);
             p.list = (int*)b; b += b_list;
             p.map = (int*)b; b += b_list;
             p.cov = (uint16_t*)b; b += b_cov;
-            p.ptr = (int*)b; b += b_ptr;
-            p.counts = (int*)b;
+            p.ptr = (int*)b;
+            p.counts = (int*)(slab + o_counts) + 2 * (size_t)c;
         }
     }
     HIPCHK(hipMemcpyAsync(slab, plans.data(), (size_t)count * sizeof(nemk::ChunkPlan), hipMemcpyHostToDevice, M->stream));
@@ -3093,11 +3099,15 @@ int nemgpu_solve_chunks(nemgpu_master* M, nemgpu_chunk* chunks, int count, int k
     nemk::launch_chunk_plan(M->dev, reinterpret_cast<const nemk::ChunkPlan*>(slab), count, max_dc, M->stream);
     HIPCHK(hipGetLastError());
     std::vector<int> counts((size_t)count * 2);
-    for (int c = 0; c < count; c++) {
-        HIPCHK(hipMemcpyAsync(&counts[(size_t)c * 2], plans[(size_t)c].counts, 8, hipMemcpyDeviceToHost, M->stream));
-        if (chunks[c].keep) HIPCHK(hipMemcpyAsync(chunks[c].keep, plans[(size_t)c].keep, (size_t)nw64 * 8, hipMemcpyDeviceToHost, M->stream));
-    }
+    std::vector<char> keeps;
+    bool want_keep = false;
+    for (int c = 0; c < count; c++) want_keep = want_keep || chunks[c].keep != nullptr;
+    HIPCHK(hipMemcpyAsync(counts.data(), slab + o_counts, (size_t)count * 8, hipMemcpyDeviceToHost, M->stream));
+    if (want_keep) { keeps.resize(b_keeps); HIPCHK(hipMemcpyAsync(keeps.data(), slab + o_keeps, b_keeps, hipMemcpyDeviceToHost, M->stream)); }
     HIPCHK(hipStreamSynchronize(M->stream));
+    if (want_keep)
+        for (int c = 0; c < count; c++) if (chunks[c].keep) memcpy(chunks[c].keep, keeps.data() + b_keep * (size_t)c, (size_t)nw64 * 8);
+    const auto t_plan = std::chrono::steady_clock::now();
     // ---- the problems: sizes from phase 1, PPanGGOLiN-style initial parameters (one value per class and kind)
     std::vector<nemgpu_problem> P((size_t)count);
     std::vector<int> nnzc((size_t)count);
@@ -3125,8 +3135,14 @@ int nemgpu_solve_chunks(nemgpu_master* M, nemgpu_chunk* chunks, int count, int k
     }
     ChunkSource src;
     src.master = M; src.plans = plans.data(); src.nnz = nnzc.data(); src.labels = labels.data();
+    const auto t_prep = std::chrono::steady_clock::now();
     const int rc = solve_many_one(P.data(), count, cfg, M->device, workers, group, &src);
     for (int c = 0; c < count; c++) { chunks[c].rc = P[(size_t)c].rc; chunks[c].result = P[(size_t)c].result; }
+    if (prof) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[solve_chunks] %d chunks: plans (which families, which edges; one wait) %.2f ms, problem records %.2f ms, pipeline %.2f ms\n",
+                count, ms(t_begin, t_plan), ms(t_plan, t_prep), ms(t_prep, std::chrono::steady_clock::now()));
+    }
     return rc;
 }
 
