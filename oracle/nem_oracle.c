@@ -160,6 +160,16 @@ int orc_relax_round(int lo, int hi, int k, const int* nei_ptr_local, const int* 
                     float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
                     unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out)
 {
+    return orc_relax_round_keyed(lo, hi, k, nei_ptr_local, nei_idx, nei_w, beta, pkfki_local, ncem, tie_rule, tie_seed, sweep_id,
+                                 c_old, c_guess, c_out, 0);
+}
+
+/* ... with the tie hash keyed by (site - key_bias): a rank of the sharded driver works in label SLOTS (every rank's block
+   is followed by a flag tail), the hash rule is keyed by the family's true index -- key_bias = the slots skipped below */
+int orc_relax_round_keyed(int lo, int hi, int k, const int* nei_ptr_local, const int* nei_idx, const float* nei_w,
+                          float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
+                          unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out, int key_bias)
+{
     double* cinum = (double*)malloc(sizeof(double) * (size_t)k);
     float* row = (float*)malloc(sizeof(float) * (size_t)k);
     int* kmaxes = (int*)malloc(sizeof(int) * (size_t)k);
@@ -186,7 +196,7 @@ int orc_relax_round(int lo, int hi, int k, const int* nei_ptr_local, const int* 
             for (kk = 0; kk < k; kk++) row[kk] = (float)invz;
         }
         if (ncem) {
-            int kmap = orc_map(row, k, tie_rule, tie_seed, sweep_id, (unsigned)gi, kmaxes);
+            int kmap = orc_map(row, k, tie_rule, tie_seed, sweep_id, (unsigned)(gi - key_bias), kmaxes);
             for (kk = 0; kk < k; kk++) row[kk] = 0.0f;
             row[kmap] = 1.0f;
         }

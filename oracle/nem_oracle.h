@@ -90,6 +90,9 @@ int orc_sweep(int n, int k, const int* nei_ptr, const int* nei_idx, const float*
 int orc_relax_round(int lo, int hi, int k, const int* nei_ptr_local, const int* nei_idx, const float* nei_w,
                     float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
                     unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out);
+int orc_relax_round_keyed(int lo, int hi, int k, const int* nei_ptr_local, const int* nei_idx, const float* nei_w,
+                    float beta, const double* pkfki_local, int ncem, int tie_rule, unsigned tie_seed,
+                    unsigned sweep_id, const float* c_old, const float* c_guess, float* c_out, int key_bias);
 
 /* M: EstimPara for FAMILY_BERNOULLI (nem_mod.c:415-469, 1180-1479, 1646-1704, 922-1174) */
 int orc_mstep(int n, int d, int k, const unsigned char* x, const float* c_nk,

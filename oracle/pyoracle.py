@@ -106,17 +106,17 @@ class Oracle:
         return c, nz
 
     def relax_round(self, lo, hi, nei_local, beta, pkfki_local, ncem, c_old, c_guess, c_out, tie="hash", seed=0,
-                    sweep_id=0):
+                    sweep_id=0, key_bias=0):
         """One relaxation round for sites [lo, hi); c_* are GLOBAL [n_total, k] float32 arrays (c_out is
         written in place).  Returns the number of changed sites."""
         k = c_old.shape[1]
         ptr, idx, w = _csr(hi - lo, nei_local)
         pk = np.ascontiguousarray(pkfki_local, np.float64)
         assert c_old.flags.c_contiguous and c_guess.flags.c_contiguous and c_out.flags.c_contiguous
-        return int(self.lib.orc_relax_round(lo, hi, k, _p(ptr, C.c_int), _p(idx, C.c_int), _p(w, C.c_float),
-                                            C.c_float(beta), _p(pk, C.c_double), int(ncem), TIE[tie], C.c_uint(seed),
-                                            C.c_uint(sweep_id), _p(c_old, C.c_float), _p(c_guess, C.c_float),
-                                            _p(c_out, C.c_float)))
+        return int(self.lib.orc_relax_round_keyed(lo, hi, k, _p(ptr, C.c_int), _p(idx, C.c_int), _p(w, C.c_float),
+                                                  C.c_float(beta), _p(pk, C.c_double), int(ncem), TIE[tie], C.c_uint(seed),
+                                                  C.c_uint(sweep_id), _p(c_old, C.c_float), _p(c_guess, C.c_float),
+                                                  _p(c_out, C.c_float), int(key_bias)))
 
     def mstep(self, x, c, disper, propor, prop, center, disp):
         n, d = x.shape

@@ -130,10 +130,10 @@ class OracleStepper:
         sid = self.sweep_next if sweep_id < 0 else sweep_id
         c_old, c_guess = self._onehot(old.numpy()), self._onehot(guess.numpy())
         c_out = np.zeros_like(c_old)
-        # the oracle's round works on the slot index space directly (lo/hi/nei are slots); its tie hash is
-        # keyed by the slot index too, so the tests use tie-free data
+        # the oracle's round works on the slot index space directly (lo/hi/nei are slots); the tie hash is keyed by the
+        # family's TRUE index: the slots of the flag tails below this rank's block are taken off
         self.o.relax_round(self.lo, self.lo + self.n, self.nei, beta, self.pk, True, c_old, c_guess, c_out, tie="hash",
-                           seed=self.seed, sweep_id=sid)
+                           seed=self.seed, sweep_id=sid, key_bias=self.rank * (self.stride - self.blk))
         new = c_out[self.lo:self.lo + self.n].argmax(1).astype(np.uint8)
         changed = int(np.any(new != guess.numpy()[self.lo:self.lo + self.n]))
         out.numpy()[self.lo:self.lo + self.n] = new
@@ -214,6 +214,10 @@ def _worker(rank, world, initfile, n, d, beta, kind, outdir):
         else:
             x, _ = synth.bernoulli_pa_matrix(n, d, 1)
         nei = synth.contiguity_graph(n, 1)
+        if kind == "coverage":                                    # PPanGGOLiN's own weights: counts of organisms, 1..d
+            nei = synth.contiguity_graph(n, 1, chord_frac=0.3, weights="coverage", d=d)
+        elif kind == "ring709":                                   # beta * sum(w) on either side of 709: NaN rows, ties
+            nei = synth.ring_graph(n, 6, 8, 150, 200)
         prop, center, disp = synth.default_init(d)
         lo, hi, _ = shard_bounds(n, world, rank)
         blk, stride = slot_layout(n, world, 3 + 3 * d)
@@ -253,6 +257,28 @@ def test_sharded_em_equals_single_process_oracle(oracle, world, n, d, beta):
         assert np.array_equal(o["center"], want["center"])
         assert np.array_equal(o["disp"], want["disp"]) and np.array_equal(o["prop"], want["prop"])
         assert np.array_equal(o["nbobs_k"], want["nbobs_k"])
+
+
+@pytest.mark.parametrize("world,n,d,kind", [(2, 1500, 400, "coverage"), (8, 2000, 300, "coverage"), (2, 600, 100, "ring709"), (3, 600, 100, "ring709")])
+def test_sharded_em_with_heavy_edge_weights(oracle, world, n, d, kind):
+    """The weights the reference's caller writes (counts of organisms) and weight sums that straddle the overflow of the
+    site's exp (NaN rows: ComputeMAP's ties are hashed per site and sweep, the same on every rank): the sharded protocol
+    -- the oracle as every rank's stepper -- ends where the single process ends, or stops with the same emptied class."""
+    from pangenomenem_amd import synth
+    outs = _run(world, n, d, 0.5, kind=kind)
+    x, _ = synth.bernoulli_pa_matrix(n, d, 1)
+    nei = synth.contiguity_graph(n, 1, chord_frac=0.3, weights="coverage", d=d) if kind == "coverage" else synth.ring_graph(n, 6, 8, 150, 200)
+    prop, center, disp = synth.default_init(d)
+    want = oracle.run(x, nei, 3, prop, center, disp, algo="ncem", beta=0.5, tie="hash", seed=11)
+    assert np.isneginf(want["crit"][3]) or want["status"] == 2    # (the regime: M = -inf, or a class emptied by NaN rows)
+    for o in outs:
+        assert int(o["status"]) == want["status"] and int(o["iters"]) == want["iters"]
+        if want["status"] == 2:
+            assert int(o["emptyk"]) == want["emptyk"]
+            continue
+        assert bool(o["converged"]) == want["converged"]
+        assert np.array_equal(o["labels"], want["c"].argmax(1))
+        assert np.array_equal(o["center"], want["center"]) and np.array_equal(o["disp"], want["disp"])
 
 
 def test_sharded_em_empty_class(oracle):

@@ -98,6 +98,46 @@ def test_heavy_fixtures_family_sharded(gpu_lib, name, world, backend):
         assert maxdiff(o["disp"], exp["disp"]) <= TOL and maxdiff(o["prop"], exp["prop"]) <= TOL
 
 
+def _fuzzy_worker(rank, world, initfile, name, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from pangenomenem_amd.distributed import Comm, ShardedFuzzyNem
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        case = load_case(name)
+        cfg = case["cfg"]
+        job = ShardedFuzzyNem.from_problem(case["x"], case["nei"], case["k"], case["prop"], case["center"], case["disp"], cfg["beta"],
+                                           rank, world, 0, disper=cfg["disper"])
+        res = job.run(cfg["it_max"])
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), c=job.memberships(), iters=res["iters"], status=res["status"],
+                 emptyk=res["emptyk"], **job.params())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["cov60_nem_sk", "cov500_nem_sk", "mid88_709_nem", "edge88_nem", "straddle709_nem"])
+def test_heavy_fuzzy_fixtures_sharded_over_families_and_organisms(gpu_lib, name):
+    """fuzzy NEM on two ranks (E-step over families, M-step's i-ordered chains over organisms): the reference's
+    memberships within 1e-6 where beta * sum(w) is between 88 and 709, its emptied class where a NaN row gets in"""
+    import tempfile
+    import torch.multiprocessing as mp
+    outdir = tempfile.mkdtemp(prefix="nemghf_")
+    mp.spawn(_fuzzy_worker, args=(2, os.path.join(outdir, "rdv"), name, outdir), nprocs=2, join=True)
+    exp = load_case(name)["expected"]
+    for r in range(2):
+        o = np.load(os.path.join(outdir, "rank%d.npz" % r))
+        assert int(o["status"]) == int(exp["status"]) and int(o["iters"]) == int(exp["iters"]), name
+        if int(exp["status"]) == 2:
+            assert int(o["emptyk"]) > 0
+            continue
+        assert maxdiff(o["c"], exp["c"]) <= TOL and np.array_equal(o["c"].argmax(1), exp["c"].argmax(1))
+        assert np.array_equal(o["center"], exp["center"]) and maxdiff(o["disp"], exp["disp"]) <= TOL and maxdiff(o["prop"], exp["prop"]) <= TOL
+
+
 def heavy_problem(seed):
     """tests/test_gpu_fuzz.py's random problem with a graph whose weights are (kind 0) integers U[1, 600] -- the
     coverage weights of a 600-organism chunk -- or (kinds 1, 2) chosen per site so that beta * sum(w) falls within +-2 of
