@@ -269,8 +269,13 @@ def pmc_traffic(kernel, n_loc, d):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
             for w in rec.get("workloads", []):
-                if w.get("families") == n_loc and w.get("organisms") == d and kernel in w.get("kernels", {}):
-                    return w["kernels"][kernel]["traffic_bytes_per_launch"]
+                if w.get("families") != n_loc or w.get("organisms") != d or w.get("problems_per_launch"):
+                    continue
+                # (template instances carry their arguments in the name: the instance with the most launches is the loop's)
+                hits = [(v.get("launches", 0), v["traffic_bytes_per_launch"]) for name, v in w.get("kernels", {}).items()
+                        if name == kernel or name.startswith(kernel + "<")]
+                if hits:
+                    return max(hits)[1]
         except (OSError, ValueError):
             pass
     return None
@@ -630,15 +635,18 @@ def sharded_run(args, ranks, n_tot, d, k, beta, seed, steps, warmup, repeats, wa
         job.run_steps(2 * m, m)
     job.run_steps(warmup, cycle)
     blocks = []
+    nb0, nh0 = job.n_batches, job.n_host_sweeps
     for _ in range(max(1, repeats)):
         ranks.sync(None)
         t0 = time.perf_counter()
         job.run_steps(steps, cycle)
         ranks.torch.cuda.synchronize()
         blocks.append(ranks.sync(time.perf_counter() - t0))
+    nb1, nh1 = job.n_batches, job.n_host_sweeps
     coll = job.time_collective(100)
     stride_bytes = int(job.stride)
     facts = dict(iters_to_converge=cycle, cycle_iterations=cycle, native_rccl=bool(job.native), rccl_ranks=job.eng.rccl_ranks(),
+                 batches_timed=nb1 - nb0, host_finished_sweeps_timed=nh1 - nh0, pipe_depth=job.PIPE_DEPTH,
                  backend=args.backend, batch_graphs=bool(job.use_graphs or job.library_graphs),
                  collective=dict(what="in-place all-gather of the ranks' label blocks (labels, flag bytes, int32 M-step statistics)",
                                  bytes_per_rank=stride_bytes, per_allgather_ms=coll * 1e3, per_iteration=2,

@@ -301,7 +301,8 @@ class GpuStepper:
 class ShardedNem:
     """EM driver over a stepper + Comm (mirrors NemAlgo, nem_alg.c:1746-1879, for NCEM)."""
 
-    PIPE_DEPTH = 6       # whole iterations enqueued between host synchronisations
+    PIPE_DEPTH = 7       # whole iterations enqueued between host synchronisations (the single engine's kPipeDepth: a run of
+                         # PPanGGOLiN's, 5-7 iterations, is ONE batch; NEM_DIST_PIPE_DEPTH overrides)
 
     def __init__(self, stepper, comm, n_total, beta, cvtest="clas", cvthres=1e-8, param_fix=False):
         if cvtest not in ("none", "clas"):
@@ -333,6 +334,8 @@ class ShardedNem:
                 and os.environ.get("NEM_DIST_NATIVE", "1") != "0"):
             self.native = bool(stepper.enable_native(comm))
         self._graphs, self._seen = {}, set()
+        self.PIPE_DEPTH = max(1, int(os.environ.get("NEM_DIST_PIPE_DEPTH", self.PIPE_DEPTH)))
+        self.n_batches, self.n_host_sweeps = 0, 0             # (what a timed region cost besides its launches)
         self.library_graphs = bool(self.native and comm.world == 1)
         self.first_sweep_is_long, self._last_need_rounds = False, False
         self.reset()
@@ -479,6 +482,7 @@ class ShardedNem:
             else:
                 self._graphs[key] = graph
         self._seen.add(key)
+        self.n_batches += 1
         with self.st.on_stream():
             if graph is not None:
                 graph.replay()
@@ -490,6 +494,7 @@ class ShardedNem:
         if with_init and res["need_rounds"] == 2:
             # the initial beta sweep was not at its fixed point after two rounds: finish it from the host;
             # the iterations enqueued behind it all returned at the stop word
+            self.n_host_sweeps += 1
             self._finish_sweep_on_host(1, 1)
             self.cur, self.sweep_id = 2, 2
             self.st.set_sweep_number(2)
@@ -504,6 +509,7 @@ class ShardedNem:
             self.converged = True
         elif res["need_rounds"] == 1:
             P = self.cur
+            self.n_host_sweeps += 1
             new = self._finish_sweep_on_host(P, s0 + res["iters"] - 1)
             self.cur = new
             self._publish_stats(new)

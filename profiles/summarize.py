@@ -60,7 +60,7 @@ def full_launch_us(trace_csv, kernel):
 
 def main():
     averages = []
-    for cfg in ("c2", "c3", "c4", "c2_fuzzy", "b16", "dist1"):
+    for cfg in ("c2", "c3", "c4", "c2_fuzzy", "b16", "dist1", "c2_adjacency"):
         f = newest("%s_%s/*/*_kernel_stats.csv" % (R, cfg))
         if f:
             shutil.copy(f, os.path.join(HERE, "%s_%s_kernel_stats.csv" % (R, cfg)))
@@ -109,11 +109,19 @@ def main():
                 w.writerow([k, fr[0], "%.2f" % fr[1], "%.2f" % wr[1], "%.0f" % traffic])
                 rec[k] = dict(fetch_kb_raw=fr[1], write_kb=wr[1], traffic_bytes_per_launch=traffic, launches=fr[0])
         entry = {"families": n, "organisms": d, "command": cmd, "fetch_scale": scale,
-                 "kernels": {k: rec[k] for k in rec if k.startswith("k_density")}}
+                 "kernels": {k: rec[k] for k in rec if k.startswith("k_density")}, "all_kernels": rec}
         if cfg == "b16":
             entry["problems_per_launch"] = 16
         workloads.append(entry)
     if workloads:
+        # (round 4: every kernel of the run, not the density kernels only -- bench.py's roofline.kernels[].traffic for the
+        #  sweep rounds and the counts comes from here)
+        every = [dict({k: v for k, v in w.items() if k not in ("kernels", "all_kernels")}, kernels=w["all_kernels"]) for w in workloads]
+        json.dump({"what": "HBM-side bytes per launch, every kernel of the profiled run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                           "separate passes, FETCH_SIZE scaled by the calibration factor (MI355X_MICROARCH.md, HBM / rocprofv3 section)",
+                   "workloads": every}, open(os.path.join(HERE, "%s_pmc_kernels.json" % R), "w"), indent=1)
+        for w in workloads:
+            w.pop("all_kernels", None)
         json.dump({"workloads": [w for w in workloads if "problems_per_launch" not in w] +
                                 [w for w in workloads if "problems_per_launch" in w]},
                   open(os.path.join(HERE, "%s_pmc_density.json" % R), "w"), indent=1)
@@ -148,6 +156,7 @@ def main():
                  "bench_20000x500_skd.json", "bench_dist_world1.json", "bench_2ranks_gloo_one_gpu.json", "dist_world1.json",
                  "dist_world1_20000x500.json", "dist_2ranks_gloo_strong.json", "dist_2ranks_gloo_replicas.json", "dist_2ranks_gloo_weak.json",
                  "pcie_inclusive.json", "batch_chunks.json", "batch_chunks_256.json", "batch_lockstep.json", "random_starts.json",
+                 "bench_20000x500_adjacency.json", "bench_20000x500_coverage.json", "chunks_device.json", "sweep_phases.json", "gpu_suite.txt",
                  "dropin_whole_call.json", "dropin_logged.json", "fuzzy_mstep.txt", "fuzzy_mstep_lane_per_chain.txt", "fuzzy_mstep_wave_per_chain.txt"):
         b = os.path.join(OUT, "%s_%s" % (R, name))
         if os.path.isfile(b) and os.path.getsize(b) > 0:
