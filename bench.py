@@ -230,6 +230,31 @@ class EngineRun:
         return blocks, info
 
 
+def host_facts():
+    """what the CPU figure was taken on (it moved from box to box with nothing to explain it): model, cores
+    visible to this process, frequency governor and current clock of core 0, load average"""
+    out = {"cores_visible": os.cpu_count()}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                out["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    for key, path in (("governor", "/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor"),
+                      ("cpu0_khz", "/sys/devices/system/cpu/cpu0/cpufreq/scaling_cur_freq")):
+        try:
+            out[key] = open(path).read().strip()
+        except OSError:
+            out[key] = None
+    try:
+        out["affinity_cores"] = len(os.sched_getaffinity(0))
+        out["loadavg_1min"] = os.getloadavg()[0]
+    except (AttributeError, OSError):
+        pass
+    return out
+
+
 def cpu_baseline(x, nei, k, prop, center, disp, beta, algo, disper, iters):
     """Time the CPU checker on THIS host, 1 core: the compiled reference (oracle/_ref) when it is there, else the
     plain-C port (oracle/nem_oracle.c).  Bounded sample: the same workload, `iters` iterations with the convergence
@@ -254,7 +279,7 @@ def cpu_baseline(x, nei, k, prop, center, disp, beta, algo, disper, iters):
                sample="%d EM iterations of the same %dx%d workload, convergence test off, loop time only "
                       "(%.3f s/iteration = the difference of a %d-iteration and a 0-iteration call of the reference's "
                       "ClassifyByNem, divided by %d); host has %d cores" % (iters, n, d, per_it, iters, iters, os.cpu_count() or 0),
-               em_iterations_per_sec=1.0 / per_it, seconds_per_iteration=per_it)
+               em_iterations_per_sec=1.0 / per_it, seconds_per_iteration=per_it, host=host_facts())
     out.update(extra)
     return out
 
