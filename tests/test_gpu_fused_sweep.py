@@ -145,10 +145,11 @@ def test_engines_side_by_side_keep_meeting(gpu_lib, oracle):
         eng.close()
 
     threads = [threading.Thread(target=work, args=(i,)) for i in range(len(probs))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    with env(NEM_MI355X_FUSED_SWEEP="1"):                    # (off by default since the A/B of round 4; read at engine creation)
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     for a, b, c in zip(alone, got, cnt):
         assert c["fused_launches"] > 0 and c["fused_failed"] == 0
         assert a["iters"] == b["iters"] and np.array_equal(a["c"], b["c"]) and np.array_equal(a["crit"], b["crit"], equal_nan=True)
