@@ -783,7 +783,10 @@ int sweep_first_rounds(const nemgpu_engine* e, float beta, int wanted, int pipel
 // SweepArgs::exp_tab for the configured beta (outside any capture / recording: loop_begin, init_partition)
 int ensure_exp_table(nemgpu_engine* e)
 {
-    if (current_recorder() != nullptr || !e->ncem() || !e->has_graph || e->cfg.beta == 0.0f) return NEMGPU_OK;
+    if (current_recorder() != nullptr || !e->ncem() || !e->has_graph || e->cfg.beta == 0.0f || e->parent != nullptr) return NEMGPU_OK;
+    if (e->exp_need <= 64) return NEMGPU_OK;              // (small weights: every block computes its 64 entries itself)
+    static const bool off = getenv("NEM_MI355X_EXP_TABLE") && getenv("NEM_MI355X_EXP_TABLE")[0] == '0';   // (A/B: every exp evaluated)
+    if (off) return NEMGPU_OK;
     if (e->exp_ready && e->exp_beta == e->cfg.beta) return NEMGPU_OK;
     if (e->exp_tab == nullptr) { alloc_for(e); int r = dev_alloc(&e->exp_tab, (size_t)kExpTabGlobal); if (r) return r; }
     launch_exp_table(e->cfg.beta, e->exp_tab, kExpTabGlobal, e->stream);
@@ -866,6 +869,10 @@ int sweep_setup(nemgpu_engine* e, float beta, SweepCtx& c, bool id_by_value)
         if (e->stop_ptr == nullptr) { int r = ensure_draw_window(e, e->draws, draw_need(e)); if (r) return r; }
         sweep_draw_args(e, a, e->stop_ptr == nullptr);
     }
+    // exp(beta * context) from the per-beta table where the graph's weights reach beyond the 64 entries a block computes
+    // itself (sweep_body); the table was made by ensure_exp_table, ahead of any capture or recording
+    a.exp_tab = (c.use_nei && e->ncem() && e->exp_ready && e->exp_beta == beta) ? e->exp_tab : nullptr;
+    a.exp_tab_len = e->exp_need;
     return NEMGPU_OK;
 }
 
@@ -1069,6 +1076,8 @@ int host_rounds_ctx(nemgpu_engine* e, SweepCtx& sc, uint32_t sweep_id, int launc
     a.n_local = e->n; a.lo = e->lo; a.n_total = e->n_total; a.K = e->k; a.npad = e->npad; a.use_nei = sc.use_nei ? 1 : 0;
     a.nei_ptr = e->nei_ptr; a.nei_idx = e->nei_idx; a.nei_w = e->nei_w; a.beta = e->cfg.beta; a.pkfki = e->pkfki;
     a.tie_rule = e->cfg.tie_rule; a.tie_seed = e->cfg.tie_seed; a.sweep_id = sweep_id; a.sweep_id_ptr = nullptr;
+    a.exp_tab = (sc.use_nei && e->ncem() && e->exp_ready && e->exp_beta == a.beta) ? e->exp_tab : nullptr;
+    a.exp_tab_len = e->exp_need;
     sc.r = launched; sc.checked = launched;               // (the enqueued rounds all changed something)
     if (e->libc()) {
         for (int q = 0; q < launched; q++) if (e->h_round(q)[FLAG_NTIES] & (1 << 30)) e->tie_heavy = true;
@@ -2513,6 +2522,7 @@ int nemgpu_configure(nemgpu_engine* e, const nemgpu_config* cfg)
     e->cfg = *cfg;
     HIPCHK(hipSetDevice(e->device));
     drop_graphs(e);                                                // kernel arguments are baked into captured batches
+    { const int xr = ensure_exp_table(e); if (xr) return xr; }     // (the graph is normally set by now; loop_begin looks again)
     return reset_state(e, true);
 }
 
@@ -3723,6 +3733,8 @@ void shard_sweep_args(nemgpu_engine* e, SweepArgs& a, float beta, int sweep_id)
     a.stop = e->stop_ptr;
     a.n_ranks = e->sh_world; a.slot_stride = e->sh_stride; a.slot_pad = e->sh_stride - e->sh_blk;
     a.fold_ticket = e->sweep_next + 32;
+    a.exp_tab = (a.use_nei && e->ncem() && e->exp_ready && e->exp_beta == beta) ? e->exp_tab : nullptr;
+    a.exp_tab_len = e->exp_need;
     if (e->libc()) { sweep_draw_args(e, a, e->stop_ptr == nullptr); a.rank_index = e->sh_rank; }
 }
 uint8_t* own_flag_byte(nemgpu_engine* e, uint8_t* labels) { return labels + (size_t)e->sh_rank * e->sh_stride + e->sh_blk; }

@@ -367,9 +367,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     // exp((double)beta * (double)(float)m), m = 0 .. kExpTab - 1, with the SAME device exp on the same argument the site
     // would pass (bit-identical by construction), one entry per thread, and a site whose context is such an integer
     // reads it instead of running three double-precision exp (a third of the round's vector instructions)
-    // (fused launch: the table comes from SweepArgs::exp_tab -- made once per beta by the same exp -- and is as long as the
-    //  contexts of PPanGGOLiN's own edge weights need, counts of organisms up to D: 4096 entries, copied to LDS once per sweep)
-    constexpr int kExpTab = FUSED ? kExpTabGlobal : 64;
+    // Graphs with PPanGGOLiN's own edge weights -- counts of organisms, up to D -- have contexts in the hundreds: there the
+    // table comes from SweepArgs::exp_tab (made once per beta by the same exp on the same arguments, k_exp_table) and is
+    // copied to LDS, as many entries as the graph's largest weight sum can index: up to 1024 in a round of its own, 4096
+    // in a fused launch.  (64 entries or fewer: the block computes them itself, no dependent load at its head.)
+    constexpr int kExpTab = FUSED ? kExpTabGlobal : 1024;
     __shared__ double s_exp[NCEM ? kExpTab : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_lab[NCEM ? BS : 1];   // the block's labels while it iterates
     __shared__ uint64_t s_drew[BS / 64];                 // TIE_LIBC: per wave, which of its sites drew
@@ -388,9 +390,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; s_chg = 0; s_mov = 0; }
     if (NCEM) s_lab[threadIdx.x] = (uint8_t)my_guess;
     int exp_len = 64;                                    // usable entries of s_exp
-    if (FUSED && a.exp_tab != nullptr) {
+    if (NCEM && a.exp_tab != nullptr && (FUSED || a.exp_tab_len > 64)) {
         exp_len = a.exp_tab_len < kExpTab ? a.exp_tab_len : kExpTab;
-        if (NCEM && a.use_nei) for (int m = threadIdx.x; m < exp_len; m += BS) s_exp[m] = a.exp_tab[m];
+        if (a.use_nei && !skip) for (int m = threadIdx.x; m < exp_len; m += BS) s_exp[m] = a.exp_tab[m];
     } else if (NCEM && a.use_nei && !skip && threadIdx.x < 64) s_exp[threadIdx.x] = exp((double)a.beta * (double)(float)threadIdx.x);
     int* rflags = a.flags;                               // this round's flag slot (a fused launch moves on slot by slot)
     __syncthreads();
