@@ -785,8 +785,11 @@ int ensure_exp_table(nemgpu_engine* e)
 {
     if (current_recorder() != nullptr || !e->ncem() || !e->has_graph || e->cfg.beta == 0.0f || e->parent != nullptr) return NEMGPU_OK;
     if (e->exp_need <= 64) return NEMGPU_OK;              // (small weights: every block computes its 64 entries itself)
-    static const bool off = getenv("NEM_MI355X_EXP_TABLE") && getenv("NEM_MI355X_EXP_TABLE")[0] == '0';   // (A/B: every exp evaluated)
-    if (off) return NEMGPU_OK;
+    // (measured neutral, round 4 -- profiles/r04_exp_table_ab.json: adjacency weights, one engine 0.03450 vs 0.03469 ms per
+    //  iteration, 64 problems in lock step 5.02 vs 4.98 us per problem-iteration: the exponentials are not what bounds a
+    //  round, alone or in a batch -- so the table is opt-in, NEM_MI355X_EXP_TABLE=1; the fused sweep uses it when both are on)
+    static const bool on = getenv("NEM_MI355X_EXP_TABLE") && getenv("NEM_MI355X_EXP_TABLE")[0] == '1';
+    if (!on) return NEMGPU_OK;
     if (e->exp_ready && e->exp_beta == e->cfg.beta) return NEMGPU_OK;
     if (e->exp_tab == nullptr) { alloc_for(e); int r = dev_alloc(&e->exp_tab, (size_t)kExpTabGlobal); if (r) return r; }
     launch_exp_table(e->cfg.beta, e->exp_tab, kExpTabGlobal, e->stream);
