@@ -482,6 +482,10 @@ int nemgpu_graph_counters(const nemgpu_engine* e, int out[4]);
    except at 200 000 x 5 000, DESIGN.md -- NEM_MI355X_FUSED_ROUNDS sets the rounds per launch).  out[0] such launches issued or captured so far, out[1] launches whose blocks failed to meet (the sweep was
    redone with one launch per round and the engine keeps to that form), out[2] 1 while the form is in use, out[3] 0. */
 int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4]);
+/* how the last nemgpu_run_random went (RandNemAlgo, nem_alg.c:1574-1742, starts in lock step): out = {lock-step rounds,
+   starts that stood in them, starts run alone on the engine's own path, starts thrown away and redone because a start
+   before them drew tie-breaks behind its initial sweeps (TIE_LIBC: one random() stream for all starts)} */
+int nemgpu_random_start_counters(const nemgpu_engine* e, int out[4]);
 /* development probe (NEM_MI355X_SWEEP_PROF=1): the device's 100 MHz clock at the phase boundaries of the last fused
    launch, first block in out[0..31], last block in out[32..63] (0: phase not reached) */
 int nemgpu_sweep_phases(unsigned long long out64[64]);

@@ -14,6 +14,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -30,6 +31,15 @@ static double now_s(void)
 }
 
 double orc_last_loop_seconds(void) { return g_loop_seconds; }
+/* tie draws made by the sweeps since the library was loaded (a diagnostic: ORC_DRAW_LOG=1 prints it per sweep) */
+static long g_draws = 0;
+long orc_tie_draws(void) { return g_draws; }
+static void draw_log(const char* what, int iter)
+{
+    static int on = -1;
+    if (on < 0) on = getenv("ORC_DRAW_LOG") != NULL;
+    if (on) fprintf(stderr, "orc draws %s %d %ld\n", what, iter, g_draws);
+}
 
 /* The HIP engine's counter-based stand-in for the reference's time-seeded
    random() (nem_exe.c:353,621; nem_rnd.c:40-63).  Must stay identical to
@@ -107,7 +117,7 @@ static int orc_map(const float* row, int k, int tie_rule, unsigned seed, unsigne
     kmaxes[0] = kmax;
     for (kk = kmax + 1; kk < k; kk++) if (row[kk] == ukmax) kmaxes[++nequal] = kk;    /* :620-628 */
     if (nequal > 0) {
-        if (tie_rule == ORC_TIE_LIBC) return kmaxes[(int)(random() % (nequal + 1))]; /* nem_rnd.c:53-61 */
+        if (tie_rule == ORC_TIE_LIBC) { g_draws++; return kmaxes[(int)(random() % (nequal + 1))]; } /* nem_rnd.c:53-61 */
         return kmaxes[orc_mix32(seed, sweep, site) % (unsigned)(nequal + 1)];
     }
     return kmax;
@@ -461,6 +471,7 @@ static int run_from_params(const orc_problem* p, orc_state* s, int reseed)
                                    p->tie_rule, p->tie_seed, sweep++, s->c_nk);
     s->n_zero_density += orc_sweep(n, k, p->nei_ptr, p->nei_idx, p->nei_w, p->beta, s->pkfki_nk, ncem,
                                    p->tie_rule, p->tie_seed, sweep++, s->c_nk);
+    draw_log("init", 0);
 
     /* NemAlgo (nem_alg.c:1789-1840) */
     {
@@ -480,6 +491,7 @@ static int run_from_params(const orc_problem* p, orc_state* s, int reseed)
             orc_density(n, d, k, p->x, s->prop_k, s->center_kd, s->disp_kd, s->pkfki_nk, s->logpkfki_nk);
             s->n_zero_density += orc_sweep(n, k, p->nei_ptr, p->nei_idx, p->nei_w, p->beta, s->pkfki_nk,
                                            ncem, p->tie_rule, p->tie_seed, sweep++, s->c_nk);
+            draw_log("iter", iter);
             if (p->cvtest == ORC_CV_CLAS) converged = orc_converged(n, k, s->c_nk, cold, p->cvthres);
             else if (p->cvtest == ORC_CV_CRIT || p->cvtest == ORC_CV_CRIT_LOGGED) {     /* nem_alg.c:2090-2105 */
                 float curcrit, critdif;

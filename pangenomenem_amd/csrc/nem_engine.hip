@@ -133,6 +133,12 @@ struct nemgpu_engine {
     float crit_ref = 0.0f;               // CVTEST_CRIT: the criterion the next iteration's is compared with
     int draws = 0; bool tie_heavy = false;
     bool draw_borrowed = false;          // the table is the parent's (lock-step random starts): never written through this engine
+    int draws_after_init = 0;                  // TIE_LIBC: the stream's position behind a run's two initial sweeps
+    char* rs_par_host = nullptr; size_t rs_par_host_size = 0;   // random starts under TIE_LIBC: the starts' parameters, pinned
+    const int* draw_extra_once = nullptr;      // TIE_LIBC: the next sweep set up adds this device word to the draws before it (a sweep enqueued behind one whose count the host has not seen)
+    int libc_init_hist[2][17] = {};            // TIE_LIBC random starts: how many relaxation rounds the blind / the beta initial sweep of the starts so far needed (16: more)
+    int rs_two_waits = 0;                      // ... starts of phase A whose blind sweep was not through in the rounds enqueued (done again, sweep by sweep)
+    int rs_rounds = 0, rs_lockstep = 0, rs_alone = 0, rs_redone = 0;   // the last nemgpu_run_random: lock-step rounds, starts that stood in them, starts run alone, starts thrown away
     bool libc() const { return cfg.algo == NEMGPU_ALGO_NCEM && cfg.tie_rule == NEMGPU_TIE_LIBC; }
     float* cbuf[3] = {nullptr, nullptr, nullptr};    // fuzzy partitions, n_total*k each
     int cur = 0;
@@ -748,7 +754,7 @@ void sweep_draw_args(nemgpu_engine* e, SweepArgs& a, bool by_value)
     a.draw_tab = e->draw_tab; a.draw_tab_len = e->draw_cap;
     a.draw_base = e->draws; a.draw_tab0 = (int)e->draw_tab0;
     a.draw_ctl = by_value ? nullptr : e->draw_ctl;
-    a.draw_extra = nullptr;
+    a.draw_extra = e->draw_extra_once; e->draw_extra_once = nullptr;
 }
 // the device words the pipelined loop reads the stream position from (outside any graph capture)
 int publish_draw_ctl(nemgpu_engine* e)
@@ -911,7 +917,9 @@ int fused_fallback(nemgpu_engine* e, SweepCtx& c)
 
 // `extra` is set when rounds beyond the first batch were needed (work enqueued after the first
 // batch read a partition that was not final yet and must be redone by the caller).
-int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, bool flags_ready = false)
+// `grow`: every further batch of rounds is as long as all the rounds before it (up to 16) instead of round_batch -- for
+// sweeps whose need is long-tailed (the initial sweeps of a random start that ties at thousands of families).
+int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, bool flags_ready = false, bool grow = false)
 {
     int done_at = -1;
     if (extra) *extra = false;
@@ -947,14 +955,15 @@ int sweep_complete(nemgpu_engine* e, SweepCtx& c, int* rounds_out, bool* extra, 
             if (rr) return rr;
             sweep_draw_args(e, c.a, true);
         }
-        if (c.r % kRoundCap == 0 || c.r % kRoundCap + e->round_batch > kRoundCap) {
+        const int more = grow ? std::min(16, std::max(e->round_batch, c.r % kRoundCap)) : e->round_batch;
+        if (c.r % kRoundCap == 0 || c.r % kRoundCap + more > kRoundCap) {
             // the flag window is about to wrap: every earlier round has been examined, start a clean window
             // (keeps the parity of r, which selects the ping-pong buffers)
             HIPCHK(hipMemsetAsync(e->round_flags(0), 0, (kRoundCap * FLAG_ROUND_STRIDE + kMeetWords) * sizeof(int), e->stream));
             while (c.r % kRoundCap != 0) c.r += 2;       // skip to the window start, same parity
             c.checked = c.r;
         }
-        int rr = sweep_launch_rounds(e, c, e->round_batch);
+        int rr = sweep_launch_rounds(e, c, more);
         if (rr) return rr;
     }
     // the round that changed nothing recomputed every site: its zero-density tally is the sweep's
@@ -1203,7 +1212,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
 // ---- TIE_LIBC start: the two initial sweeps draw from ONE stream, the blind one first, so each is completed (its
 // rounds verified from the host, its draws booked) before the next is enqueued.  Three enqueue steps with a host step
 // after the first two; recordable like everything else.
-int libc_init_a(nemgpu_engine* e, SweepCtx& c)
+int libc_init_a(nemgpu_engine* e, SweepCtx& c, int rounds = 0)
 {
     int r;
     FinishArgs t = finish_args(e, 0, nullptr);                 // initial parameters back in place, loop control cleared, tables
@@ -1213,12 +1222,12 @@ int libc_init_a(nemgpu_engine* e, SweepCtx& c)
     e->tables_fresh = true; e->density_fresh = false;
     e->cur = 0; e->sweep_counter = 0;
     if ((r = do_density(e))) return r;
-    return sweep_enqueue(e, 0.0f, c);                          // blind sweep 0 -> 1
+    return sweep_enqueue(e, 0.0f, c, false, nullptr, false, 0, rounds);          // blind sweep 0 -> 1
 }
-int libc_init_b(nemgpu_engine* e, SweepCtx& c)
+int libc_init_b(nemgpu_engine* e, SweepCtx& c, int rounds = 0)
 {
     e->cur = 1;
-    return sweep_enqueue(e, e->cfg.beta, c);                   // 1 -> 2
+    return sweep_enqueue(e, e->cfg.beta, c, false, nullptr, false, 0, rounds);   // 1 -> 2
 }
 int libc_init_c(nemgpu_engine* e)
 {
@@ -1227,6 +1236,71 @@ int libc_init_c(nemgpu_engine* e)
     e->masks_valid = false;
     if ((r = do_labels_post(e, 2, -1))) return r;
     launch_fill(e->sweep_next, 1, (int)e->sweep_counter, e->stream);
+    return NEMGPU_OK;
+}
+
+// The same start with ONE wait: the beta sweep's rounds go out behind the blind sweep's, taking the blind sweep's draw
+// count from the flag slot of its last round on the device (rounds behind a sweep's fixed point carry the count along),
+// and the class masks behind them.  `ra` blind rounds on the last slots of the flag window, `rb` beta rounds from slot 0.
+// Then the host looks once: blind sweep at its fixed point within ra rounds?  (else what ran behind it is void:
+// *redo = true, nothing booked, the caller starts over with libc_init_a)  beta sweep within rb?  (else it is continued
+// from the host as any sweep is, and the masks are made again).  rounds[0..1]: what the two sweeps needed.
+int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[2])
+{
+    int r;
+    *redo = false;
+    ra = std::max(1, std::min(ra, kRoundCap / 4)); rb = std::max(1, std::min(rb, kRoundCap / 2));
+    FinishArgs t = finish_args(e, 0, nullptr);
+    t.reset_prop = e->prop0; t.reset_center = e->center0; t.reset_disp = e->disp0;
+    t.reset_ctrl = e->ctrl(); t.reset_ctrl_words = C_WORDS; t.reset_sweep_next = e->sweep_next;
+    launch_finish(t, e->stream);
+    e->tables_fresh = true; e->density_fresh = false;
+    e->cur = 0; e->sweep_counter = 0;
+    if ((r = do_density(e))) return r;                             // (also clears every sweep flag slot)
+    SweepCtx ca, cb;
+    const int base_a = kRoundCap - ra;
+    if ((r = sweep_enqueue(e, 0.0f, ca, false, nullptr, false, base_a, ra))) return r;          // blind sweep 0 -> 1
+    e->flags_clean = true;                                         // (the beta sweep's slots have not been touched)
+    e->cur = 1;
+    e->draw_extra_once = e->round_flags(kRoundCap - 1) + FLAG_NTIES;
+    if ((r = sweep_enqueue(e, e->cfg.beta, cb, false, nullptr, false, 0, rb))) return r;         // 1 -> 2
+    e->draw_extra_once = nullptr;
+    e->cur = 2;
+    e->masks_valid = false;
+    if ((r = do_labels_post(e, 2, -1))) return r;
+    launch_fill(e->sweep_next, 1, (int)e->sweep_counter, e->stream);
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if ((r = check_fault(e))) return r;
+    auto book = [&](const int* f, int done_at) {
+        e->draws += f[FLAG_NTIES] & ((1 << 30) - 1);
+        if (f[FLAG_NZERO] > 0) { e->zero_density += f[FLAG_NZERO]; if (e->first_zero < 0) e->first_zero = e->n_total - f[FLAG_FIRSTZERO]; }
+        e->sweep_rounds += done_at + 1;
+    };
+    int done_a = -1; bool tab_short = false;
+    for (int q = 0; q < ra && done_a < 0; q++) {
+        const int* f = e->h_round(base_a + q);
+        if (f[FLAG_NTIES] & (1 << 30)) tab_short = true;
+        if (f[FLAG_CHANGED] == 0) done_a = q;
+    }
+    if (done_a < 0 || tab_short) { *redo = true; e->cur = 0; e->sweep_counter = 0; e->masks_valid = false; e->flags_clean = false; return NEMGPU_OK; }
+    const int blind_draws = e->h_round(base_a + done_a)[FLAG_NTIES] & ((1 << 30) - 1);
+    book(e->h_round(base_a + done_a), done_a);
+    rounds[0] = done_a + 1;
+    int done_b = -1;
+    for (int q = 0; q < rb && done_b < 0; q++) {
+        const int* f = e->h_round(q);
+        if (f[FLAG_NTIES] & (1 << 30)) tab_short = true;
+        if (f[FLAG_CHANGED] == 0) done_b = q;
+    }
+    if (done_b >= 0 && !tab_short) { book(e->h_round(done_b), done_b); rounds[1] = done_b + 1; return NEMGPU_OK; }
+    // the beta sweep goes on from the host: its draws-before by value now (the blind sweep's are booked)
+    e->cur = 1;
+    cb.a.draw_base += blind_draws; cb.a.draw_extra = nullptr;
+    if ((r = sweep_complete(e, cb, &rounds[1], nullptr, true, true))) return r;
+    e->cur = 2;
+    e->masks_valid = false;
+    if ((r = do_labels_post(e, 2, -1))) return r;
     return NEMGPU_OK;
 }
 
@@ -1425,6 +1499,7 @@ int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
         if ((r = libc_init_c(e))) return r;
         HIPCHK(hipGetLastError());
         lc.first = false;
+        e->draws_after_init = e->draws;
     }
     while (loop_wants_batch(e, lc)) {
         if ((r = batch_plan(e, lc))) return r;
@@ -1721,7 +1796,7 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
         if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_b(E[m], ctx[m]); }, true))) return r;
         for (int m : members) if ((r = sweep_complete(E[m], ctx[m], nullptr, nullptr, true))) return r;
         if ((r = lockstep(E, members, recs, [&](int m) { return libc_init_c(E[m]); }, false))) return r;
-        for (int m : members) L[m].first = false;
+        for (int m : members) { L[m].first = false; E[m]->draws_after_init = E[m]->draws; }
     }
     for (;;) {
         members.clear();
@@ -2194,7 +2269,8 @@ void nemgpu_destroy(nemgpu_engine* e)
     std::vector<PoolBlock> blocks;
     blocks.push_back({false, e->clone_slab, e->clone_slab_size});
     blocks.push_back({true, (char*)e->clone_flags_host, e->clone_flags_size});
-    e->clone_slab = nullptr; e->clone_flags_host = nullptr;
+    blocks.push_back({true, e->rs_par_host, e->rs_par_host_size});
+    e->clone_slab = nullptr; e->clone_flags_host = nullptr; e->rs_par_host = nullptr; e->rs_par_host_size = 0;
     rccl_release(e);
     drop_graphs(e);
     if (g_alloc_engine == e) g_alloc_engine = nullptr;
@@ -3447,9 +3523,17 @@ static int ensure_clones(nemgpu_engine* e, int count)
 }
 
 // RandNemAlgo (nem_alg.c:1574-1742) with the starts in lock step.  TIE_LIBC: the starts' centre draws and the sweeps'
-// tie draws are one stream, so where start s begins depends on the ties of the starts before it.  The starts of a round
-// are drawn as if none of them tied; the first that did tie is still right (its own draws came from where they should)
-// and everything behind it is redone from the position it left the stream at.
+// tie draws are one stream, so where start s begins depends on the ties of the starts before it.  Where the ties ARE
+// is what makes lock step possible: a random start gives every class the same dispersion (the whole sample's over K,
+// nem_alg.c:1400) and the same proportion, so in the two initial sweeps every family that is as far from two centres
+// ties exactly -- hundreds to thousands of draws per start -- while from the first M-step on the classes' parameters
+// differ and a tie is an accident (profiles/r04_random_starts_draws.json: 100 starts, 0 draws behind the initial sweeps).
+// So a round runs in two phases.  A: start by start, in stream order -- centres drawn, parameters up, density, the blind
+// sweep and the beta sweep completed from the host (what the sequential form does for them), which leaves the stream
+// where the next start's centres are drawn.  B: the EM iterations of all the round's starts in lock step, each from its
+// own initial partition, on the assumption that none of them draws.  The assumption is checked: the first start whose
+// iterations did draw is still right (its draws came from where they should) and everything behind it is redone from
+// the position it left the stream at.
 static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
 {
     int r;
@@ -3487,18 +3571,19 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     if (e->ncem()) { if (!e->best_lab && (r = dev_alloc(&e->best_lab, (size_t)e->n_total))) return r; }
     else { if (!e->best_c && (r = dev_alloc(&e->best_c, (size_t)e->n_total * k))) return r; }
     const int group = std::min(n_starts, 64);
-    // Starts per round.  TIE_LIBC: the starts' centre draws and the sweeps' tie draws are ONE stream, so a round's starts
-    // are drawn as if none of them tied and everything behind the first that did is thrown away.  Whether the data tie
-    // at all is not known ahead: start 0 runs ALONE, on this engine's own pipelined path (what the sequential form
-    // does); the width of a round follows the starts seen so far -- four times the run of tie-free starts behind it
-    // (1, 4, 20, the rest on tie-free data), one start alone after a start that tied or a round that was voided, and
-    // after two voided rounds in a row every remaining start alone: data whose every start ties cost what the
-    // sequential form costs, data that tie now and then waste a few lock-step starts, never whole rounds of fifty.
-    int width = e->libc() ? 1 : group;
+    // Starts per round.  TIE_LIBC: phase B bets that no start draws behind its initial sweeps.  Whether these data keep
+    // the bet is not known ahead: start 0 runs ALONE, on this engine's own pipelined path (what the sequential form
+    // does), and tells; if its iterations drew nothing the rest go as wide as the group allows.  After a start whose
+    // iterations drew (alone, or one that voided the round behind it) the next runs alone, the width grows with the run
+    // of clean starts behind it (4, 20, the rest), and after two voided rounds in a row every remaining start runs alone:
+    // data whose every start draws in its iterations cost what the sequential form costs.
+    const char* fa = getenv("NEM_MI355X_STARTS_FIRST_ALONE");      // (0: bet from the first start on -- tests of the losing path)
+    int width = (e->libc() && !(fa && fa[0] == '0')) ? 1 : group;
     int voided_in_a_row = 0, clean_run = 0; bool alone_for_good = false;
     if ((r = ensure_clones(e, group))) return r;
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
 
+    e->rs_rounds = e->rs_lockstep = e->rs_alone = e->rs_redone = e->rs_two_waits = 0;
     int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
     float best_crit[6] = {0, 0, 0, 0, 0, 0};
     nemgpu_result best_res{};
@@ -3506,22 +3591,23 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     std::vector<int> start_pos;
     std::vector<GlibcRandom> rng_after;                           // (hash / first tie rules: the generator after each start's draws)
     int next = 0;
+    static const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
     while (next < n_starts) {
         const int M = std::min(width, n_starts - next);
         std::vector<nemgpu_engine*> E(e->clones.begin(), e->clones.begin() + M);
         host_par.assign((size_t)M * par, 0.0f);
         start_pos.assign((size_t)M, 0);
-        const int pos_first = e->draws;
-        for (int j = 0; j < M; j++) {
+        // MakeRandomPara, nem_alg.c:1381-1473, for start j of the round (TIE_LIBC: from where the stream stands)
+        auto make_random_para = [&](int j) -> int {
             float* prop = host_par.data() + (size_t)j * par; float* center = prop + k; float* disp = center + kd;
-            // MakeRandomPara, nem_alg.c:1381-1473
             for (int h = 0; h < k; h++) for (int t = 0; t < d; t++) disp[(size_t)h * d + t] = dispsam[t] / k;     // :1400
             for (int h = 0; h < k; h++) prop[h] = (float)(1.0 / k);                                              // :1405
             for (int h = 0; h < k; h++) {
                 int ipt = 0;
                 bool again = true;
                 for (int ndraw = 0; again && ndraw < 100; ndraw++) {                                             // :1419
-                    if ((r = draw_integer(0, n - 1, &ipt))) return r;
+                    int rr = draw_integer(0, n - 1, &ipt);
+                    if (rr) return rr;
                     again = false;
                     for (int g = 0; g < h && !again; g++) {
                         bool different = false;
@@ -3532,18 +3618,21 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 for (int t = 0; t < d; t++) center[(size_t)h * d + t] = bit(ipt, t);                             // :1457
             }
             start_pos[j] = e->draws;                                 // where this start's sweeps begin to draw
-        }
+            return NEMGPU_OK;
+        };
         if (e->libc() && M == 1) {
             // ---- one start alone: this engine's own run (nemgpu_run_random's sequential body)
+            if ((r = make_random_para(0))) return r;
             const float* prop = host_par.data(); const float* center = prop + k; const float* disp = center + kd;
             HIPCHK(copy_sync(e, e->prop0, prop, sizeof(float) * k, hipMemcpyHostToDevice));
             HIPCHK(copy_sync(e, e->center0, center, sizeof(float) * kd, hipMemcpyHostToDevice));
             HIPCHK(copy_sync(e, e->disp0, disp, sizeof(float) * kd, hipMemcpyHostToDevice));
+            e->draws_after_init = e->draws;
             if ((r = iterate(e, e->cfg.it_max, true))) return r;
             if (e->iters == 0) { if ((r = do_mstep(e)) || (r = do_tables(e)) || (r = do_density(e))) return r; }
             float crit[6];
             if ((r = criteria(e, crit))) return r;
-            const bool tied = e->draws != start_pos[0];
+            const bool drew_late = e->draws != e->draws_after_init;  // (its iterations drew: phase B's bet would have been lost)
             last_status = e->status;
             if (e->status == NEMGPU_OK) {
                 nbsucc++;
@@ -3554,23 +3643,101 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                     fill_result(e, &best_res);
                 }
             }
-            next += 1;
-            clean_run = tied ? 0 : clean_run + 1;
-            width = (alone_for_good || clean_run == 0) ? 1 : std::min(group, 4 * clean_run);
+            next += 1; e->rs_alone++;
+            clean_run = drew_late ? 0 : clean_run + 1;
+            width = (alone_for_good || clean_run == 0) ? 1 : (voided_in_a_row == 0 ? group : std::min(group, 4 * clean_run));
             continue;
         }
-        HIPCHK(copy_sync(e, e->clone_par0, host_par.data(), host_par.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<LoopCursor> L((size_t)M);
+        std::vector<int> after_init((size_t)M, 0);
         if (e->libc()) {
-            if ((r = ensure_draw_window(e, pos_first, (long)(e->draws - pos_first) + draw_need(e)))) return r;
-            for (int j = 0; j < M; j++) {
-                nemgpu_engine* c = E[j];
+            // ---- phase A: the starts' initial partitions, one after the other in stream order
+            using clk = std::chrono::steady_clock;
+            const auto ta = clk::now();
+            double seg[5] = {0, 0, 0, 0, 0};
+            auto lap = [&](int which, clk::time_point& t) { if (prof) { const auto now = clk::now(); seg[which] += std::chrono::duration<double, std::micro>(now - t).count(); t = now; } };
+            auto lend_window = [&](nemgpu_engine* c) {
                 c->draw_tab = e->draw_tab; c->draw_cap = e->draw_cap; c->draw_tab0 = e->draw_tab0; c->draw_valid = true;
                 c->draw_borrowed = true;                           // (a twin that outgrows the shared window builds its own)
-                c->draws = start_pos[j]; c->tie_heavy = e->tie_heavy;
+            };
+            // the starts' parameters go up from a pinned block, one slot per start: no wait for a copy
+            const size_t par_bytes = par * sizeof(float);
+            if (e->rs_par_host_size < (size_t)M * par_bytes) {
+                HIPCHK(hipStreamSynchronize(e->stream));
+                pool_put(e->device, true, e->rs_par_host, e->rs_par_host_size); e->rs_par_host = nullptr; e->rs_par_host_size = 0;
+                HIPCHK(pool_get(e->device, true, (size_t)group * par_bytes, &e->rs_par_host, &e->rs_par_host_size));
             }
+            static const bool one_wait = !(getenv("NEM_MI355X_STARTS_ONE_WAIT") && getenv("NEM_MI355X_STARTS_ONE_WAIT")[0] == '0');
+            for (int j = 0; j < M; j++) {
+                nemgpu_engine* c = E[j];
+                auto t = clk::now();
+                if ((r = make_random_para(j))) return r;
+                memcpy(e->rs_par_host + (size_t)j * par_bytes, host_par.data() + (size_t)j * par, par_bytes);
+                HIPCHK(hipMemcpyAsync(c->prop0, e->rs_par_host + (size_t)j * par_bytes, par_bytes, hipMemcpyHostToDevice, e->stream));
+                if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+                lend_window(c);
+                c->draws = e->draws; c->tie_heavy = e->tie_heavy;
+                if ((r = loop_begin(c, L[j], e->cfg.it_max, true))) return r;
+                lap(0, t);
+                // The rounds a sweep needs are long-tailed: a start that ties at a few families is through in three or
+                // four, one whose centres tie at thousands needs dozens (a draw's number depends on every tie before
+                // it).  What goes out at once: for the blind sweep the most any start so far needed (two to five), for
+                // the beta sweep what 70 % of them got by with; a sweep that needs more gets batches that double.
+                auto usual = [&](int which, int percent) {
+                    const int* h = e->libc_init_hist[which];
+                    int total = 0; for (int q = 0; q <= 16; q++) total += h[q];
+                    int acc = 0, q = 0;
+                    for (; q < 16; q++) { acc += h[q]; if (total > 0 && 100 * acc >= percent * total) break; }
+                    return std::max(e->round_batch, total > 0 ? q : 3);
+                };
+                int rounds[2] = {0, 0};
+                bool redo = false;
+                if (one_wait) {
+                    if ((r = libc_init_one_wait(c, std::min(8, usual(0, 100)), usual(1, 70), &redo, rounds))) return r;
+                    lap(1, t);
+                    if (redo) e->rs_two_waits++;
+                }
+                if (!one_wait || redo) {
+                    SweepCtx sc;
+                    if ((r = libc_init_a(c, sc, std::min(8, usual(0, 100))))) return r;
+                    lap(1, t);
+                    if ((r = sweep_complete(c, sc, &rounds[0], nullptr, false, true))) return r;
+                    lap(2, t);
+                    if ((r = libc_init_b(c, sc, usual(1, 70)))) return r;
+                    lap(3, t);
+                    if ((r = sweep_complete(c, sc, &rounds[1], nullptr, false, true))) return r;
+                    if ((r = libc_init_c(c))) return r;
+                }
+                e->libc_init_hist[0][std::min(16, rounds[0])]++;
+                e->libc_init_hist[1][std::min(16, rounds[1])]++;
+                if (prof && rounds[1] >= 16) fprintf(stderr, "[random starts]   start %d: beta sweep %d rounds, %d draws in its initial sweeps\n", next + j, rounds[1], c->draws - start_pos[j]);
+                HIPCHK(hipGetLastError());
+                lap(4, t);
+                L[j].first = false;
+                c->draws_after_init = after_init[j] = c->draws;
+                e->draws = c->draws; e->tie_heavy = e->tie_heavy || c->tie_heavy;
+            }
+            // (the parent's window may have slid or grown since a twin borrowed it: every twin gets it as it is now; one
+            //  whose position it does not cover builds its own when it first needs a draw)
+            if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+            for (int j = 0; j < M; j++) { lend_window(E[j]); E[j]->tie_heavy = e->tie_heavy; }
+            if (prof) {
+                HIPCHK(hipStreamSynchronize(e->stream));
+                fprintf(stderr, "[random starts] phase A, %d starts: %.0f us (centres + upload %.0f, blind sweep out %.0f + wait %.0f, beta sweep out %.0f + wait and masks %.0f), "
+                                "%d of them sweep by sweep, stream at %d\n", M,
+                        std::chrono::duration<double, std::micro>(clk::now() - ta).count(), seg[0], seg[1], seg[2], seg[3], seg[4], e->rs_two_waits, e->draws);
+                for (int w = 0; w < 2; w++) {
+                    fprintf(stderr, "[random starts]   rounds needed by the %s sweeps so far:", w ? "beta" : "blind");
+                    for (int q = 1; q <= 16; q++) if (e->libc_init_hist[w][q]) fprintf(stderr, " %d%s x%d", q, q == 16 ? "+" : "", e->libc_init_hist[w][q]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        } else {
+            for (int j = 0; j < M; j++) if ((r = make_random_para(j))) return r;
+            HIPCHK(copy_sync(e, e->clone_par0, host_par.data(), host_par.size() * sizeof(float), hipMemcpyHostToDevice));
+            for (int j = 0; j < M; j++) if ((r = loop_begin(E[j], L[j], e->cfg.it_max, true))) return r;
         }
-        std::vector<LoopCursor> L((size_t)M);
-        for (int j = 0; j < M; j++) if ((r = loop_begin(E[j], L[j], e->cfg.it_max, true))) return r;
+        // ---- the EM iterations in lock step (TIE_LIBC: phase B)
         if ((r = iterate_many(E, L))) return r;
         for (int j = 0; j < M; j++)
             if (E[j]->iters == 0) { if ((r = do_mstep(E[j])) || (r = do_tables(E[j])) || (r = do_density(E[j]))) return r; }
@@ -3600,10 +3767,10 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 HIPCHK(hipMemcpyAsync(crits.data() + (size_t)j * 6, E[j]->crit6_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         }
         HIPCHK(hipStreamSynchronize(e->stream));
-        // the starts of this round that stand: all of them, or (TIE_LIBC) up to the first one whose sweeps drew
+        // the starts of this round that stand: all of them, or (TIE_LIBC) up to the first one whose iterations drew
         int valid = M;
         if (e->libc())
-            for (int j = 0; j < M; j++) if (E[j]->draws != start_pos[j]) { valid = j + 1; break; }
+            for (int j = 0; j < M; j++) if (E[j]->draws != after_init[j]) { valid = j + 1; break; }
         for (int j = 0; j < valid; j++) {
             nemgpu_engine* c = E[j];
             const float* crit = crits.data() + (size_t)j * 6;
@@ -3620,15 +3787,15 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
             }
         }
         if (e->libc()) {
-            if (valid < M || E[M - 1]->draws != start_pos[M - 1]) e->draws = E[valid - 1]->draws;   // the stream as start `valid - 1` left it
+            e->draws = E[valid - 1]->draws;                        // the stream as start `valid - 1` left it
             e->tie_heavy = e->tie_heavy || E[valid - 1]->tie_heavy;
         } else if (valid < M) {
             set_error("internal: lock-step starts out of order"); return NEMGPU_E_FUNCARG;
         }
-        next += valid;
+        next += valid; e->rs_rounds++; e->rs_lockstep += valid; e->rs_redone += M - valid;
         if (e->libc()) {
-            if (valid < M) { voided_in_a_row++; clean_run = 0; if (voided_in_a_row >= 2) alone_for_good = true; width = 1; }
-            else { voided_in_a_row = 0; clean_run += M; width = std::min(group, 4 * clean_run); }
+            if (valid < M || E[M - 1]->draws != after_init[M - 1]) { voided_in_a_row++; clean_run = 0; if (voided_in_a_row >= 2) alone_for_good = true; width = 1; }
+            else { voided_in_a_row = 0; clean_run += M; width = group; }
         }
     }
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -4782,6 +4949,13 @@ int nemgpu_sweep_counters(const nemgpu_engine* e, int out[4])
 {
     if (!e || !out) return NEMGPU_E_FUNCARG;
     out[0] = e->n_fused; out[1] = e->n_fused_failed; out[2] = e->fused_sweep ? 1 : 0; out[3] = 0;
+    return NEMGPU_OK;
+}
+
+int nemgpu_random_start_counters(const nemgpu_engine* e, int out[4])
+{
+    if (!e || !out) return NEMGPU_E_FUNCARG;
+    out[0] = e->rs_rounds; out[1] = e->rs_lockstep; out[2] = e->rs_alone; out[3] = e->rs_redone;
     return NEMGPU_OK;
 }
 

@@ -354,6 +354,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     }
     if (skip && !(NCEM && a.post_on)) {
         if (a.publish_byte != nullptr && bx == 0 && threadIdx.x == 0) *a.publish_byte = 0;
+        // TIE_LIBC: the sweep's draw count rides on through the rounds that have nothing left to do, so that whoever was
+        // enqueued behind the LAST of them finds it there (SweepArgs::draw_extra of the sweep that follows)
+        if (LIBC && a.prev_changed != nullptr && bx == 0 && threadIdx.x == 0) a.flags[FLAG_NTIES] = a.prev_changed[FLAG_NTIES - FLAG_CHANGED];
         return;
     }
     __shared__ int s_nzero, s_first;

@@ -103,6 +103,7 @@ def load_library():
     lib.nemgpu_graph_counters.argtypes = [vp, ip]
     lib.nemgpu_profile_density_many.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.nemgpu_sweep_counters.argtypes = [vp, ip]
+    lib.nemgpu_random_start_counters.argtypes = [vp, ip]
     lib.nemgpu_rccl_ranks.argtypes = [vp]
     lib.nemgpu_rccl_selftest.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.nemgpu_ff_table.argtypes = [C.c_double, C.c_double, vp, vp]
@@ -436,6 +437,11 @@ class NemEngine:
         out = (C.c_int * 4)()
         self._chk(self.lib.nemgpu_sweep_counters(self._h, out))
         return dict(fused_launches=out[0], fused_failed=out[1], fused_on=bool(out[2]))
+
+    def random_start_counters(self):
+        out = (C.c_int * 4)()
+        self._chk(self.lib.nemgpu_random_start_counters(self._h, out))
+        return dict(rounds=out[0], in_lockstep=out[1], alone=out[2], redone=out[3])
 
     def rccl_ranks(self):
         return int(self.lib.nemgpu_rccl_ranks(self._h))

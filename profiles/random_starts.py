@@ -30,6 +30,7 @@ for (n, d, tie, gen) in [(5000, 500, "hash", "ushape"), (20000, 500, "hash", "us
             row["fifty_lockstep_replayed_s"] = min(go(50) for _ in range(3))
         row["best_%s" % mode] = best.value
         row["tie_draws_%s" % mode] = int(r.tie_draws)
+        if mode == "1": row["how"] = eng.random_start_counters()   # lock-step rounds, starts in them, starts alone, starts redone
         eng.close()
     row["lockstep_over_one_start"] = row["fifty_lockstep_s"] / row["one_start_s"]
     row["speedup"] = row["fifty_sequential_s"] / row["fifty_lockstep_s"]

@@ -171,6 +171,41 @@ def test_random_starts_with_the_reference_tie_stream(gpu_lib, oracle, reference,
     eng.close()
 
 
+@pytest.mark.parametrize("d,seed,first_alone", [(1066, 3, "1"), (1068, 1, "1"), (1068, 2, "1"), (1069, 2, "1"), (1069, 2, "0"),
+                                               (1100, 1, "1"), (1100, 1, "0")])
+def test_random_starts_whose_iterations_draw(gpu_lib, oracle, monkeypatch, d, seed, first_alone):
+    """TIE_LIBC random starts in lock step bet that a start draws only in its two initial sweeps (all classes share the
+    whole sample's dispersion there; later their parameters differ).  Around d = 1068 half-and-half columns the densities
+    of SOME families underflow to an all-zero row in SOME starts' iterations -- a K-way tie, a draw: the bet is lost in
+    the middle of a round and the starts behind the one that drew are redone from where it left the stream (d = 1100:
+    every start draws at every family, every iteration).  Engine == oracle, start for start."""
+    from pangenomenem_amd.engine import NemEngine
+    monkeypatch.setenv("NEM_MI355X_STARTS_FIRST_ALONE", first_alone)
+    n, k, starts = 300, 3, 8
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed, p=(0.5, 0.5, 0.5))
+    nei = synth.contiguity_graph(n, seed)
+    eng = NemEngine(n, d, k)
+    eng.set_matrix(x)
+    eng.set_graph(nei)
+    eng.configure(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=12, tie="libc", seed=seed)
+    got = eng.run_random(n_starts=starts, rng_seed=seed)
+    how = eng.random_start_counters()
+    want = oracle.run_random(x, nei, k, n_starts=starts, rng_seed=seed, algo="ncem", disper="sk_", beta=0.5, it_max=12, tie="libc")
+    assert how["in_lockstep"] + how["alone"] == starts
+    if d < 1100 or first_alone == "0":
+        assert how["redone"] > 0, how                             # a round did lose the bet
+    else:
+        assert how["alone"] == starts and how["redone"] == 0, how  # start 0 told: nobody was run on the bet
+    assert got["status"] == want["status"] and got["best_start"] == want["best_start"]
+    assert got["iters"] == want["iters"]
+    assert np.array_equal(got["c"], want["c"])
+    assert np.array_equal(got["center"], want["center"])
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, key
+    assert_crit_close(got["crit"], want["crit"], 1e-6)
+    eng.close()
+
+
 def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
     # D > 32768: the class masks of the uniform chain no longer fit its LDS staging, every class takes the general
     # chain; K = 32 is the engine's maximum
