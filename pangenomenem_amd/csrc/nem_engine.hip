@@ -217,6 +217,7 @@ struct nemgpu_engine {
     bool fault_seen = false; int fault_inject = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // nemgpu_profile_density
+    hipEvent_t ev_flags = nullptr;             // libc_init_one_wait: the flag block has reached the host
     bool defer_layout = false, layout_pending = false;   // nemgpu_solve_many: the device layouts are made by the group's run (zipped)
     hipEvent_t ready_ev = nullptr;             // nemgpu_solve_many: recorded behind the engine's uploads on its builder's stream,
     bool ready_pending = false;                // which carries other engines' uploads too -- a run waits for the event, not the stream
@@ -1265,12 +1266,16 @@ int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[
     e->draw_extra_once = e->round_flags(kRoundCap - 1) + FLAG_NTIES;
     if ((r = sweep_enqueue(e, e->cfg.beta, cb, false, nullptr, false, 0, rb))) return r;         // 1 -> 2
     e->draw_extra_once = nullptr;
+    // the flags leave as soon as the rounds are through (an event marks the copy); the class masks and the sweep counter
+    // run while the host wakes up and draws the next start's centres
+    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (!e->ev_flags) HIPCHK(hipEventCreateWithFlags(&e->ev_flags, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_flags, e->stream));
     e->cur = 2;
     e->masks_valid = false;
     if ((r = do_labels_post(e, 2, -1))) return r;
     launch_fill(e->sweep_next, 1, (int)e->sweep_counter, e->stream);
-    HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipEventSynchronize(e->ev_flags));
     if ((r = check_fault(e))) return r;
     auto book = [&](const int* f, int done_at) {
         e->draws += f[FLAG_NTIES] & ((1 << 30) - 1);
@@ -2285,6 +2290,7 @@ void nemgpu_destroy(nemgpu_engine* e)
     zip_context_release(e);
     if (e->own_stream && e->stream) pool_stream_put(e->device, e->stream);
     lap(2);
+    if (e->ev_flags) (void)hipEventDestroy(e->ev_flags);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ready_ev) (void)hipEventDestroy(e->ready_ev);

@@ -14,6 +14,7 @@ import pytest
 
 from tests.golden_util import load_case
 from tests.util import assert_crit_close, maxdiff
+from pangenomenem_amd import synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -188,3 +189,33 @@ def test_heavy_weight_problem(gpu_lib, oracle, seed):
     assert np.array_equal(np.nan_to_num(got["center"], nan=-7), np.nan_to_num(want["center"], nan=-7)), ctx
     assert got["n_zero_density"] == want["n_zero_density"], ctx
     assert_crit_close(got["crit"], want["crit"], 1e-5, ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,beta,seed", [(300, 600, 1.0, 4), (300, 600, 0.5, 4), (400, 200, 1.0, 5)])
+def test_heavy_weight_random_starts_on_the_reference_tie_stream(gpu_lib, oracle, n, d, beta, seed):
+    """RandNemAlgo on a graph with the caller's coverage weights (U[1, d]) under TIE_LIBC.  Where beta * sum(w) passes 709
+    a site's row is NaN and ComputeMAP's NaN rules redraw it in EVERY sweep: the starts draw behind their initial sweeps
+    (case 1: all of them, case 2: three of six -- the lock-step bet is lost mid-round and the starts behind the one that
+    drew are redone, case 3: none), and the chosen criterion M is -inf for every start, so the first start stays the
+    best (nem_alg.c:1676-1697).  Engine == oracle."""
+    from pangenomenem_amd.engine import NemEngine
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed)
+    nei = synth.contiguity_graph(n, seed, weights="coverage", d=d)
+    eng = NemEngine(n, d, 3)
+    eng.set_matrix(x)
+    eng.set_graph(nei)
+    eng.configure(algo="ncem", beta=beta, disper="sk_", propor="pk", it_max=8, tie="libc", seed=seed)
+    got = eng.run_random(n_starts=6, rng_seed=seed)
+    how = eng.random_start_counters()
+    want = oracle.run_random(x, nei, 3, n_starts=6, rng_seed=seed, algo="ncem", disper="sk_", beta=beta, it_max=8, tie="libc")
+    assert how["in_lockstep"] + how["alone"] == 6
+    if (d, beta) == (600, 0.5):
+        assert how["redone"] > 0, how
+    assert got["status"] == want["status"] and got["best_start"] == want["best_start"] and got["iters"] == want["iters"]
+    assert np.array_equal(got["c"], want["c"])
+    assert np.array_equal(got["center"], want["center"])
+    for key in ("disp", "prop"):
+        assert np.max(np.abs(got[key] - want[key])) <= 1e-6, key
+    assert_crit_close(got["crit"], want["crit"], 1e-6, "criteria")
+    eng.close()
