@@ -443,7 +443,21 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         }
     }
     const bool long_row = ne - nb > 4;
-    int lower_draws = -1;                                // TIE_LIBC: draws of the blocks below this one (lazily)
+    // TIE_LIBC: draws of the blocks below this one, as the guess has them -- summed once by the block's first wave (a
+    // lane that ties used to add the counts up itself: up to 78 loads in a row per tying lane, 2-3 us of a round on
+    // data that tie in every sweep, the initial sweeps of a random start)
+    __shared__ int s_lower;
+    if (libc && !skip && threadIdx.x < 64 && a.tie_cnt_guess != nullptr) {
+        int part = 0;
+        for (int b = threadIdx.x; b < bx; b += 64) part += a.tie_cnt_guess[b];
+        part = wave_sum_i32(part);
+        if (threadIdx.x == 0) {
+            if (a.rank_tot_in != nullptr)                // sharded: the ranks below, as the guess has them
+                for (int r = 0; r < a.rank_index; r++) part += *reinterpret_cast<const int*>(a.rank_tot_in + (size_t)r * a.slot_stride);
+            s_lower = part;
+        }
+    }
+    int lower_draws = -1;                                // (read from s_lower behind the step's first barrier)
     bool tab_short = false;                              // TIE_LIBC: a draw fell outside the table: the round is void
     int cur = my_guess;                                  // this site's byte in s_lab
     int seen[4] = {-1, -1, -1, -1};                      // labels the last evaluation used for the dyn neighbours
@@ -520,13 +534,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
                         if (libc) {
                             // the reference's stream (nem_rnd.c:53-61): this site's draw is number
                             //   draws before the sweep + sites below it that drew in this sweep
-                            if (lower_draws < 0) {
-                                lower_draws = 0;
-                                for (int b = 0; b < bx; b++) lower_draws += a.tie_cnt_guess[b];
-                                if (a.rank_tot_in != nullptr)    // sharded: the ranks below, as the guess has them
-                                    for (int r = 0; r < a.rank_index; r++)
-                                        lower_draws += *reinterpret_cast<const int*>(a.rank_tot_in + (size_t)r * a.slot_stride);
-                            }
+                            if (lower_draws < 0) lower_draws = s_lower;
                             int base = a.draw_base, tab0 = a.draw_tab0;
                             if (a.draw_ctl != nullptr) { base = a.draw_ctl[0]; tab0 = a.draw_ctl[1]; }
                             if (a.draw_extra != nullptr) base += *a.draw_extra & (kTabShort - 1);
