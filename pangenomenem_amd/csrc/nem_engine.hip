@@ -1275,7 +1275,14 @@ int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[
     e->masks_valid = false;
     if ((r = do_labels_post(e, 2, -1))) return r;
     launch_fill(e->sweep_next, 1, (int)e->sweep_counter, e->stream);
-    HIPCHK(hipEventSynchronize(e->ev_flags));
+    // (polled: the wait is tens of microseconds and its end is on the critical path of every start; a blocking wait's
+    //  wake-up cost 5-10 us more)
+    for (;;) {
+        const hipError_t q = hipEventQuery(e->ev_flags);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { HIPCHK(q); }
+        __builtin_ia32_pause();
+    }
     if ((r = check_fault(e))) return r;
     auto book = [&](const int* f, int done_at) {
         e->draws += f[FLAG_NTIES] & ((1 << 30) - 1);
@@ -3678,8 +3685,13 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 nemgpu_engine* c = E[j];
                 auto t = clk::now();
                 if ((r = make_random_para(j))) return r;
-                memcpy(e->rs_par_host + (size_t)j * par_bytes, host_par.data() + (size_t)j * par, par_bytes);
-                HIPCHK(hipMemcpyAsync(c->prop0, e->rs_par_host + (size_t)j * par_bytes, par_bytes, hipMemcpyHostToDevice, e->stream));
+                // (k_finish reads the start's parameters where the host wrote them: a pinned slot is device-visible, 12 KB
+                //  cross the bus inside the launch; a copy command of its own was 2 us + two queue gaps of 4-5 us in the chain)
+                float* slot = reinterpret_cast<float*>(e->rs_par_host + (size_t)j * par_bytes);
+                memcpy(slot, host_par.data() + (size_t)j * par, par_bytes);
+                float* const own_par[3] = {c->prop0, c->center0, c->disp0};
+                c->prop0 = slot; c->center0 = slot + k; c->disp0 = slot + k + kd;
+                struct ParBack { nemgpu_engine* c; float* const* own; ~ParBack() { c->prop0 = own[0]; c->center0 = own[1]; c->disp0 = own[2]; } } par_back{c, own_par};
                 if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
                 lend_window(c);
                 c->draws = e->draws; c->tie_heavy = e->tie_heavy;
@@ -3687,8 +3699,9 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 lap(0, t);
                 // The rounds a sweep needs are long-tailed: a start that ties at a few families is through in three or
                 // four, one whose centres tie at thousands needs dozens (a draw's number depends on every tie before
-                // it).  What goes out at once: for the blind sweep the most any start so far needed (two to five), for
-                // the beta sweep what 70 % of them got by with; a sweep that needs more gets batches that double.
+                // it).  What goes out at once: what 90 % of the starts so far got by with for the blind sweep (three: a
+                // round behind the fixed point still costs 4 us), 70 % for the beta sweep; a sweep that needs more gets
+                // batches that double.
                 auto usual = [&](int which, int percent) {
                     const int* h = e->libc_init_hist[which];
                     int total = 0; for (int q = 0; q <= 16; q++) total += h[q];
@@ -3699,13 +3712,13 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 int rounds[2] = {0, 0};
                 bool redo = false;
                 if (one_wait) {
-                    if ((r = libc_init_one_wait(c, std::min(8, usual(0, 100)), usual(1, 70), &redo, rounds))) return r;
+                    if ((r = libc_init_one_wait(c, std::min(8, usual(0, 90)), usual(1, 70), &redo, rounds))) return r;
                     lap(1, t);
                     if (redo) e->rs_two_waits++;
                 }
                 if (!one_wait || redo) {
                     SweepCtx sc;
-                    if ((r = libc_init_a(c, sc, std::min(8, usual(0, 100))))) return r;
+                    if ((r = libc_init_a(c, sc, std::min(8, usual(0, 90))))) return r;
                     lap(1, t);
                     if ((r = sweep_complete(c, sc, &rounds[0], nullptr, false, true))) return r;
                     lap(2, t);
