@@ -85,7 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `also` block (N = 1: coverage weights, 64 problems in lock "
-                    "step, 200 000 x 5 000, 256 whole chunks; N > 1: replicas, 200 000 x 5 000)")
+                    "step, 50 random starts on the tie stream, 200 000 x 5 000, 256 whole chunks; N > 1: replicas, 200 000 x 5 000)")
     ap.add_argument("--extras-strong-shape", default="200000x5000", help="families x organisms of the `also` block's strong-scaling problem")
     ap.add_argument("--dist", action="store_true", help="use the sharded torch.distributed path even with 1 GPU")
     ap.add_argument("--cpu-iters", type=int, default=24, help="reference iterations timed for the CPU baseline")
@@ -450,6 +450,47 @@ def also_single_gpu(args, k, beta):
             e.close()
     except Exception as exc:
         also["lockstep_64_configs1"] = {"error": repr(exc)}
+    # (2b) RandNemAlgo's 50 random starts (init_mode = 1) under the reference's own tie stream: their initial sweeps in
+    # stream order, their iterations in lock step, against the same starts one after the other
+    try:
+        from pangenomenem_amd.engine import NemEngine, Result
+        import ctypes as C
+        x0, _ = synth.ushaped_pa_matrix(20000, 500, 9)
+        nei0 = synth.contiguity_graph(20000, 9)
+        rec = {}
+        for mode, key in (("0", "one_after_the_other_ms"), ("1", "lockstep_ms")):
+            old_env = os.environ.get("NEM_MI355X_BATCH_STARTS")
+            os.environ["NEM_MI355X_BATCH_STARTS"] = mode
+            try:
+                e = NemEngine(20000, 500, 3)
+                e.set_matrix(x0); e.set_graph(nei0)
+                e.configure(algo="ncem", beta=beta, disper="sk_", propor="pk", it_max=100, tie="libc", seed=3)
+                r, bst = Result(), C.c_int(-1)
+                best = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc = e.lib.nemgpu_run_random(e._h, 50, C.c_uint32(3), C.byref(r), C.byref(bst))
+                    dt = time.perf_counter() - t0
+                    if rc != 0:
+                        raise RuntimeError("nemgpu_run_random: status %d" % rc)
+                    best = dt if best is None else min(best, dt)
+                rec[key] = best * 1e3
+                rec["best_start_" + mode] = int(bst.value)
+                rec["tie_draws"] = int(r.tie_draws)
+                if mode == "1":
+                    rec["how"] = e.random_start_counters()
+                e.close()
+            finally:
+                if old_env is None:
+                    os.environ.pop("NEM_MI355X_BATCH_STARTS", None)
+                else:
+                    os.environ["NEM_MI355X_BATCH_STARTS"] = old_env
+        rec["same_best_start"] = rec.pop("best_start_0") == rec.pop("best_start_1")
+        rec["note"] = ("50 starts of 20 000 x 500, K = 3, NCEM, srandom(3); TIE_LIBC: the starts' centre draws and every sweep's tie "
+                       "draws are one random() stream; best of 3 calls each; how = lock-step rounds / starts in them / alone / redone")
+        also["random_starts_50_tie_stream"] = rec
+    except Exception as exc:
+        also["random_starts_50_tie_stream"] = {"error": repr(exc)}
     # (3) 200 000 x 5 000 on this one GPU (BASELINE configs[3]'s matrix)
     try:
         x, nei, prop, center, disp, disper, _ = make_workload(200000, 5000, k, "ushape", 2)
