@@ -3373,6 +3373,7 @@ static int run_random_impl(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu
     int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
     float best_crit[6] = {0, 0, 0, 0, 0, 0};
     nemgpu_result best_res{};
+    e->rs_rounds = e->rs_lockstep = e->rs_redone = e->rs_two_waits = 0; e->rs_alone = n_starts;   // (one after the other)
     for (int s = 0; s < n_starts; s++) {
         // MakeRandomPara
         for (int h = 0; h < k; h++) for (int j = 0; j < d; j++) disp[(size_t)h * d + j] = dispsam[j] / k;      // :1400

@@ -206,6 +206,42 @@ def test_random_starts_whose_iterations_draw(gpu_lib, oracle, monkeypatch, d, se
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,k,beta,disper,starts,it_max,graph", [
+    (800, 12, 3, 0.0, "sk_", 7, 15, True),       # beta = 0: the sweeps read no neighbour, the draw counter still couples the sites
+    (800, 12, 3, 0.5, "sk_", 7, 15, False),      # no graph at all
+    (700, 10, 5, 0.7, "skd", 9, 12, True),       # K = 5, free dispersion
+    (600, 8, 2, 0.5, "s__", 6, 10, True),        # K = 2, one dispersion for everything
+    (500, 9, 3, 0.5, "sk_", 70, 6, True),        # more starts than a lock-step round holds (64): two rounds of phase A / B
+    (900, 14, 3, 0.5, "sk_", 1, 20, True),       # one start
+    (900, 14, 3, 0.5, "sk_", 5, 0, True),        # it_max = 0: initial partitions only
+    (3000, 7, 4, 1.5, "s_d", 8, 10, True)])      # a strong field: long dominoes in the initial beta sweep
+def test_random_starts_on_the_tie_stream_across_configurations(gpu_lib, oracle, n, d, k, beta, disper, starts, it_max, graph):
+    """RandNemAlgo under TIE_LIBC in its two-phase lock-step form (initial sweeps in stream order, iterations in lock
+    step) against the oracle's plain loop, start for start: few organisms => many identical families => every start
+    ties at hundreds of families."""
+    from pangenomenem_amd.engine import NemEngine
+    seed = 1000 + n + d
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed, p=(0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, seed) if graph else (np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    eng = NemEngine(n, d, k)
+    eng.set_matrix(x)
+    if graph:
+        eng.set_graph(nei)
+    eng.configure(algo="ncem", beta=beta, disper=disper, propor="pk", it_max=it_max, tie="libc", seed=seed)
+    got = eng.run_random(n_starts=starts, rng_seed=seed)
+    how = eng.random_start_counters()
+    want = oracle.run_random(x, nei, k, n_starts=starts, rng_seed=seed, algo="ncem", disper=disper, beta=beta, it_max=it_max, tie="libc")
+    assert how["in_lockstep"] + how["alone"] == starts
+    assert got["tie_draws"] >= starts * k                     # (the centres' draws; all cases but the last tie on top of them)
+    assert got["status"] == want["status"] and got["best_start"] == want["best_start"] and got["iters"] == want["iters"]
+    assert np.array_equal(got["c"], want["c"])
+    assert np.array_equal(got["center"], want["center"])
+    for key in ("disp", "prop"):
+        assert maxdiff(got[key], want[key]) <= TOL, key
+    assert_crit_close(got["crit"], want["crit"], 1e-6)
+    eng.close()
+
+
 def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
     # D > 32768: the class masks of the uniform chain no longer fit its LDS staging, every class takes the general
     # chain; K = 32 is the engine's maximum
