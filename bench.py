@@ -166,7 +166,7 @@ def timing_fields(blocks, steps):
 class EngineRun:
     """One problem resident on one GPU, timed the way the module docstring says."""
 
-    def __init__(self, x, nei, k, prop, center, disp, algo, beta, disper, device=0):
+    def __init__(self, x, nei, k, prop, center, disp, algo, beta, disper, device=0, tie="hash"):
         from pangenomenem_amd.engine import NemEngine
         n, d = x.shape
         self.algo, self.beta, self.disper = algo, beta, disper
@@ -175,13 +175,13 @@ class EngineRun:
         eng.set_graph(nei)
         eng.set_params(prop, center, disp)
         # how many iterations does this workload need?  (the reference's call: clas, 1e-8, it_max 100)
-        eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="clas", cvthres=1e-8, it_max=100)
+        eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="clas", cvthres=1e-8, it_max=100, tie=tie, seed=1)
         first = eng.run()
         self.first = first
         # (a run that ends with an empty class -- K = 9 of the K sweep -- stops in the M-step of its last iteration:
         #  the iterations before it are the ones that can be timed)
         self.cycle = max(1, int(first["iters"]) - (1 if first["status"] != 0 else 0))
-        eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="none", it_max=100)
+        eng.configure(algo=algo, beta=beta, disper=disper, propor="pk", cvtest="none", it_max=100, tie=tie, seed=1)
         eng.set_graph_policy(True)
 
     def run_steps(self, count):
@@ -409,6 +409,24 @@ def also_single_gpu(args, k, beta):
             run.eng.close()
         except Exception as exc:
             also[key] = {"error": repr(exc)}
+    # (1b) the headline workload under the reference's own tie rule (TIE_LIBC, the drop-in's default: ComputeMAP's ties are
+    # broken by the draws of glibc's random() in the sequential sweep's order).  The headline itself runs the stateless hash
+    # rule; here the sweeps carry the draw bookkeeping and a restart's two initial sweeps are completed from the host.
+    try:
+        x, nei, prop, center, disp, disper, _ = make_workload(20000, 500, k, "ushape", 2)
+        run = EngineRun(x, nei, k, prop, center, disp, "ncem", beta, "sk_", tie="libc")
+        steps = max(run.cycle, (140 // run.cycle) * run.cycle)
+        blocks, info = run.timed(steps, run.cycle, reps)
+        tf, med = timing_fields(blocks, steps)
+        also["reference_tie_stream"] = dict(
+            workload="BASELINE configs[1], the headline's matrix and graph, tie rule TIE_LIBC",
+            ms_per_step=tf["ms_per_step"], ms_per_step_min=tf["ms_per_step_min"], ms_per_step_max=tf["ms_per_step_max"],
+            steps=steps, repeats=tf["repeats"], cells_per_sec=20000 * 500 * steps / med, iters_to_converge=info["iters_to_converge"],
+            tie_draws_first_run=int(run.first["tie_draws"]), sweep_rounds_per_iteration=info["sweep_rounds_per_iteration"],
+            host_finished_sweeps_timed=info["host_finished_sweeps_timed"])
+        run.eng.close()
+    except Exception as exc:
+        also["reference_tie_stream"] = {"error": repr(exc)}
     # (2) 64 configs[1]-sized problems in lock step (one launch per EM step for all of them)
     try:
         from pangenomenem_amd.engine import NemEngine, Result, profile_density_many

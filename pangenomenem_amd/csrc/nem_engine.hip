@@ -1316,6 +1316,46 @@ int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[
     return NEMGPU_OK;
 }
 
+// How many rounds of an initial sweep go out at once: what `percent` % of the runs so far got by with (which: 0 the blind
+// sweep, 1 the beta sweep; the tally lives on the engine that owns the twins)
+int libc_init_usual(const nemgpu_engine* e, int which, int percent)
+{
+    const nemgpu_engine* o = e->parent ? e->parent : e;
+    const int* h = o->libc_init_hist[which];
+    int total = 0; for (int q = 0; q <= 16; q++) total += h[q];
+    int acc = 0, q = 0;
+    for (; q < 16; q++) { acc += h[q]; if (total > 0 && 100 * acc >= percent * total) break; }
+    return std::max(e->round_batch, total > 0 ? q : 3);
+}
+void libc_init_tally(nemgpu_engine* e, const int rounds[2])
+{
+    nemgpu_engine* o = e->parent ? e->parent : e;
+    o->libc_init_hist[0][std::max(0, std::min(16, rounds[0]))]++;
+    o->libc_init_hist[1][std::max(0, std::min(16, rounds[1]))]++;
+}
+// a TIE_LIBC run's start: the one-wait form, or (asked for, or its blind sweep was not through) sweep by sweep
+int libc_init(nemgpu_engine* e, int* rounds_beta = nullptr, bool* was_redone = nullptr)
+{
+    static const bool one_wait = !(getenv("NEM_MI355X_STARTS_ONE_WAIT") && getenv("NEM_MI355X_STARTS_ONE_WAIT")[0] == '0');
+    int r;
+    int rounds[2] = {0, 0};
+    bool redo = false;
+    const int ra = std::min(8, libc_init_usual(e, 0, 90)), rb = libc_init_usual(e, 1, 70);
+    if (one_wait && current_recorder() == nullptr) { if ((r = libc_init_one_wait(e, ra, rb, &redo, rounds))) return r; }
+    if (was_redone) *was_redone = redo;
+    if (!one_wait || redo || current_recorder() != nullptr) {
+        SweepCtx sc;
+        if ((r = libc_init_a(e, sc, ra)) || (r = sweep_complete(e, sc, &rounds[0], nullptr, false, true))) return r;
+        if ((r = libc_init_b(e, sc, rb)) || (r = sweep_complete(e, sc, &rounds[1], nullptr, false, true))) return r;
+        if ((r = libc_init_c(e))) return r;
+    }
+    HIPCHK(hipGetLastError());
+    libc_init_tally(e, rounds);
+    if (rounds_beta) *rounds_beta = rounds[1];
+    e->draws_after_init = e->draws;
+    return NEMGPU_OK;
+}
+
 // ---- one batch of the pipelined loop, in three pieces so that the same code drives ONE engine (iterate) or SEVERAL
 // in lock step (iterate_many: the pieces' launches are recorded per engine and issued once for all of them) ----------
 struct LoopCursor {
@@ -1504,14 +1544,10 @@ int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
     LoopCursor lc;
     if ((r = loop_begin(e, lc, n_iters, with_init))) return r;
     if (lc.first && e->libc()) {
-        // TIE_LIBC: the two initial sweeps run from the host, sweep by sweep; the iterations behind them are pipelined
-        SweepCtx c;
-        if ((r = libc_init_a(e, c)) || (r = sweep_complete(e, c, nullptr, nullptr))) return r;
-        if ((r = libc_init_b(e, c)) || (r = sweep_complete(e, c, nullptr, nullptr))) return r;
-        if ((r = libc_init_c(e))) return r;
-        HIPCHK(hipGetLastError());
+        // TIE_LIBC: the two initial sweeps are completed from the host (one wait: libc_init_one_wait); the iterations
+        // behind them are pipelined
+        if ((r = libc_init(e))) return r;
         lc.first = false;
-        e->draws_after_init = e->draws;
     }
     while (loop_wants_batch(e, lc)) {
         if ((r = batch_plan(e, lc))) return r;
@@ -3681,7 +3717,6 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 pool_put(e->device, true, e->rs_par_host, e->rs_par_host_size); e->rs_par_host = nullptr; e->rs_par_host_size = 0;
                 HIPCHK(pool_get(e->device, true, (size_t)group * par_bytes, &e->rs_par_host, &e->rs_par_host_size));
             }
-            static const bool one_wait = !(getenv("NEM_MI355X_STARTS_ONE_WAIT") && getenv("NEM_MI355X_STARTS_ONE_WAIT")[0] == '0');
             for (int j = 0; j < M; j++) {
                 nemgpu_engine* c = E[j];
                 auto t = clk::now();
@@ -3702,35 +3737,13 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 // four, one whose centres tie at thousands needs dozens (a draw's number depends on every tie before
                 // it).  What goes out at once: what 90 % of the starts so far got by with for the blind sweep (three: a
                 // round behind the fixed point still costs 4 us), 70 % for the beta sweep; a sweep that needs more gets
-                // batches that double.
-                auto usual = [&](int which, int percent) {
-                    const int* h = e->libc_init_hist[which];
-                    int total = 0; for (int q = 0; q <= 16; q++) total += h[q];
-                    int acc = 0, q = 0;
-                    for (; q < 16; q++) { acc += h[q]; if (total > 0 && 100 * acc >= percent * total) break; }
-                    return std::max(e->round_batch, total > 0 ? q : 3);
-                };
-                int rounds[2] = {0, 0};
-                bool redo = false;
-                if (one_wait) {
-                    if ((r = libc_init_one_wait(c, std::min(8, usual(0, 90)), usual(1, 70), &redo, rounds))) return r;
-                    lap(1, t);
-                    if (redo) e->rs_two_waits++;
-                }
-                if (!one_wait || redo) {
-                    SweepCtx sc;
-                    if ((r = libc_init_a(c, sc, std::min(8, usual(0, 90))))) return r;
-                    lap(1, t);
-                    if ((r = sweep_complete(c, sc, &rounds[0], nullptr, false, true))) return r;
-                    lap(2, t);
-                    if ((r = libc_init_b(c, sc, usual(1, 70)))) return r;
-                    lap(3, t);
-                    if ((r = sweep_complete(c, sc, &rounds[1], nullptr, false, true))) return r;
-                    if ((r = libc_init_c(c))) return r;
-                }
-                e->libc_init_hist[0][std::min(16, rounds[0])]++;
-                e->libc_init_hist[1][std::min(16, rounds[1])]++;
-                if (prof && rounds[1] >= 16) fprintf(stderr, "[random starts]   start %d: beta sweep %d rounds, %d draws in its initial sweeps\n", next + j, rounds[1], c->draws - start_pos[j]);
+                // batches that double (libc_init).
+                int rounds_beta = 0;
+                bool redone = false;
+                if ((r = libc_init(c, &rounds_beta, &redone))) return r;
+                if (redone) e->rs_two_waits++;
+                lap(1, t);
+                if (prof && rounds_beta >= 16) fprintf(stderr, "[random starts]   start %d: beta sweep %d rounds, %d draws in its initial sweeps\n", next + j, rounds_beta, c->draws - start_pos[j]);
                 HIPCHK(hipGetLastError());
                 lap(4, t);
                 L[j].first = false;
