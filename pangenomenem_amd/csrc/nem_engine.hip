@@ -135,6 +135,7 @@ struct nemgpu_engine {
     bool draw_borrowed = false;          // the table is the parent's (lock-step random starts): never written through this engine
     int draws_after_init = 0;                  // TIE_LIBC: the stream's position behind a run's two initial sweeps
     char* rs_par_host = nullptr; size_t rs_par_host_size = 0;   // random starts under TIE_LIBC: the starts' parameters, pinned
+    int libc_ra = 3, libc_rb = 3;              // TIE_LIBC, pipelined start: rounds enqueued for the blind / the beta initial sweep (batch_plan sets them; part of a first batch's graph)
     const int* draw_extra_once = nullptr;      // TIE_LIBC: the next sweep set up adds this device word to the draws before it (a sweep enqueued behind one whose count the host has not seen)
     int libc_init_hist[2][17] = {};            // TIE_LIBC random starts: how many relaxation rounds the blind / the beta initial sweep of the starts so far needed (16: more)
     int rs_two_waits = 0;                      // ... starts of phase A whose blind sweep was not through in the rounds enqueued (done again, sweep by sweep)
@@ -1173,6 +1174,15 @@ int enqueue_iteration(nemgpu_engine* e, int cur, uint32_t sweep_id, bool defer_c
 
 // the restart + the two initial sweeps as the head of a pipelined batch (buffers 0 -> 1 -> 2)
 // defer_ctrl: an iteration follows in the same batch (see enqueue_iteration)
+int libc_init_usual(const nemgpu_engine* e, int which, int percent);
+// TIE_LIBC: is a run's start part of its first pipelined batch (verified on the device, see ctrl_logic), or completed
+// from the host before it (NEM_MI355X_LIBC_INIT=host)?
+static bool libc_init_pipelined()
+{
+    const char* v = getenv("NEM_MI355X_LIBC_INIT");          // (read every time: a switch for tests and A/B runs)
+    return !(v && strcmp(v, "host") == 0);
+}
+
 int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
 {
     int r;
@@ -1189,20 +1199,29 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     if ((r = do_density(e))) return r;                             // (also clears every sweep flag slot)
     SweepCtx c0, c1;
     e->sweep_counter = 0;
-    // blind sweep: one round, 0 -> 1, on a flag slot of its own so that no clear is needed before the next sweep
-    if ((r = sweep_enqueue(e, 0.0f, c0, true, nullptr, false, kRoundCap - 1))) return r;
+    // blind sweep: one round, 0 -> 1, on a flag slot of its own so that no clear is needed before the next sweep.
+    // TIE_LIBC: its sites are coupled through the draw counter -- `ra` verified rounds on the window's last slots; the
+    // beta sweep behind it takes the blind sweep's draw count from the last of those slots on the device (the rounds
+    // behind a fixed point carry it along), the loop control checks both sweeps and books their draws (ctrl_logic).
+    const bool libc = e->libc();
+    const int ra = libc ? e->libc_ra : 1;
+    if ((r = sweep_enqueue(e, 0.0f, c0, true, nullptr, false, kRoundCap - ra, libc ? ra : 0))) return r;
     e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
     ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0));
+    if (libc) ca.n_rounds = std::max(ca.n_rounds, e->libc_rb);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
     ca.is_init = 1;
-    ca.blind = e->round_flags(kRoundCap - 1);
+    ca.blind = e->round_flags(kRoundCap - ra);
+    ca.blind_rounds = libc ? ra : 0;
     const bool defer = defer_ctrl && e->ncem() && !e->cfg.param_fix;
     CtrlArgs none{};
+    if (libc) e->draw_extra_once = e->round_flags(kRoundCap - 1) + FLAG_NTIES;
     if ((r = sweep_enqueue(e, e->cfg.beta, c1, true, e->ncem() ? (defer ? &none : &ca) : nullptr, false, 0, ca.n_rounds))) return r;   // 1 -> 2 (and 0 as the pong buffer)
+    e->draw_extra_once = nullptr;
     if (defer) { e->ctrl_deferred = ca; e->ctrl_pending = true; }
     if (e->ncem()) e->masks_valid = true;
     else { launch_ctrl(ca, e->stream); HIPCHK(hipGetLastError()); }
@@ -1413,6 +1432,11 @@ int batch_plan(nemgpu_engine* e, LoopCursor& lc)
         if (e->cfg.param_fix) { if ((r = do_tables(e))) return r; }
     }
     if (e->libc()) {
+        if (lc.first) {
+            // the rounds of the two initial sweeps: what most runs so far got by with (at most 8: the loop control's window)
+            const int ra = std::max(2, std::min(8, libc_init_usual(e, 0, 90))), rb = std::max(2, std::min(8, libc_init_usual(e, 1, 70)));
+            if (ra != e->libc_ra || rb != e->libc_rb) { e->libc_ra = ra; e->libc_rb = rb; drop_graphs(e); }
+        }
         if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;      // (may drop the graphs)
         if ((r = publish_draw_ctl(e))) return r;
     }
@@ -1452,6 +1476,20 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
     const bool first = lc.batch_first;
     const int base = lc.base;
     const uint32_t sweep0 = lc.sweep0;
+    if (first && e->libc()) {
+        if (c[C_NEED_ROUNDS] >= 2) {
+            // TIE_LIBC: one of the two initial sweeps was not through in the rounds enqueued (or a draw left the table):
+            // nothing was booked, everything behind returned at the stop word -- the start is done again from the host
+            e->n_host_rounds++;
+            e->flags_clean = false;
+            if ((r = libc_init(e))) return r;
+            lc.first = false;
+            return NEMGPU_OK;
+        }
+        const int got[2] = {e->libc_ra, e->libc_rb};
+        libc_init_tally(e, got);                               // (what was enqueued was enough)
+        e->draws_after_init = e->draws + c[C_DRAWS_INIT];
+    }
     e->iters += done;
     e->draws += c[C_DRAWS];
     e->sweep_rounds += c[C_SWEEP_ROUNDS];
@@ -1543,9 +1581,9 @@ int iterate_pipelined(nemgpu_engine* e, int n_iters, bool with_init)
     int r;
     LoopCursor lc;
     if ((r = loop_begin(e, lc, n_iters, with_init))) return r;
-    if (lc.first && e->libc()) {
-        // TIE_LIBC: the two initial sweeps are completed from the host (one wait: libc_init_one_wait); the iterations
-        // behind them are pipelined
+    if (lc.first && e->libc() && !libc_init_pipelined()) {
+        // TIE_LIBC, NEM_MI355X_LIBC_INIT=host: the two initial sweeps are completed from the host (one wait:
+        // libc_init_one_wait); the iterations behind them are pipelined
         if ((r = libc_init(e))) return r;
         lc.first = false;
     }
@@ -1836,7 +1874,7 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
     std::vector<int> members;
     // TIE_LIBC members: the two initial sweeps, completed one after the other (see libc_init_a)
     members.clear();
-    for (int i = 0; i < B; i++) if (L[i].first && E[i]->libc()) members.push_back(i);
+    for (int i = 0; i < B; i++) if (L[i].first && E[i]->libc() && !libc_init_pipelined()) members.push_back(i);
     if (!members.empty()) {
         std::vector<SweepCtx> ctx((size_t)B);
         if ((r = lockstep(E, members, recs, [&](int m) { pending_layout(E[m]); return libc_init_a(E[m], ctx[m]); }, true))) return r;

@@ -28,7 +28,8 @@ enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_FAULT = 2, FLAG_MOVED = 3, FLA
 // C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
 // zero-density sites" (how the next sweeps tally them, see k_sweep); it survives a restart.
 enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
-       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_DEEP = 12, C_WORDS = 16 };
+       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_DEEP = 12, C_DRAWS_INIT = 13, C_WORDS = 16 };
+// C_DRAWS_INIT (TIE_LIBC): of C_DRAWS, what the run's two initial sweeps drew
 // C_DEEP: the last iteration of the batch (1-based) whose sweep used more than two of its relaxation rounds
 
 struct CtrlArgs {
@@ -43,6 +44,7 @@ struct CtrlArgs {
     int moved_bytes;               // sharded: the byte behind a rank's flag byte says 'one of its labels moved' (1: in r_flags, 2: in q_flags)
     int is_init;                   // the two initial sweeps: no iteration is counted, the sweep number becomes 2
     const int* blind;              // is_init: flag slot of the blind beta = 0 sweep (its zero-density tally), or nullptr
+    int blind_rounds;              // is_init, TIE_LIBC: the blind sweep ran this many verified rounds, their slots from `blind` on (0: one slot, nothing to verify)
     int* draw_ctl;                 // TIE_LIBC: {draws made so far, first draw of the table} (device), else nullptr
     const uint8_t* q_tot;          // TIE_LIBC, sharded: rank 0's draw total in the tail of the sweep's first buffer (flag_stride apart)
 };

@@ -52,7 +52,18 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
 #pragma unroll
     for (int r = 0; r < kMaxRounds; r++) rf[r] = r < nr ? reinterpret_cast<const int4*>(a.round0)[r] : make_int4(1, 0, 0, 0);
     int4 bf = make_int4(0, 0, 0, 0);
-    if (a.is_init && a.blind != nullptr) bf = *reinterpret_cast<const int4*>(a.blind);
+    bool blind_ok = true;
+    if (a.is_init && a.blind != nullptr) {
+        if (a.blind_rounds > 1) {
+            // TIE_LIBC: the blind sweep's sites are coupled through the draw counter, it ran verified rounds like any
+            // sweep: its result is the first round that changed nothing (the rounds behind it did not run)
+            blind_ok = false;
+            for (int q = 0; q < a.blind_rounds && !blind_ok; q++) {
+                const int4 f = reinterpret_cast<const int4*>(a.blind)[q];
+                if (f.x == 0) { bf = f; blind_ok = true; }
+            }
+        } else bf = *reinterpret_cast<const int4*>(a.blind);
+    }
     int draw0 = 0, rank_draws = 0;
     if (a.draw_ctl != nullptr) {
         draw0 = a.draw_ctl[0];
@@ -89,6 +100,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     if (a.is_init) *a.sweep_next = 2;
     else { iters += 1; c[C_ITERS] = iters; *a.sweep_next = sweep_next + 1; }
     if (a.is_init) {                                              // ComputePartitionFromPara(Needinit=1): no iteration counted
+        if (!blind_ok) { c[C_NEED_ROUNDS] = 3; c[C_STOP] = 1; return; }   // (what ran behind the blind sweep is void: the host starts over)
         if (bf.y > 0) {                                           // the blind sweep's zero-density sites come first
             nzero += bf.y;
             if (firstzero == 0) firstzero = bf.z;
@@ -98,6 +110,12 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
             if (f.y > 0) { nzero += f.y; if (firstzero == 0) firstzero = f.z; }
             c[C_FOLD] = f.y > 0;                                  // how the next sweeps tally such sites, see k_sweep
             c[C_SWEEP_ROUNDS] = sweep_rounds;
+            if (a.draw_ctl != nullptr && a.blind_rounds > 1) {    // TIE_LIBC: both sweeps' draws move the stream on
+                const int nt = (bf.w & ((1 << 30) - 1)) + (f.w & ((1 << 30) - 1));
+                a.draw_ctl[0] = draw0 + nt;
+                c[C_DRAWS] = draws + nt;
+                c[C_DRAWS_INIT] = nt;
+            }
         }
         c[C_NZERO] = nzero; c[C_FIRSTZERO] = firstzero;
         if (last < 0) { c[C_NEED_ROUNDS] = 2; c[C_STOP] = 1; }

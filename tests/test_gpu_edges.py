@@ -242,6 +242,41 @@ def test_random_starts_on_the_tie_stream_across_configurations(gpu_lib, oracle, 
     eng.close()
 
 
+@pytest.mark.parametrize("n,d,beta,init_mode,stops", [(3000, 5, 0.5, "pipelined", True), (3000, 5, 1.5, "pipelined", True),
+                                                       (6000, 4, 1.0, "pipelined", False), (3000, 5, 1.5, "host", False)])
+def test_a_tie_stream_start_that_needs_more_rounds_than_were_enqueued(gpu_lib, oracle, monkeypatch, n, d, beta, init_mode, stops):
+    """Under TIE_LIBC a run's two initial sweeps ride in its first pipelined batch with a fixed number of relaxation rounds
+    (verified by the loop control on the device).  With 4-5 organisms thousands of families are identical: equal
+    dispersions at the start make whole blocks tie, a draw's number depends on every tie before it, and the beta sweep
+    needs far more rounds than were enqueued -- the batch stops itself, books nothing, and the start is done again from
+    the host (third case: 4 583 draws, but through in the rounds enqueued).  Result = oracle either way, and with
+    NEM_MI355X_LIBC_INIT=host, the form without the device check."""
+    from pangenomenem_amd.engine import NemEngine
+    monkeypatch.setenv("NEM_MI355X_LIBC_INIT", init_mode)
+    seed = 31
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed, p=(0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, seed)
+    prop = np.full(3, 1.0 / 3, np.float32)
+    center = x[[0, n // 2, n - 1]].astype(np.float32)              # three families as centres, one dispersion: the random starts' shape
+    if len({tuple(r) for r in center}) < 3:
+        center = np.array([[0] * d, [1] * d, [1] + [0] * (d - 1)], np.float32)
+    disp = np.full((3, d), 0.12, np.float32)
+    eng = NemEngine(n, d, 3)
+    eng.set_matrix(x); eng.set_graph(nei); eng.set_params(prop, center, disp)
+    eng.configure(algo="ncem", beta=beta, disper="sk_", propor="pk", it_max=12, tie="libc", seed=seed)
+    got = eng.run()
+    want = oracle.run(x, nei, 3, prop, center, disp, algo="ncem", beta=beta, disper="sk_", it_max=12, tie="libc", seed=seed)
+    assert got["tie_draws"] > 100, got["tie_draws"]
+    if stops:
+        assert eng.graph_counters()["host_finished_sweeps"] >= 1      # the first batch did stop itself
+    if init_mode == "host":
+        assert eng.graph_counters()["host_finished_sweeps"] == 0
+    same_run(got, want, "ncem")
+    got2 = eng.run()                                                   # (the rounds enqueued have adapted or not: same result)
+    same_run(got2, want, "ncem")
+    eng.close()
+
+
 def test_very_wide_matrix_and_maximum_class_count(gpu_lib, oracle):
     # D > 32768: the class masks of the uniform chain no longer fit its LDS staging, every class takes the general
     # chain; K = 32 is the engine's maximum
