@@ -1486,8 +1486,8 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
             lc.first = false;
             return NEMGPU_OK;
         }
-        const int got[2] = {e->libc_ra, e->libc_rb};
-        libc_init_tally(e, got);                               // (what was enqueued was enough)
+        const int got[2] = {c[C_INIT_ROUNDS] >> 8, c[C_INIT_ROUNDS] & 0xFF};
+        libc_init_tally(e, got);                               // (what the two sweeps needed, as the loop control saw it)
         e->draws_after_init = e->draws + c[C_DRAWS_INIT];
     }
     e->iters += done;

@@ -28,8 +28,8 @@ enum { FLAG_EMPTYK = 0, FLAG_EMPTY_PROP = 1, FLAG_FAULT = 2, FLAG_MOVED = 3, FLA
 // C_FOLD sits next to C_STOP so that a sweep block reads both with one 8-byte scalar load: "the last sweep met
 // zero-density sites" (how the next sweeps tally them, see k_sweep); it survives a restart.
 enum { C_STOP = 0, C_FOLD = 1, C_ITERS = 10, C_COMMITS = 2, C_STATUS = 3, C_EMPTYK = 4, C_CONVERGED = 5, C_NEED_ROUNDS = 6,
-       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_DEEP = 12, C_DRAWS_INIT = 13, C_WORDS = 16 };
-// C_DRAWS_INIT (TIE_LIBC): of C_DRAWS, what the run's two initial sweeps drew
+       C_SWEEP_ROUNDS = 7, C_NZERO = 8, C_FIRSTZERO = 9, C_DRAWS = 11, C_DEEP = 12, C_DRAWS_INIT = 13, C_INIT_ROUNDS = 14, C_WORDS = 16 };
+// C_DRAWS_INIT (TIE_LIBC): of C_DRAWS, what the run's two initial sweeps drew; C_INIT_ROUNDS: the rounds they needed (blind << 8 | beta)
 // C_DEEP: the last iteration of the batch (1-based) whose sweep used more than two of its relaxation rounds
 
 struct CtrlArgs {

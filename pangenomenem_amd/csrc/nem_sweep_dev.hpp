@@ -53,6 +53,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
     for (int r = 0; r < kMaxRounds; r++) rf[r] = r < nr ? reinterpret_cast<const int4*>(a.round0)[r] : make_int4(1, 0, 0, 0);
     int4 bf = make_int4(0, 0, 0, 0);
     bool blind_ok = true;
+    int blind_needed = 1;
     if (a.is_init && a.blind != nullptr) {
         if (a.blind_rounds > 1) {
             // TIE_LIBC: the blind sweep's sites are coupled through the draw counter, it ran verified rounds like any
@@ -60,7 +61,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
             blind_ok = false;
             for (int q = 0; q < a.blind_rounds && !blind_ok; q++) {
                 const int4 f = reinterpret_cast<const int4*>(a.blind)[q];
-                if (f.x == 0) { bf = f; blind_ok = true; }
+                if (f.x == 0) { bf = f; blind_ok = true; blind_needed = q + 1; }
             }
         } else bf = *reinterpret_cast<const int4*>(a.blind);
     }
@@ -115,6 +116,7 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
                 a.draw_ctl[0] = draw0 + nt;
                 c[C_DRAWS] = draws + nt;
                 c[C_DRAWS_INIT] = nt;
+                c[C_INIT_ROUNDS] = (blind_needed << 8) | (last + 1);
             }
         }
         c[C_NZERO] = nzero; c[C_FIRSTZERO] = firstzero;
@@ -408,7 +410,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     // used -- behind the label store, which they might alias -- they would be one more memory latency at the tail
     int my_guess = 0, my_old = 0, my_new = 255;           // my_guess: the whole byte; my_old: the class
     if (NCEM && active) { my_guess = a.lab_guess[gi]; my_old = a.lab_old[gi] & kLabMask; }
-    if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; s_chg = 0; s_mov = 0; }
+    // (TIE_LIBC: the block's draw count in the guess, compared at the round's end -- asked for here, not there: a load at
+    //  the tail is a memory latency added to the block's run time)
+    int blk_cnt_guess = 0;
+    if (LIBC && threadIdx.x == 0 && a.tie_cnt_guess != nullptr) blk_cnt_guess = a.tie_cnt_guess[bx];
+    __shared__ int s_anydrew;                            // TIE_LIBC: a site of the block drew at some local step of this launch
+    if (threadIdx.x == 0) { s_nzero = 0; s_first = 0; s_chg = 0; s_mov = 0; s_anydrew = 0; }
     if (NCEM) s_lab[threadIdx.x] = (uint8_t)my_guess;
     int exp_len = 64;                                    // usable entries of s_exp
     if (NCEM && a.exp_tab != nullptr && (FUSED || a.exp_tab_len > 64)) {
@@ -416,7 +423,25 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         if (a.use_nei && !skip) for (int m = threadIdx.x; m < exp_len; m += BS) s_exp[m] = a.exp_tab[m];
     } else if (NCEM && a.use_nei && !skip && threadIdx.x < 64) s_exp[threadIdx.x] = exp((double)a.beta * (double)(float)threadIdx.x);
     int* rflags = a.flags;                               // this round's flag slot (a fused launch moves on slot by slot)
-    __syncthreads();
+    // TIE_LIBC: draws of the blocks below this one, as the guess has them -- summed once by the block's first wave (a
+    // lane that ties used to add the counts up itself: up to 78 loads in a row per tying lane, 2-3 us of a round on
+    // data that tie in every sweep, the initial sweeps of a random start)
+    __shared__ int s_lower;
+    if (LIBC && !skip && threadIdx.x < 64 && a.tie_cnt_guess != nullptr) {
+        int part = 0;
+        for (int b = threadIdx.x; b < bx; b += 64) part += a.tie_cnt_guess[b];
+        part = wave_sum_i32(part);
+        if (threadIdx.x == 0) {
+            if (a.rank_tot_in != nullptr)                // sharded: the ranks below, as the guess has them
+                for (int r = 0; r < a.rank_index; r++) part += *reinterpret_cast<const int*>(a.rank_tot_in + (size_t)r * a.slot_stride);
+            s_lower = part;
+        }
+    }
+    // TIE_LIBC: does any site of the block carry "drew" in the guess?  Blocks without ties (most blocks, most rounds) skip
+    // the per-step tally of who drew -- a ballot and a barrier per local step, and another pair at the round's end
+    bool blk_drew = false;
+    if (LIBC) blk_drew = __syncthreads_or((my_guess & kLabDrew) != 0) != 0;
+    else __syncthreads();
     NEM_SWEEP_STAMP(1);
 
     if (NCEM) {
@@ -461,21 +486,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         }
     }
     const bool long_row = ne - nb > 4;
-    // TIE_LIBC: draws of the blocks below this one, as the guess has them -- summed once by the block's first wave (a
-    // lane that ties used to add the counts up itself: up to 78 loads in a row per tying lane, 2-3 us of a round on
-    // data that tie in every sweep, the initial sweeps of a random start)
-    __shared__ int s_lower;
-    if (libc && !skip && threadIdx.x < 64 && a.tie_cnt_guess != nullptr) {
-        int part = 0;
-        for (int b = threadIdx.x; b < bx; b += 64) part += a.tie_cnt_guess[b];
-        part = wave_sum_i32(part);
-        if (threadIdx.x == 0) {
-            if (a.rank_tot_in != nullptr)                // sharded: the ranks below, as the guess has them
-                for (int r = 0; r < a.rank_index; r++) part += *reinterpret_cast<const int*>(a.rank_tot_in + (size_t)r * a.slot_stride);
-            s_lower = part;
-        }
-    }
-    int lower_draws = -1;                                // (read from s_lower behind the step's first barrier)
+    int lower_draws = -1;                                // (read from s_lower, written ahead of the barrier at the block's head)
     bool tab_short = false;                              // TIE_LIBC: a draw fell outside the table: the round is void
     int cur = my_guess;                                  // this site's byte in s_lab
     int seen[4] = {-1, -1, -1, -1};                      // labels the last evaluation used for the dyn neighbours
@@ -494,7 +505,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     for (int it = 0; it < kInnerCap; it++) {
         int below_in_block = 0;
         uint64_t drew_lt = 0;
-        if (libc) {                                      // who drew, per wave (block-uniform branch)
+        if (libc && blk_drew) {                          // who drew, per wave (block-uniform branch)
             const uint64_t bal = __ballot((s_lab[threadIdx.x] & kLabDrew) != 0);
             if ((threadIdx.x & 63) == 0) s_drew[threadIdx.x >> 6] = bal;
             __syncthreads();
@@ -582,7 +593,12 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
         const bool moved_now = nxt != cur;
         cur = nxt;
         s_lab[threadIdx.x] = (uint8_t)cur;
-        if (!__syncthreads_or(moved_now)) break;
+        // (__syncthreads_or hands back a truth value, not the OR of the arguments: "somebody drew" travels through LDS,
+        //  written ahead of the barrier, and sticks -- a block that has met a tie keeps the tally for the rest of the launch)
+        if (libc && !blk_drew && (cur & kLabDrew) != 0) s_anydrew = 1;
+        const int any_moved = __syncthreads_or(moved_now);
+        if (libc && !blk_drew) blk_drew = s_anydrew != 0;
+        if (!any_moved) break;
     }
     if (active && !skip) {
         changed = (cur != my_guess) || tab_short;         // (a void round never passes for the fixed point)
@@ -633,13 +649,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const int bx, con
     }
     if (libc && !skip) {
         // the block's draws of this round, next to the labels they belong to: a guess is (labels, counts)
-        const uint64_t bal = __ballot(active && (cur & kLabDrew) != 0);
-        if ((threadIdx.x & 63) == 0) s_drew[threadIdx.x >> 6] = bal;
-        __syncthreads();
+        if (blk_drew) {
+            const uint64_t bal = __ballot(active && (cur & kLabDrew) != 0);
+            if ((threadIdx.x & 63) == 0) s_drew[threadIdx.x >> 6] = bal;
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
             int cnt = 0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); w++) cnt += (int)__popcll(s_drew[w]);
-            if (cnt != a.tie_cnt_guess[bx]) changed = true;
+            if (blk_drew) for (int w = 0; w < (int)(blockDim.x >> 6); w++) cnt += (int)__popcll(s_drew[w]);
+            if (cnt != blk_cnt_guess) changed = true;
             a.tie_cnt_out[bx] = cnt;
             if (cnt > 0) atomicAdd(&rflags[FLAG_NTIES], cnt);
         }
