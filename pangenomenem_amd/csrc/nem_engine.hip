@@ -3672,6 +3672,9 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
 
     e->rs_rounds = e->rs_lockstep = e->rs_alone = e->rs_redone = e->rs_two_waits = 0;
+    // (random starts tie by the hundreds in their initial sweeps: the draw window is sized for that from the first start on,
+    //  instead of growing -- and sliding away from the earlier starts' positions -- when the first heavy start is met)
+    if (e->libc()) e->tie_heavy = true;
     int nbsucc = 0, best = -1, last_status = NEMGPU_OK;
     float best_crit[6] = {0, 0, 0, 0, 0, 0};
     nemgpu_result best_res{};
@@ -3740,6 +3743,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
         std::vector<int> after_init((size_t)M, 0);
         if (e->libc()) {
             // ---- phase A: the starts' initial partitions, one after the other in stream order
+            const int pos_round_first = e->draws;
             using clk = std::chrono::steady_clock;
             const auto ta = clk::now();
             double seg[5] = {0, 0, 0, 0, 0};
@@ -3788,9 +3792,11 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
                 c->draws_after_init = after_init[j] = c->draws;
                 e->draws = c->draws; e->tie_heavy = e->tie_heavy || c->tie_heavy;
             }
-            // (the parent's window may have slid or grown since a twin borrowed it: every twin gets it as it is now; one
-            //  whose position it does not cover builds its own when it first needs a draw)
-            if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;
+            // (the parent's window may have slid or grown since a twin borrowed it: it is made to reach from the round's
+            //  first start to what the last one may still draw, and every twin gets it as it is now -- a twin whose
+            //  position it did not cover would build a table of its own at its first batch, generator run from the seed
+            //  and 2 MB up: 0.3 ms per twin, 14.7 ms of a cold engine's first round)
+            if ((r = ensure_draw_window(e, pos_round_first, (long)(e->draws - pos_round_first) + draw_need(e)))) return r;
             for (int j = 0; j < M; j++) { lend_window(E[j]); E[j]->tie_heavy = e->tie_heavy; }
             if (prof) {
                 HIPCHK(hipStreamSynchronize(e->stream));
