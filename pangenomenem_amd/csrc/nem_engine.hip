@@ -1900,6 +1900,128 @@ int iterate_many(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L)
     return NEMGPU_OK;
 }
 
+// ---- RandNemAlgo's per-iteration log with the starts in lock step ------------------------------------------------
+// What one start writes to <Fname>.log (nem_alg.c:1662-1669, 2361, 2398): line 0 for its initial partition, then a line
+// per iteration -- the six criteria of the partition the E-step started from and of the one it left, both on the new
+// densities, and the iteration's parameters.  The criteria are i-ordered float sums (four lone blocks per partition,
+// 75-100 us at configs[1] size): one start after the other they are most of a logged iteration; with the starts in lock
+// step the blocks of all starts run side by side.  The lines are kept per start and handed to the caller's writer in the
+// reference's order afterwards.
+struct StartLogLine {
+    int kind = NEMGPU_LOG_LINE, iter = 0, emptyk = 0;
+    float cb[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> prop, center, disp, nb;
+    bool has_nb = false;
+};
+struct StartLog { std::vector<StartLogLine> lines; };
+
+int criteria(nemgpu_engine* e, float crit6[6], int buf);
+
+// E: the starts' engines behind their initial partitions (cur = 2; blind partition in buffer 1); L: their cursors with
+// first = false; host_par: the starts' own parameters, `par` floats apart (prop | center | disp)
+static int iterate_many_logged(std::vector<nemgpu_engine*>& E, std::vector<LoopCursor>& L, const float* host_par, size_t par,
+                               std::vector<StartLog>& logs)
+{
+    int r;
+    const int B = (int)E.size();
+    nemgpu_engine* lead = E[0];
+    const int k = lead->k, d = lead->d;
+    const size_t kd = (size_t)k * d, W = 12 + lead->par_words;
+    std::vector<Recorder> recs((size_t)B);
+    std::vector<int> members((size_t)B), left((size_t)B), it_no((size_t)B, 0), oldbuf((size_t)B, 0), newbuf((size_t)B, 0);
+    for (int i = 0; i < B; i++) { members[i] = i; left[i] = L[i].remaining; }
+    char* st_dev = nullptr; char* st_host = nullptr; size_t dev_size = 0, host_size = 0;
+    HIPCHK(pool_get(lead->device, false, (size_t)B * W * sizeof(float), &st_dev, &dev_size));
+    if (pool_get(lead->device, true, (size_t)B * W * sizeof(float), &st_host, &host_size) != hipSuccess) {
+        pool_put(lead->device, false, st_dev, dev_size);
+        set_error("no pinned memory for the starts' log lines"); return NEMGPU_E_DEVICE;
+    }
+    struct Back { int dev; char* a; size_t as; char* b; size_t bs; hipStream_t s; ~Back() { (void)hipStreamSynchronize(s); pool_put(dev, false, a, as); pool_put(dev, true, b, bs); } }
+        back{lead->device, st_dev, dev_size, st_host, host_size, lead->stream};
+    auto slot_dev = [&](int m) { return reinterpret_cast<int*>(st_dev) + (size_t)m * W; };
+    auto slot_host = [&](int m) { return reinterpret_cast<const float*>(st_host) + (size_t)m * W; };
+    auto fetch = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(st_host, st_dev, (size_t)B * W * sizeof(float), hipMemcpyDeviceToHost, lead->stream));
+        HIPCHK(hipStreamSynchronize(lead->stream));
+        return NEMGPU_OK;
+    };
+    auto two_criteria = [&](int m, int before, int after) -> int {   // (recorded: zipped over the members)
+        nemgpu_engine* c = E[m];
+        int rr = criteria_enqueue(c, before);
+        if (rr == NEMGPU_OK) launch_copy_words(reinterpret_cast<const int*>(c->crit6_dev), slot_dev(m), 6, lead->stream);
+        if (rr == NEMGPU_OK) rr = criteria_enqueue(c, after);
+        if (rr == NEMGPU_OK) launch_copy_words(reinterpret_cast<const int*>(c->crit6_dev), slot_dev(m) + 6, 6, lead->stream);
+        return rr;
+    };
+    // ---- line 0: the initial partition (before: the blind sweep's, buffer 1; after: the beta sweep's, buffer 2)
+    if ((r = lockstep(E, members, recs, [&](int m) { return two_criteria(m, 1, 2); }, false))) return r;
+    if ((r = fetch())) return r;
+    for (int m = 0; m < B; m++) {
+        StartLogLine ln;
+        ln.iter = 0;
+        memcpy(ln.cb, slot_host(m), sizeof ln.cb); memcpy(ln.ca, slot_host(m) + 6, sizeof ln.ca);
+        const float* p0 = host_par + (size_t)m * par;
+        ln.prop.assign(p0, p0 + k); ln.center.assign(p0 + k, p0 + k + kd); ln.disp.assign(p0 + k + kd, p0 + k + 2 * kd);
+        logs[(size_t)m].lines.push_back(std::move(ln));
+    }
+    // ---- one iteration per step for every start that still runs
+    for (;;) {
+        members.clear();
+        for (int i = 0; i < B; i++) if (left[i] > 0 && !E[i]->converged && E[i]->status == NEMGPU_OK) members.push_back(i);
+        if (members.empty()) break;
+        r = lockstep(E, members, recs, [&](int m) {
+            nemgpu_engine* c = E[m];
+            L[m].remaining = 1;
+            int rr = batch_plan(c, L[m]);
+            oldbuf[m] = L[m].base; newbuf[m] = (L[m].base + 1) % 3;
+            if (rr == NEMGPU_OK) rr = batch_enqueue(c, L[m], false);
+            if (rr == NEMGPU_OK) rr = two_criteria(m, oldbuf[m], newbuf[m]);     // (speculated: void if the sweep was not through)
+            if (rr == NEMGPU_OK) launch_copy_words(reinterpret_cast<const int*>(c->prop), slot_dev(m) + 12, (int)c->par_words, lead->stream);
+            return rr;
+        }, true);
+        if (r) return r;
+        if ((r = fetch())) return r;
+        for (int m : members) {
+            nemgpu_engine* c = E[m];
+            const bool clean = c->h_ctrl()[C_NEED_ROUNDS] == 0 && c->h_ctrl()[C_STATUS] != NEMGPU_W_EMPTYCLASS;
+            c->n_plain++;
+            if ((r = batch_finish(c, L[m]))) return r;
+            left[m] -= 1; it_no[m] += 1;
+            StartLogLine ln;
+            ln.iter = it_no[m];
+            if (c->status == NEMGPU_W_EMPTYCLASS) {
+                // EstimSizes (nem_mod.c:1275-1317) ran before the empty class was found: i-ordered float sums per class
+                std::vector<float> part((size_t)c->n * k);
+                if ((r = nemgpu_get_partition(c, part.data()))) return r;
+                ln.kind = NEMGPU_LOG_EMPTY; ln.emptyk = c->emptyk; ln.nb.assign((size_t)k, 0.0f); ln.has_nb = true;
+                for (int h = 0; h < k; h++) {
+                    float acc = 0.0f;
+                    for (int i = 0; i < c->n; i++) acc += part[(size_t)i * k + h];
+                    ln.nb[(size_t)h] = acc;
+                }
+                logs[(size_t)m].lines.push_back(std::move(ln));
+                continue;
+            }
+            ln.prop.resize((size_t)k); ln.center.resize(kd); ln.disp.resize(kd); ln.nb.resize((size_t)k); ln.has_nb = true;
+            if (clean) {
+                const float* f = slot_host(m);
+                memcpy(ln.cb, f, sizeof ln.cb); memcpy(ln.ca, f + 6, sizeof ln.ca);
+                memcpy(ln.prop.data(), f + 12, sizeof(float) * k);
+                memcpy(ln.center.data(), f + 12 + c->par_o_center, sizeof(float) * kd);
+                memcpy(ln.disp.data(), f + 12 + c->par_o_disp, sizeof(float) * kd);
+                memcpy(ln.nb.data(), f + 12 + c->par_o_nb, sizeof(float) * k);
+            } else {
+                // (the sweep was finished from the host: the plain sequence of calls, this start alone)
+                if ((r = criteria(c, ln.cb, (c->cur + 2) % 3)) || (r = criteria(c, ln.ca, -1))) return r;
+                if ((r = nemgpu_get_results(c, ln.prop.data(), ln.center.data(), ln.disp.data(), ln.nb.data(), nullptr))) return r;
+            }
+            logs[(size_t)m].lines.push_back(std::move(ln));
+        }
+    }
+    for (int i = 0; i < B; i++) L[i].remaining = 0;
+    return NEMGPU_OK;
+}
+
 // several whole runs (nemgpu_run) in lock step; every engine complete (matrix, graph, parameters, configuration), all on
 // one device.  They are run on E[0]'s stream for the duration.
 // A group's results in one block (nemgpu_solve_many): every member's partition and parameter block (the layout of
@@ -2872,7 +2994,8 @@ int nemgpu_run_many(nemgpu_engine** engines, int count, nemgpu_result* results)
 // with every family in class 0; every start draws its centres from the data (MakeRandomPara, :1381-1473), runs the
 // INIT_PARAM_FILE pipeline on them and is ranked by criterion M (DEFAULT_CRIT, nem_typ.h:80); the best partition is
 // restored and EstimPara run on it (:1703-1713).
-static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
+constexpr int kStartsNotInLockStep = -7001;   // run_random_lockstep, logged: a start drew behind its initial sweeps -- nothing was handed to the writer, the caller runs the starts one after the other
+static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start, nemgpu_log_fn fn = nullptr, void* user = nullptr);
 
 // Many whole problems, from host arrays to host arrays, in one call: `workers` threads of the library build the
 // engines (bit packing, uploads out of pinned blocks -- nothing waits for the device), the calling thread runs every
@@ -3404,7 +3527,17 @@ static int run_random_impl(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu
         // the starts are independent EM runs on ONE matrix: by default they run in lock step, every launch serving all
         // of them (NEM_MI355X_BATCH_STARTS=0: one after the other on this engine)
         const char* g = getenv("NEM_MI355X_BATCH_STARTS");
-        if (!fn && n_starts > 1 && !(g && g[0] == '0') && !crit_test(e)) return run_random_lockstep(e, n_starts, seed, res, best_start);
+        const bool lock_ok = n_starts > 1 && !(g && g[0] == '0') && !crit_test(e);
+        if (!fn && lock_ok) return run_random_lockstep(e, n_starts, seed, res, best_start);
+        // With the per-iteration log (fn): one iteration per lock-step step, the criteria of all starts side by side, the
+        // lines handed over start by start afterwards (NEM_MI355X_BATCH_STARTS_LOGGED=0: one start after the other).  One
+        // round only -- under TIE_LIBC a start that draws behind its initial sweeps sends the call to the sequential form
+        // below before a line has been handed over.
+        const char* gl = getenv("NEM_MI355X_BATCH_STARTS_LOGGED");
+        if (fn && lock_ok && n_starts <= 64 && !(gl && gl[0] == '0')) {
+            const int rr = run_random_lockstep(e, n_starts, seed, res, best_start, fn, user);
+            if (rr != kStartsNotInLockStep) return rr;
+        }
     }
     int r;
     const int n = e->n, d = e->d, k = e->k, wf = e->wf;
@@ -3622,7 +3755,7 @@ static int ensure_clones(nemgpu_engine* e, int count)
 // own initial partition, on the assumption that none of them draws.  The assumption is checked: the first start whose
 // iterations did draw is still right (its draws came from where they should) and everything behind it is redone from
 // the position it left the stream at.
-static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start)
+static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start, nemgpu_log_fn fn, void* user)
 {
     int r;
     const int n = e->n, d = e->d, k = e->k, wf = e->wf;
@@ -3666,7 +3799,7 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
     // of clean starts behind it (4, 20, the rest), and after two voided rounds in a row every remaining start runs alone:
     // data whose every start draws in its iterations cost what the sequential form costs.
     const char* fa = getenv("NEM_MI355X_STARTS_FIRST_ALONE");      // (0: bet from the first start on -- tests of the losing path)
-    int width = (e->libc() && !(fa && fa[0] == '0')) ? 1 : group;
+    int width = (e->libc() && !(fa && fa[0] == '0') && fn == nullptr) ? 1 : group;   // (a logged run bets from the first start on: a lost bet sends the whole call to the sequential form)
     int voided_in_a_row = 0, clean_run = 0; bool alone_for_good = false;
     if ((r = ensure_clones(e, group))) return r;
     for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; c->round_batch = e->round_batch; c->ff_mode = e->ff_mode; }
@@ -3815,7 +3948,15 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
             for (int j = 0; j < M; j++) if ((r = loop_begin(E[j], L[j], e->cfg.it_max, true))) return r;
         }
         // ---- the EM iterations in lock step (TIE_LIBC: phase B)
-        if ((r = iterate_many(E, L))) return r;
+        std::vector<StartLog> logs((size_t)(fn ? M : 0));
+        if (fn) {
+            if (!e->libc()) {                                       // (the initial partitions first: a batch of no iterations)
+                for (int j = 0; j < M; j++) L[j].remaining = 0;
+                if ((r = iterate_many(E, L))) return r;
+                for (int j = 0; j < M; j++) L[j].remaining = e->cfg.it_max;
+            }
+            if ((r = iterate_many_logged(E, L, host_par.data(), par, logs))) return r;
+        } else if ((r = iterate_many(E, L))) return r;
         for (int j = 0; j < M; j++)
             if (E[j]->iters == 0) { if ((r = do_mstep(E[j])) || (r = do_tables(E[j])) || (r = do_density(E[j]))) return r; }
         std::vector<float> crits((size_t)M * 6);
@@ -3848,6 +3989,23 @@ static int run_random_lockstep(nemgpu_engine* e, int n_starts, uint32_t seed, ne
         int valid = M;
         if (e->libc())
             for (int j = 0; j < M; j++) if (E[j]->draws != after_init[j]) { valid = j + 1; break; }
+        if (fn && (valid < M || (e->libc() && E[M - 1]->draws != after_init[M - 1]))) return kStartsNotInLockStep;
+        if (fn) {
+            // the round's lines to the caller's writer, start by start in the reference's order
+            for (int j = 0; j < M; j++) {
+                nemgpu_log_event ev{};
+                ev.kind = NEMGPU_LOG_START; ev.start = next + j;
+                fn(&ev, user);
+                for (const StartLogLine& ln : logs[(size_t)j].lines) {
+                    ev = nemgpu_log_event{};
+                    ev.kind = ln.kind; ev.start = next + j; ev.iter = ln.iter; ev.emptyk = ln.emptyk;
+                    ev.crit_before = ln.cb; ev.crit_after = ln.ca;
+                    ev.prop = ln.prop.data(); ev.center = ln.center.data(); ev.disp = ln.disp.data();
+                    ev.nbobs_k = ln.has_nb ? ln.nb.data() : nullptr;
+                    fn(&ev, user);
+                }
+            }
+        }
         for (int j = 0; j < valid; j++) {
             nemgpu_engine* c = E[j];
             const float* crit = crits.data() + (size_t)j * 6;

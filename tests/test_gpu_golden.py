@@ -237,10 +237,47 @@ def test_dropin_random_start_log_equals_the_reference_fixture(gpu_lib, tmp_path,
     assert got.count("Random initialization") == 50 and got.count(" empty at iteration ") == meta["starts_with_empty_class"]
     assert_same_nem_log(got, want)
     assert "Best start was %d " % (meta["best_start"] + 1) in open(base + ".stderr").read()
-    # NEM_MI355X_LOG=0: the lock-step run and a header-only log; the same partition
     uf = open(base + ".uf").read()
+    # (that was the logged run with the starts in lock step; one start after the other: the same text, the same partition)
+    monkeypatch.setenv("NEM_MI355X_BATCH_STARTS_LOGGED", "0")
+    assert nem_module.nem(base.encode(), k, meta["algo"].encode(), meta["beta"], b"clas", 1e-8, b"fuzzy", 100, True, b"bern",
+                          b"pk", meta["disper"].encode(), 1) == 0
+    assert_same_nem_log(open(base + ".log").read(), want)
+    assert open(base + ".log").read().split("\n", 1)[1] == got.split("\n", 1)[1]      # (but the date line)
+    assert open(base + ".uf").read() == uf
+    monkeypatch.delenv("NEM_MI355X_BATCH_STARTS_LOGGED")
+    # NEM_MI355X_LOG=0: the lock-step run and a header-only log; the same partition
     monkeypatch.setenv("NEM_MI355X_LOG", "0")
     assert nem_module.nem(base.encode(), k, meta["algo"].encode(), meta["beta"], b"clas", 1e-8, b"fuzzy", 100, True, b"bern",
                           b"pk", meta["disper"].encode(), 1) == 0
     assert open(base + ".uf").read() == uf
     assert "Random initialization" not in open(base + ".log").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,seed", [(1069, 2), (1100, 1), (12, 5)])
+def test_dropin_random_start_log_in_lock_step_and_one_after_the_other(gpu_lib, tmp_path, monkeypatch, d, seed):
+    """The per-iteration log of an INIT_RANDOM run with the 50 starts in lock step (one EM iteration per step for all of
+    them, their criteria side by side, the lines handed to the writer start by start afterwards) against the same call
+    with the starts one after the other: the same text but the date.  d = 1 069 / 1 100: starts draw tie-breaks behind
+    their initial sweeps -- the lock-step attempt notices, hands nothing over and the call runs sequentially (the log
+    must not carry a line twice); d = 12: hundreds of ties per start, all in the initial sweeps -- lock step throughout."""
+    from pangenomenem_amd import nemfiles, synth
+    import nem as nem_module
+    n, k = (300, 3) if d > 100 else (2000, 3)
+    x, _ = synth.bernoulli_pa_matrix(n, d, seed, p=(0.5, 0.5, 0.5) if d > 100 else (0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, seed)
+    prop, center, disp = synth.default_init(d)
+    base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
+    os.remove(base + ".m")
+    monkeypatch.setenv("NEM_MI355X_SEED", str(seed))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NEM_MI355X_BATCH_STARTS_LOGGED", mode)
+        rc = nem_module.nem(base.encode(), k, b"ncem", 0.5, b"clas", 1e-8, b"fuzzy", 12, True, b"bern", b"pk", b"sk_", 1)
+        out[mode] = (rc, open(base + ".log").read().split("\n", 1)[1], open(base + ".uf").read() if rc == 0 else "",
+                     open(base + ".mf").read() if rc == 0 else "")
+    assert out["1"][0] == out["0"][0]
+    assert out["1"][1].count("Random initialization") == 50
+    assert out["1"][1] == out["0"][1]
+    assert out["1"][2:] == out["0"][2:]
