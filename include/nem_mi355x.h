@@ -241,9 +241,11 @@ int nemgpu_solve_chunks(nemgpu_master* m, nemgpu_chunk* chunks, int count, int k
    best_start: 0-based index of the chosen start, -1 if every start ended with an empty class. */
 int nemgpu_run_random(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start);
 /* The same run with what the reference writes to <Fname>.log for INIT_RANDOM (nem_alg.c:1632-1636, 1662-1669: "Random
-   initialization %d :", the start's line 0, then NemAlgo's line per iteration): the starts run one after the other and
-   `fn` is called on the calling thread for every event, in the reference's order.  The pointers of an event are host
-   arrays that are valid during the call only. */
+   initialization %d :", the start's line 0, then NemAlgo's line per iteration): `fn` is called on the calling thread for
+   every event, in the reference's order -- start by start, though up to 64 starts run in lock step underneath (their
+   lines are kept and handed over when the round is through; more starts, the `crit` convergence test or
+   NEM_MI355X_BATCH_STARTS_LOGGED=0: one start after the other, events as they happen).  The pointers of an event are
+   host arrays that are valid during the call only. */
 typedef struct nemgpu_log_event {
     int kind;                     /* NEMGPU_LOG_START | _LINE | _EMPTY */
     int start;                    /* 0-based start */
