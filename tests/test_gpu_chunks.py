@@ -59,6 +59,38 @@ def test_a_device_formed_chunk_against_the_oracle(gpu_lib, oracle):
     assert np.array_equal(got["center"], want["center"]) and maxdiff(got["disp"], want["disp"]) <= 1e-6
 
 
+@pytest.mark.parametrize("dc,beta", [(6, 0.5), (9, 1.0), (40, 0.5)])
+def test_device_formed_chunks_under_the_reference_tie_rule(gpu_lib, oracle, dc, beta):
+    """The drop-in's own tie rule (TIE_LIBC, every problem its own srandom(seed) stream) through nemgpu_solve_chunks.  Two
+    classes start with the same centre, dispersion and proportion: they tie wherever they win -- about 1 800 draws per
+    sample, most in the two initial sweeps (which ride in the first lock-step batch, verified on the device, and are
+    done again from the host when they need more rounds than were enqueued).  Each sample against the oracle on the
+    host-formed problem, and the lock-step groups against one sample at a time."""
+    from pangenomenem_amd.chunks import Master, form_chunk_host
+    n, d = 3000, 120
+    x, (ptr, idx), eb = synth.master_pangenome(n, d, 21)
+    subs = samples(d, dc, 7, 8)
+    cfg = dict(algo="ncem", beta=beta, disper="sk_", it_max=25, tie="libc", seed=6)
+    start = dict(center_k=(1.0, 1.0, 0.0), disp_k=(0.1, 0.1, 0.1))
+    m = Master(x, ptr, idx, eb)
+    got = m.solve_chunks(subs, workers=2, group=4, **start, **cfg)
+    alone = [m.solve_chunks([s], workers=1, group=1, **start, **cfg)[0] for s in subs]
+    m.close()
+    p0 = np.float32(0.33333)
+    prop = np.array([p0, p0, np.float32(np.float32(np.float32(1.0) - p0) - p0)], np.float32)
+    center = np.stack([np.ones(dc), np.ones(dc), np.zeros(dc)]).astype(np.float32)
+    disp = np.full((3, dc), 0.1, np.float32)
+    for g, a, sub in zip(got, alone, subs):
+        xc, nei, fam = form_chunk_host(x, ptr, idx, eb, sub)
+        want = oracle.run(xc, nei, 3, prop, center, disp, **cfg)
+        assert np.array_equal(g["families"], fam)
+        assert g["status"] == want["status"] and g["iters"] == want["iters"] and g["converged"] == want["converged"]
+        assert np.array_equal(g["labels"], want["c"].argmax(1))
+        assert np.array_equal(g["center"], want["center"]) and maxdiff(g["disp"], want["disp"]) <= 1e-6 and maxdiff(g["prop"], want["prop"]) <= 1e-6
+        for key in ("labels", "prop", "center", "disp", "nbobs_k", "crit"):
+            assert np.array_equal(g[key], a[key], equal_nan=True), key
+
+
 def test_bad_samples_are_refused(gpu_lib):
     from pangenomenem_amd.chunks import Master
     from pangenomenem_amd.engine import NemGpuError
