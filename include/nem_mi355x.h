@@ -262,6 +262,14 @@ typedef struct nemgpu_log_event {
 } nemgpu_log_event;
 enum { NEMGPU_LOG_START = 0, NEMGPU_LOG_LINE = 1, NEMGPU_LOG_EMPTY = 2 };
 typedef void (*nemgpu_log_fn)(const nemgpu_log_event* ev, void* user);
+/* nemgpu_run (INIT_PARAM_FILE: ComputePartitionFromPara + NemAlgo, nem_alg.c:1160, 1746-1879) with what the reference writes
+   to <Fname>.log when dolog is set (WriteLogCrit, nem_alg.c:2361, 2398): `fn` gets a _LINE event for the initial partition
+   (iter 0) and one per EM iteration, or _EMPTY for the iteration that emptied a class; `start` is 0.  The iterations run
+   pipelined, seven per wait, and the criteria of a batch's iterations are evaluated together afterwards (NCEM with the
+   `clas` / `none` tests; otherwise, or with NEM_MI355X_LOG_BATCHED=0, one iteration per wait as nemgpu_iterate_logged).
+   res->crit: the criteria of the final partition when the last line carried them, else crit[0] = NaN (the caller asks
+   nemgpu_criteria, after nemgpu_mstep + nemgpu_density if no iteration ran, nem_alg.c:1845-1852). */
+int nemgpu_run_logged(nemgpu_engine* e, nemgpu_result* res, nemgpu_log_fn fn, void* user);
 int nemgpu_run_random_logged(nemgpu_engine* e, int n_starts, uint32_t seed, nemgpu_result* res, int* best_start,
                              nemgpu_log_fn fn, void* user);
 /* Test hook: the first `count` values random() returns after srandom(seed), from the restated generator. */

@@ -186,69 +186,6 @@ void log_classes(std::string& line, const LogParams& P, float beta, int k, int d
     line += "\n";
 }
 
-// The INIT_PARAM_FILE run with the reference's log: one EM iteration per engine call, two criteria evaluations
-// per iteration (the partition the sweep started from is still in its buffer afterwards).
-int run_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res)
-{
-    const float mult = log_mult(n);
-    fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
-    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)mult);
-    fprintf(fl, "Initializing parameters from given value :\n");
-    fprintf(fl, "%4d ", 0);
-    int rc;
-    float cb[6], ca[6];
-    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
-    nemgpu_result r1{};
-    // the start (reset, the two initial sweeps), both criteria evaluations and the parameters: one submission, one wait
-    if ((rc = nemgpu_iterate_logged(e, 1, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data()))) return rc;
-    log_crit(fl, cb, mult); log_crit(fl, ca, mult);
-    log_classes(fl, P, cfg.beta, k, d, false);
-    fprintf(fl, "\n");                                                     // Needinit, :1985-1986
-    log_header(fl, k, d);
-    double loop_s = 0.0;
-    // the line of an iteration (9 000 numbers at configs[1]) is put together by a helper thread while the device runs
-    // the next iteration; the lines reach the file in order
-    bool last_logged = false;                                                // ca holds the criteria of the final partition
-    std::future<std::string> pending;
-    auto flush_line = [&]() { if (pending.valid()) { const std::string t = pending.get(); fwrite(t.data(), 1, t.size(), fl); } };
-    for (int iter = 1; iter <= cfg.it_max && !r1.converged && r1.status == NEMGPU_OK; iter++) {
-        // the iteration, both criteria evaluations and the parameters: one submission, one wait
-        rc = nemgpu_iterate_logged(e, 0, &r1, cb, ca, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data());
-        flush_line();
-        if (rc) return rc;
-        loop_s += r1.loop_seconds;
-        fprintf(fl, "%4d ", iter);
-        if (r1.status == NEMGPU_W_EMPTYCLASS) {                             // :1835-1837
-            fprintf(fl, " Class %d empty at iteration %d\n", r1.emptyk, iter);
-            last_logged = false;
-            break;
-        }
-        last_logged = true;
-        struct Line { float cb[6], ca[6]; LogParams P; };
-        auto L = std::make_shared<Line>();
-        memcpy(L->cb, cb, sizeof cb); memcpy(L->ca, ca, sizeof ca); L->P = P;
-        const float beta = cfg.beta; const bool sizes = !cfg.param_fix;
-        pending = std::async(std::launch::async, [L, mult, beta, k, d, sizes]() {
-            std::string t;
-            log_crit(t, L->cb, mult); log_crit(t, L->ca, mult);
-            log_classes(t, L->P, beta, k, d, sizes);
-            return t;
-        });
-    }
-    flush_line();
-    *res = r1;
-    res->loop_seconds = loop_s;
-    if (r1.iters == 0) {                                                    // :1845-1851
-        int ek = 0;
-        rc = nemgpu_mstep(e, &ek);
-        if (rc != NEMGPU_OK && rc != NEMGPU_W_EMPTYCLASS) return rc;
-        if ((rc = nemgpu_density(e))) return rc;
-    }
-    // (the last logged iteration's second criteria evaluation was of the final partition, on the final densities)
-    if (last_logged && r1.iters > 0) { memcpy(res->crit, ca, sizeof ca); return NEMGPU_OK; }
-    return nemgpu_criteria(e, res->crit);
-}
-
 // The INIT_RANDOM run with the reference's log (RandNemAlgo, nem_alg.c:1632-1636, 1662-1669, 1730-1732): per start
 // "Random initialization %d :", line 0 (the start's own parameters; NbObs_KD is whatever the run so far left there --
 // NaN from InitPara, :1270-1276, before the first start, then the sizes of the last EstimPara, which nothing resets),
@@ -371,6 +308,61 @@ void random_log_event(const nemgpu_log_event* ev, void* user)
     j.blank_after = ev->iter == 0;                                           // Needinit, :1985-1986
     L.w->push(std::move(j));
     if (ev->iter == 0) { LogJob h; h.kind = LogJob::HEADER; L.w->push(std::move(h)); }   // NemAlgo's header, :1783
+}
+
+// The INIT_PARAM_FILE run with the reference's log through nemgpu_run_logged: the iterations pipelined, the criteria of a
+// batch's iterations evaluated together, the lines formatted by the writer's threads.
+struct RunLog { LogWriter* w; int k, d; bool sizes; };
+
+void run_log_event(const nemgpu_log_event* ev, void* user)
+{
+    RunLog& L = *static_cast<RunLog*>(user);
+    char t[96];
+    LogJob j;
+    if (ev->kind == NEMGPU_LOG_EMPTY) {
+        snprintf(t, sizeof t, "%4d  Class %d empty at iteration %d\n", ev->iter, ev->emptyk, ev->iter);     // :1798, :1835-1837
+        j.text = t;
+        L.w->push(std::move(j));
+        return;
+    }
+    const size_t kd = (size_t)L.k * L.d;
+    j.kind = LogJob::LINE;
+    // NbObs_KD: zero until the first EstimPara (calloc, nem_exe.c:320), then N_K for every organism (no missing data)
+    const bool sizes = ev->iter > 0 && L.sizes && ev->nbobs_k != nullptr;
+    j.P = LogParams{std::vector<float>(ev->prop, ev->prop + L.k), std::vector<float>(ev->center, ev->center + kd),
+                    std::vector<float>(ev->disp, ev->disp + kd),
+                    sizes ? std::vector<float>(ev->nbobs_k, ev->nbobs_k + L.k) : std::vector<float>((size_t)L.k, 0.0f)};
+    memcpy(j.cb, ev->crit_before, sizeof j.cb); memcpy(j.ca, ev->crit_after, sizeof j.ca);
+    snprintf(t, sizeof t, "%4d ", ev->iter);
+    j.text = t;
+    j.blank_after = ev->iter == 0;                                           // Needinit, :1985-1986
+    L.w->push(std::move(j));
+    if (ev->iter == 0) { LogJob h; h.kind = LogJob::HEADER; L.w->push(std::move(h)); }   // NemAlgo's header, :1783
+}
+
+int run_logged_pipelined(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res)
+{
+    const float mult = log_mult(n);
+    fprintf(fl, "NEM log file  -  %s\n", date_line().c_str());
+    fprintf(fl, "  Criteria are multiplied by %f\n\n", (double)mult);
+    fprintf(fl, "Initializing parameters from given value :\n");
+    fflush(fl);
+    int rc;
+    {
+        LogWriter w(fl, mult, cfg.beta, k, d, 2);
+        RunLog L{&w, k, d, !cfg.param_fix};
+        rc = nemgpu_run_logged(e, res, run_log_event, &L);
+        w.finish();
+    }
+    if (rc) return rc;
+    if (res->iters == 0) {                                                  // :1845-1851
+        int ek = 0;
+        rc = nemgpu_mstep(e, &ek);
+        if (rc != NEMGPU_OK && rc != NEMGPU_W_EMPTYCLASS) return rc;
+        if ((rc = nemgpu_density(e))) return rc;
+    }
+    if (std::isnan(res->crit[0])) return nemgpu_criteria(e, res->crit);
+    return NEMGPU_OK;
 }
 
 int run_random_logged(nemgpu_engine* e, const nemgpu_config& cfg, int n, int d, int k, FILE* fl, nemgpu_result* res, int* best)
@@ -575,7 +567,7 @@ extern "C" int nem(const char* Fname, const int nk, const char* algo, const floa
             // trip per iteration); NEM_MI355X_LOG=0 keeps the pipelined run and writes a header-only log
             const char* lenv = getenv("NEM_MI355X_LOG");
             FILE* fl = (dolog && !(lenv && lenv[0] == '0')) ? fopen((base + ".log").c_str(), "w") : nullptr;
-            if (fl) { rc = run_logged(e, cfg, in.n, in.d, nk, fl, &res); fclose(fl); full_log = true; }
+            if (fl) { rc = run_logged_pipelined(e, cfg, in.n, in.d, nk, fl, &res); fclose(fl); full_log = true; }
             else rc = nemgpu_run(e, &res);
         }
     }

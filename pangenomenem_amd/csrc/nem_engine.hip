@@ -19,6 +19,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <mutex>
@@ -1444,7 +1445,8 @@ int batch_plan(nemgpu_engine* e, LoopCursor& lc)
 }
 
 // the batch's launches (issued, captured or recorded by the caller's choice), ending with the copy of the control block
-int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
+// after_iter (optional): called behind the launches of every iteration of the batch (the logged run's snapshots)
+int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy, const std::function<int(int)>* after_iter = nullptr)
 {
     int r = NEMGPU_OK;
     e->ctrl_pending = false;                               // (a batch never inherits a deferred loop control)
@@ -1455,8 +1457,10 @@ int batch_enqueue(nemgpu_engine* e, LoopCursor& lc, bool with_copy)
     }
     e->stop_ptr = e->ctrl() + C_STOP;
     if (lc.batch_first && herr == hipSuccess) r = enqueue_init(e, lc.g > 0);
-    for (int j = 0; j < lc.g && r == NEMGPU_OK && herr == hipSuccess; j++)
-        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g, e->ncem() ? j < lc.deep : false, lc.pos0 + j);
+    for (int j = 0; j < lc.g && r == NEMGPU_OK && herr == hipSuccess; j++) {
+        r = enqueue_iteration(e, (lc.base + j) % 3, lc.sweep0 + j, j + 1 < lc.g && after_iter == nullptr, e->ncem() ? j < lc.deep : false, lc.pos0 + j);
+        if (r == NEMGPU_OK && after_iter != nullptr) r = (*after_iter)(j);
+    }
     e->stop_ptr = nullptr;
     if (herr == hipSuccess && r == NEMGPU_OK && with_copy)
         herr = hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream);
@@ -2938,6 +2942,151 @@ int nemgpu_iterate_logged(nemgpu_engine* e, int with_init, nemgpu_result* res, f
 {
     return iterate_logged_impl(e, with_init, false, res, crit_before, crit_after, prop, center, disp, nbobs_k);
 }
+
+// ---- one run with the reference's per-iteration log, the iterations pipelined ------------------------------------------
+// nemgpu_iterate_logged is one EM iteration, two criteria evaluations and a wait per call: 0.3 ms per logged iteration at
+// configs[1] size, of which the criteria's i-ordered sums (four lone blocks per partition) are 0.1-0.2 and the iteration
+// itself 0.04.  Here a batch of up to seven iterations runs as the unlogged loop runs it (device-side loop control, one
+// wait), and behind every iteration what its log line needs is set aside in a twin of the engine -- the partition the
+// E-step started from, the one it left, the densities, the parameters (0.75 MB of device copies) -- so that the criteria
+// of ALL the batch's iterations are one lock-step pass over the twins afterwards: their lone blocks side by side.
+static int ensure_clones(nemgpu_engine* e, int count);
+
+int nemgpu_run_logged(nemgpu_engine* e, nemgpu_result* res, nemgpu_log_fn fn, void* user)
+{
+    if (!e || !fn) return NEMGPU_E_FUNCARG;
+    HIPCHK(hipSetDevice(e->device));
+    int r;
+    const int k = e->k, d = e->d;
+    const size_t kd = (size_t)k * d;
+    std::vector<float> prop((size_t)k), center(kd), disp(kd), nb((size_t)k);
+    float cb[6], ca[6];
+    nemgpu_result r1{};
+    auto emit_line = [&](int iter, const float* b, const float* a, const float* p, const float* c, const float* s, const float* sizes) {
+        nemgpu_log_event ev{};
+        ev.kind = NEMGPU_LOG_LINE; ev.start = 0; ev.iter = iter; ev.crit_before = b; ev.crit_after = a;
+        ev.prop = p; ev.center = c; ev.disp = s; ev.nbobs_k = sizes;
+        fn(&ev, user);
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    static const bool prof = getenv("NEM_MI355X_BATCH_PROF") != nullptr;
+    auto lapt = t0;
+    auto lap = [&](const char* what) { if (prof) { const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[logged run] %s: %.0f us\n", what, std::chrono::duration<double, std::micro>(now - lapt).count()); lapt = now; } };
+    // ---- line 0: the start (reset, the two initial sweeps), both criteria, the parameters
+    if ((r = iterate_logged_impl(e, 1, false, &r1, cb, ca, prop.data(), center.data(), disp.data(), nb.data()))) return r;
+    emit_line(0, cb, ca, prop.data(), center.data(), disp.data(), nb.data());
+    lap("line 0 (start, two criteria)");
+    static const bool batched_on = !(getenv("NEM_MI355X_LOG_BATCHED") && getenv("NEM_MI355X_LOG_BATCHED")[0] == '0');
+    const bool batched = batched_on && e->ncem() && !crit_test(e) && e->lo == 0 && e->hi == e->n_total && e->parent == nullptr;
+    bool last_logged = false;
+    if (!batched) {
+        // (the fuzzy algorithm, the `crit` test, a sharded engine: one logged iteration per call, as nemgpu_iterate_logged)
+        for (int iter = 1; iter <= e->cfg.it_max && !e->converged && e->status == NEMGPU_OK; iter++) {
+            if ((r = iterate_logged_impl(e, 0, false, &r1, cb, ca, prop.data(), center.data(), disp.data(), nb.data()))) return r;
+            if (e->status == NEMGPU_W_EMPTYCLASS) {
+                nemgpu_log_event ev{}; ev.kind = NEMGPU_LOG_EMPTY; ev.iter = iter; ev.emptyk = e->emptyk; fn(&ev, user);
+                last_logged = false;
+                break;
+            }
+            emit_line(iter, cb, ca, prop.data(), center.data(), disp.data(), nb.data());
+            last_logged = true;
+        }
+    } else {
+        // two twins per iteration of a batch: the partition the E-step started from and the one it left, each with the
+        // iteration's densities -- 14 criteria evaluations in one pass
+        if ((r = ensure_clones(e, 2 * kPipeDepth))) return r;
+        for (nemgpu_engine* c : e->clones) { c->cfg = e->cfg; c->stream = e->stream; }
+        std::vector<nemgpu_engine*> T(e->clones.begin(), e->clones.begin() + 2 * kPipeDepth);
+        const size_t W = 12 + e->par_words;
+        char* st_dev = nullptr; char* st_host = nullptr; size_t dev_size = 0, host_size = 0;
+        HIPCHK(pool_get(e->device, false, (size_t)kPipeDepth * W * sizeof(float), &st_dev, &dev_size));
+        if (pool_get(e->device, true, (size_t)kPipeDepth * W * sizeof(float), &st_host, &host_size) != hipSuccess) {
+            pool_put(e->device, false, st_dev, dev_size);
+            set_error("no pinned memory for the log lines"); return NEMGPU_E_DEVICE;
+        }
+        struct Back { int dev; char* a; size_t as; char* b; size_t bs; hipStream_t s; ~Back() { (void)hipStreamSynchronize(s); pool_put(dev, false, a, as); pool_put(dev, true, b, bs); } }
+            back{e->device, st_dev, dev_size, st_host, host_size, e->stream};
+        std::vector<Recorder> recs((size_t)2 * kPipeDepth);
+        lap("twins and staging");
+        int iter = 0;
+        while (iter < e->cfg.it_max && !e->converged && e->status == NEMGPU_OK) {
+            LoopCursor lc;
+            const int g = std::min(e->cfg.it_max - iter, kPipeDepth);
+            if ((r = loop_begin(e, lc, g, false))) return r;
+            if ((r = batch_plan(e, lc))) return r;
+            const int base = lc.base;
+            // behind iteration j: the partition it started from and the one it left, the densities, the parameters
+            const std::function<int(int)> set_aside = [&](int j) -> int {
+                const int P = (base + j) % 3, Q = (base + j + 1) % 3;
+                for (int side = 0; side < 2; side++) {
+                    nemgpu_engine* c = T[(size_t)(2 * j + side)];
+                    HIPCHK(hipMemcpyAsync(c->lab[0], e->lab[side ? Q : P], (size_t)e->n_total, hipMemcpyDeviceToDevice, e->stream));
+                    HIPCHK(hipMemcpyAsync(c->pkfki, e->pkfki, sizeof(double) * (size_t)k * e->npad, hipMemcpyDeviceToDevice, e->stream));
+                    HIPCHK(hipMemcpyAsync(c->logpkfki, e->logpkfki, sizeof(float) * (size_t)k * e->npad, hipMemcpyDeviceToDevice, e->stream));
+                }
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<float*>(st_dev) + (size_t)j * W + 12, e->prop, sizeof(float) * e->par_words, hipMemcpyDeviceToDevice, e->stream));
+                return NEMGPU_OK;
+            };
+            e->n_plain++;
+            if ((r = batch_enqueue(e, lc, true, &set_aside))) return r;
+            HIPCHK(hipStreamSynchronize(e->stream));
+            const int* hc = e->h_ctrl();
+            const int done = hc[C_ITERS];
+            const bool tail_open = hc[C_NEED_ROUNDS] != 0 || hc[C_STATUS] == NEMGPU_W_EMPTYCLASS;   // the last counted iteration did not end in the pipeline
+            if ((r = batch_finish(e, lc))) return r;
+            if (prof) fprintf(stderr, "[logged run]   g %d done %d need_rounds %d status %d converged %d deep %d\n", g, done, hc[C_NEED_ROUNDS], hc[C_STATUS], hc[C_CONVERGED], lc.deep);
+            lap("a batch of iterations");
+            const int whole = tail_open ? std::max(0, done - 1) : done;
+            if (whole > 0) {
+                // the criteria of the `whole` iterations in one lock-step pass over the twins
+                std::vector<nemgpu_engine*> TT(T.begin(), T.begin() + 2 * whole);
+                std::vector<int> all((size_t)2 * whole);
+                for (int m = 0; m < 2 * whole; m++) all[(size_t)m] = m;
+                if ((r = lockstep(TT, all, recs, [&](int m) {
+                        nemgpu_engine* c = TT[(size_t)m];
+                        int* slot = reinterpret_cast<int*>(st_dev) + (size_t)(m / 2) * W + (m % 2) * 6;
+                        const int rr = criteria_enqueue(c, 0);
+                        if (rr == NEMGPU_OK) launch_copy_words(reinterpret_cast<const int*>(c->crit6_dev), slot, 6, e->stream);
+                        return rr;
+                    }, false))) return r;
+                HIPCHK(hipMemcpyAsync(st_host, st_dev, (size_t)whole * W * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipStreamSynchronize(e->stream));
+                for (int m = 0; m < whole; m++) {
+                    const float* f = reinterpret_cast<const float*>(st_host) + (size_t)m * W;
+                    emit_line(iter + m + 1, f, f + 6, f + 12, f + 12 + e->par_o_center, f + 12 + e->par_o_disp, f + 12 + e->par_o_nb);
+                    if (m == whole - 1) memcpy(ca, f + 6, sizeof ca);
+                }
+                last_logged = true;
+                lap("its criteria and lines");
+            }
+            iter += whole;
+            if (tail_open && done > 0) {
+                iter += 1;
+                if (e->status == NEMGPU_W_EMPTYCLASS) {
+                    nemgpu_log_event ev{}; ev.kind = NEMGPU_LOG_EMPTY; ev.iter = iter; ev.emptyk = e->emptyk; fn(&ev, user);
+                    last_logged = false;
+                    break;
+                }
+                // (its sweep was finished from the host: the plain sequence of calls)
+                if ((r = criteria(e, cb, (e->cur + 2) % 3)) || (r = criteria(e, ca, -1))) return r;
+                if ((r = nemgpu_get_results(e, prop.data(), center.data(), disp.data(), nb.data(), nullptr))) return r;
+                emit_line(iter, cb, ca, prop.data(), center.data(), disp.data(), nb.data());
+                last_logged = true;
+            }
+            if (done == 0) break;                                  // (nothing ran: the loop tests above end it)
+        }
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    fill_result(e, res);
+    if (res) {
+        res->loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // (the last logged iteration's second criteria evaluation was of the final partition, on the final densities)
+        if (last_logged && e->iters > 0) memcpy(res->crit, ca, sizeof ca);
+        else res->crit[0] = NAN;                                   // the caller asks nemgpu_criteria (after its own iters == 0 steps)
+    }
+    return NEMGPU_OK;
+}
+
 
 int nemgpu_restart_iterate(nemgpu_engine* e, int n_iters, nemgpu_result* res)
 {
