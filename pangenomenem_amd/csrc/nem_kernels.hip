@@ -2789,6 +2789,25 @@ void launch_fill(int* ptr, int words, int value, hipStream_t s)
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, s, a);
 }
 
+__global__ __launch_bounds__(256) void k_copy_segments(CopySegsArgs a)
+{
+    const int g = blockIdx.y;
+    if (g >= a.n) return;
+    const int words = a.words[g];
+    const int4* __restrict__ s4 = reinterpret_cast<const int4*>(a.src[g]);
+    int4* __restrict__ d4 = reinterpret_cast<int4*>(a.dst[g]);
+    const int quads = words >> 2;                                   // (every buffer starts on a 256-byte boundary)
+    for (int t = blockIdx.x * 256 + (int)threadIdx.x; t < quads; t += gridDim.x * 256) d4[t] = s4[t];
+    for (int t = (quads << 2) + blockIdx.x * 256 + (int)threadIdx.x; t < words; t += gridDim.x * 256) a.dst[g][t] = a.src[g][t];
+}
+void launch_copy_segments(const CopySegsArgs& a, hipStream_t s)
+{
+    int most = 0;
+    for (int g = 0; g < a.n; g++) most = std::max(most, a.words[g]);
+    const dim3 grid((unsigned)std::max(1, std::min(32, (most / 4 + 1023) / 1024)), (unsigned)std::max(1, a.n));
+    hipLaunchKernelGGL(k_copy_segments, grid, dim3(256), 0, s, a);
+}
+
 void launch_copy_words(const int* src, int* dst, int words, hipStream_t s)
 {
     CopyArgs a{src, dst, words};

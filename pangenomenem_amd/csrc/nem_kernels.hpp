@@ -137,6 +137,9 @@ struct CritArgs { int n, K, npad; const int* nei_ptr; const int* nei_idx; const 
                   float* crit6; int hard; };
 struct FillArgs { int* ptr; int words; int value; };
 struct CopyArgs { const int* src; int* dst; int words; };
+// up to eight device-to-device copies in one launch (the logged run's set-aside behind an iteration; not recordable)
+struct CopySegsArgs { const int* src[8]; int* dst[8]; int words[8]; int n; };
+void launch_copy_segments(const CopySegsArgs& a, hipStream_t s);
 struct LayoutArgs { const uint32_t* xf; const int* perm; int n, wf, W, npad, d, nw64; uint32_t* xw; uint32_t* xws; uint64_t* xt; };
 
 // ---- batched launches: B independent problems per launch ---------------------------------------------------------
