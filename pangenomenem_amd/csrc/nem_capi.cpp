@@ -86,13 +86,6 @@ void log_crit(std::string& out, const float crit6[6], float mult)
                            (double)std::nanf(""));                           // U, M, error rate (no reference partition)
     out.append(buf, (size_t)m);
 }
-void log_crit(FILE* fl, const float crit6[6], float mult)
-{
-    std::string t;
-    log_crit(t, crit6, mult);
-    fwrite(t.data(), 1, t.size(), fl);
-}
-
 void log_header(FILE* fl, int k, int d)
 {
     fprintf(fl, "%4s  %5s %5s %5s", "It", "UM", "PM", "Er");
@@ -151,21 +144,6 @@ static inline void put_fixed(std::string& out, float v, int width, int dec)
 }
 
 struct LogParams { std::vector<float> prop, center, disp, nk; };
-
-void log_classes(std::string& line, const LogParams& P, float beta, int k, int d, bool sizes_known);
-void log_classes(FILE* fl, const LogParams& P, float beta, int k, int d, bool sizes_known)
-{
-    std::string line;
-    log_classes(line, P, beta, k, d, sizes_known);
-    fwrite(line.data(), 1, line.size(), fl);
-}
-
-void log_classes(FILE* fl, nemgpu_engine* e, float beta, int k, int d, bool sizes_known)
-{
-    LogParams P{std::vector<float>(k), std::vector<float>((size_t)k * d), std::vector<float>((size_t)k * d), std::vector<float>(k)};
-    nemgpu_get_params(e, P.prop.data(), P.center.data(), P.disp.data(), P.nk.data());
-    log_classes(fl, P, beta, k, d, sizes_known);
-}
 
 void log_classes(std::string& line, const LogParams& P, float beta, int k, int d, bool sizes_known)
 {
