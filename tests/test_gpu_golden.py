@@ -255,8 +255,9 @@ def test_dropin_random_start_log_equals_the_reference_fixture(gpu_lib, tmp_path,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,seed", [(1069, 2), (1100, 1), (12, 5)])
-def test_dropin_random_start_log_in_lock_step_and_one_after_the_other(gpu_lib, tmp_path, monkeypatch, d, seed):
+@pytest.mark.parametrize("d,seed,algo,tie", [(1069, 2, "ncem", None), (1100, 1, "ncem", None), (12, 5, "ncem", None),
+                                            (12, 5, "ncem", "hash"), (40, 6, "nem", None), (40, 6, "ncem", "first")])
+def test_dropin_random_start_log_in_lock_step_and_one_after_the_other(gpu_lib, tmp_path, monkeypatch, d, seed, algo, tie):
     """The per-iteration log of an INIT_RANDOM run with the 50 starts in lock step (one EM iteration per step for all of
     them, their criteria side by side, the lines handed to the writer start by start afterwards) against the same call
     with the starts one after the other: the same text but the date.  d = 1 069 / 1 100: starts draw tie-breaks behind
@@ -271,10 +272,12 @@ def test_dropin_random_start_log_in_lock_step_and_one_after_the_other(gpu_lib, t
     base = nemfiles.write_nem_inputs(str(tmp_path), x, nei, prop, center, disp)
     os.remove(base + ".m")
     monkeypatch.setenv("NEM_MI355X_SEED", str(seed))
+    if tie is not None:                                        # (the stateless rules and the fuzzy algorithm: no stream to bet on)
+        monkeypatch.setenv("NEM_MI355X_TIE", tie)
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("NEM_MI355X_BATCH_STARTS_LOGGED", mode)
-        rc = nem_module.nem(base.encode(), k, b"ncem", 0.5, b"clas", 1e-8, b"fuzzy", 12, True, b"bern", b"pk", b"sk_", 1)
+        rc = nem_module.nem(base.encode(), k, algo.encode(), 0.5, b"clas", 1e-8, b"fuzzy", 12, True, b"bern", b"pk", b"sk_", 1)
         out[mode] = (rc, open(base + ".log").read().split("\n", 1)[1], open(base + ".uf").read() if rc == 0 else "",
                      open(base + ".mf").read() if rc == 0 else "")
     assert out["1"][0] == out["0"][0]
