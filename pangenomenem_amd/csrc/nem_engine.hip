@@ -1289,8 +1289,9 @@ int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[
     // the flags leave as soon as the rounds are through (an event marks the copy); the class masks and the sweep counter
     // run while the host wakes up and draws the next start's centres
     HIPCHK(hipMemcpyAsync(e->flags_host, e->flags_dev, e->flag_words() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    if (!e->ev_flags) HIPCHK(hipEventCreateWithFlags(&e->ev_flags, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(e->ev_flags, e->stream));
+    nemgpu_engine* ev_owner = e->parent ? e->parent : e;     // (the twins of a random-start round share their parent's event: one start at a time)
+    if (!ev_owner->ev_flags) HIPCHK(hipEventCreateWithFlags(&ev_owner->ev_flags, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_owner->ev_flags, e->stream));
     e->cur = 2;
     e->masks_valid = false;
     if ((r = do_labels_post(e, 2, -1))) return r;
@@ -1298,7 +1299,7 @@ int libc_init_one_wait(nemgpu_engine* e, int ra, int rb, bool* redo, int rounds[
     // (polled: the wait is tens of microseconds and its end is on the critical path of every start; a blocking wait's
     //  wake-up cost 5-10 us more)
     for (;;) {
-        const hipError_t q = hipEventQuery(e->ev_flags);
+        const hipError_t q = hipEventQuery(ev_owner->ev_flags);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { HIPCHK(q); }
         __builtin_ia32_pause();
