@@ -194,9 +194,16 @@ class EngineRun:
 
     def prime(self, steps, warmup):
         # every batch shape the warm-up and the timed region enqueue gets its hipGraph NOW, whatever --warmup is
-        for m in sorted({self.cycle, steps % self.cycle, warmup % self.cycle} - {0}):
-            self.eng.restart_iterate(m)
-        self.run_steps(warmup)
+        # (repeated until a pass neither captures nor sends plain launches: the engine adapts the rounds it enqueues for a
+        #  start over its first restarts and re-captures the batch shapes when it does)
+        for _ in range(6):
+            c0 = self.eng.graph_counters()
+            for m in sorted({self.cycle, steps % self.cycle, warmup % self.cycle} - {0}):
+                self.eng.restart_iterate(m)
+            self.run_steps(warmup)
+            c1 = self.eng.graph_counters()
+            if (c1["plain"], c1["captured"]) == (c0["plain"], c0["captured"]):
+                break
 
     def block(self, steps):
         """one timed block: restart_iterate() synchronises the stream before returning"""

@@ -136,6 +136,10 @@ struct nemgpu_engine {
     bool draw_borrowed = false;          // the table is the parent's (lock-step random starts): never written through this engine
     int draws_after_init = 0;                  // TIE_LIBC: the stream's position behind a run's two initial sweeps
     char* rs_par_host = nullptr; size_t rs_par_host_size = 0;   // random starts under TIE_LIBC: the starts' parameters, pinned
+    // NCEM, stateless tie rules: rounds enqueued for a start's beta sweep.  round_batch (three) until three starts in a row
+    // were through in two -- the third launch then only finds out that it has nothing to do, 4.4 us of every restart;
+    // a start that needs the third round after that is finished from the host and the count goes back up for good.
+    int init_rounds_ncem = 0; int init_two_streak = 0; bool init_rounds_locked = false;
     int libc_ra = 3, libc_rb = 3;              // TIE_LIBC, pipelined start: rounds enqueued for the blind / the beta initial sweep (batch_plan sets them; part of a first batch's graph)
     const int* draw_extra_once = nullptr;      // TIE_LIBC: the next sweep set up adds this device word to the draws before it (a sweep enqueued behind one whose count the host has not seen)
     int libc_init_hist[2][17] = {};            // TIE_LIBC random starts: how many relaxation rounds the blind / the beta initial sweep of the starts so far needed (16: more)
@@ -1184,6 +1188,15 @@ static bool libc_init_pipelined()
     return !(v && strcmp(v, "host") == 0);
 }
 
+// relaxation rounds a pipelined start enqueues for its beta sweep (enqueue_init; batch_finish continues from there)
+static int init_beta_rounds(const nemgpu_engine* e, int pipelined = -1)
+{
+    int n = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0), pipelined);
+    if (e->libc()) n = std::max(n, e->libc_rb);
+    else if (e->ncem() && current_recorder() == nullptr && e->init_rounds_ncem >= 2) n = sweep_first_rounds(e, e->cfg.beta, e->init_rounds_ncem, pipelined);
+    return n;
+}
+
 int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
 {
     int r;
@@ -1210,8 +1223,7 @@ int enqueue_init(nemgpu_engine* e, bool defer_ctrl)
     e->flags_clean = true;
     e->cur = 1;
     CtrlArgs ca{};
-    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0));
-    if (libc) ca.n_rounds = std::max(ca.n_rounds, e->libc_rb);
+    ca.ctrl = e->ctrl(); ca.iter_flags = e->iter_flags(); ca.round0 = e->round_flags(0); ca.n_rounds = init_beta_rounds(e);
     ca.param_fix = e->cfg.param_fix; ca.use_nei = ((e->has_graph && e->cfg.beta != 0.0f) || e->libc()) ? 1 : 0; ca.cvtest = e->cfg.cvtest;
     ca.ncem = e->ncem() ? 1 : 0; ca.cvthres = e->cfg.cvthres; ca.sweep_next = e->sweep_next; ca.ticket = e->sweep_next + 32;
     ca.draw_ctl = e->libc() ? e->draw_ctl : nullptr;
@@ -1505,13 +1517,23 @@ int batch_finish(nemgpu_engine* e, LoopCursor& lc)
     e->flags_clean = false;
     e->tables_fresh = e->cfg.param_fix;                        // (the fused density kernel does not rebuild the table buffers)
     if (e->ncem()) e->masks_valid = true;
+    const int init_launched = first ? init_beta_rounds(e, 1) : 0;    // (before the count below is touched)
+    if (first && !e->libc() && e->ncem() && current_recorder() == nullptr && e->has_graph && e->cfg.beta != 0.0f) {
+        if (c[C_NEED_ROUNDS] == 2) {
+            if (e->init_rounds_ncem != 0) { e->init_rounds_ncem = 0; drop_graphs(e); }       // (back to round_batch)
+            e->init_rounds_locked = true; e->init_two_streak = 0;
+        } else if (!e->init_rounds_locked && e->init_rounds_ncem == 0) {
+            e->init_two_streak = (c[C_INIT_ROUNDS] & 0xFF) <= 2 ? e->init_two_streak + 1 : 0;
+            if (e->init_two_streak >= 3 && e->round_batch > 2) { e->init_rounds_ncem = 2; drop_graphs(e); }
+        }
+    }
     if (first && c[C_NEED_ROUNDS] == 2) {
         // the initial beta sweep (buffers 1 -> 2/0) is not at its fixed point after the enqueued rounds; every
         // iteration behind it returned at the stop word.  Finish it from the host, then go on.
         e->cur = 1;
         e->n_host_rounds++;
         SweepCtx sc;
-        const int launched = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0), 1);
+        const int launched = init_launched;
         if ((r = host_rounds_ctx(e, sc, 1u, launched))) return r;
         if (fused_failed_seen(e, 0, 0, launched)) { if ((r = fused_fallback(e, sc))) return r; }
         if ((r = sweep_launch_rounds(e, sc, e->round_batch))) return r;

@@ -111,12 +111,12 @@ __device__ inline void ctrl_logic(const CtrlArgs& a)
             if (f.y > 0) { nzero += f.y; if (firstzero == 0) firstzero = f.z; }
             c[C_FOLD] = f.y > 0;                                  // how the next sweeps tally such sites, see k_sweep
             c[C_SWEEP_ROUNDS] = sweep_rounds;
+            c[C_INIT_ROUNDS] = (blind_needed << 8) | (last + 1);     // (what the two sweeps needed: the host enqueues accordingly)
             if (a.draw_ctl != nullptr && a.blind_rounds > 1) {    // TIE_LIBC: both sweeps' draws move the stream on
                 const int nt = (bf.w & ((1 << 30) - 1)) + (f.w & ((1 << 30) - 1));
                 a.draw_ctl[0] = draw0 + nt;
                 c[C_DRAWS] = draws + nt;
                 c[C_DRAWS_INIT] = nt;
-                c[C_INIT_ROUNDS] = (blind_needed << 8) | (last + 1);
             }
         }
         c[C_NZERO] = nzero; c[C_FIRSTZERO] = firstzero;

@@ -322,3 +322,39 @@ def test_lockstep_random_starts_equal_sequential_ones(gpu_lib, monkeypatch, algo
         assert other["iters"] == ref["iters"] and other["tie_draws"] == ref["tie_draws"]
         for key in ("c", "center", "disp", "prop", "crit"):
             assert np.array_equal(other[key], ref[key], equal_nan=True), key
+
+
+def test_the_starts_beta_sweep_gets_two_rounds_once_that_was_enough_and_three_again_when_it_is_not(gpu_lib, oracle):
+    """NCEM under a stateless tie rule: a pipelined start enqueues three relaxation rounds for its beta sweep until three
+    starts in a row were through in two, then two (the third launch only found out that it had nothing to do).  A start
+    that does need the third round afterwards stops its batch, is finished from the host, and the count goes back up for
+    good.  Easy starts first (the same problem four times), then starts with a strong field from poor parameters: every
+    run equals the oracle's, and the hard ones did go through the host at least once."""
+    from pangenomenem_amd.engine import NemEngine
+    n, d = 6000, 40
+    x, _ = synth.bernoulli_pa_matrix(n, d, 5)
+    nei = synth.contiguity_graph(n, 5)
+    prop, center, disp = synth.default_init(d)
+    eng = NemEngine(n, d, 3)
+    eng.set_matrix(x); eng.set_graph(nei)
+    cfg = dict(algo="ncem", beta=0.5, disper="sk_", propor="pk", it_max=6, tie="hash", seed=3)
+    want = oracle.run(x, nei, 3, prop, center, disp, **cfg)
+    for rep in range(5):
+        eng.set_params(prop, center, disp)
+        eng.configure(**cfg)
+        same_run(eng.run(), want, "ncem")
+    before = eng.graph_counters()["host_finished_sweeps"]
+    rng = np.random.default_rng(1)
+    for rep in range(6):
+        # poor parameters and a strong field: label changes run down the path, the beta sweep of the start needs more rounds
+        center2 = (rng.random((3, d)) < 0.5).astype(np.float32)
+        disp2 = np.full((3, d), 0.45, np.float32)
+        cfg2 = dict(cfg, beta=float(1.0 + rep))
+        eng.set_params(prop, center2, disp2)
+        eng.configure(**cfg2)
+        same_run(eng.run(), oracle.run(x, nei, 3, prop, center2, disp2, **cfg2), "ncem")
+    assert eng.graph_counters()["host_finished_sweeps"] > before
+    eng.set_params(prop, center, disp)
+    eng.configure(**cfg)
+    same_run(eng.run(), want, "ncem")
+    eng.close()
