@@ -1192,7 +1192,7 @@ static bool libc_init_pipelined()
 static int init_beta_rounds(const nemgpu_engine* e, int pipelined = -1)
 {
     int n = sweep_first_rounds(e, e->cfg.beta, std::max<int>(e->round_batch, (!e->ncem() && current_recorder() == nullptr) ? e->fz_init_need : 0), pipelined);
-    if (e->libc()) n = std::max(n, e->libc_rb);
+    if (e->libc()) n = sweep_first_rounds(e, e->cfg.beta, e->libc_rb, pipelined);      // (what 95 % of the starts so far needed: batch_plan)
     else if (e->ncem() && current_recorder() == nullptr && e->init_rounds_ncem >= 2) n = sweep_first_rounds(e, e->cfg.beta, e->init_rounds_ncem, pipelined);
     return n;
 }
@@ -1358,7 +1358,7 @@ int libc_init_usual(const nemgpu_engine* e, int which, int percent)
     int total = 0; for (int q = 0; q <= 16; q++) total += h[q];
     int acc = 0, q = 0;
     for (; q < 16; q++) { acc += h[q]; if (total > 0 && 100 * acc >= percent * total) break; }
-    return std::max(e->round_batch, total > 0 ? q : 3);
+    return total > 0 ? std::max(2, q) : std::max(3, e->round_batch);      // (nothing seen yet: three)
 }
 void libc_init_tally(nemgpu_engine* e, const int rounds[2])
 {
@@ -1448,7 +1448,8 @@ int batch_plan(nemgpu_engine* e, LoopCursor& lc)
     if (e->libc()) {
         if (lc.first) {
             // the rounds of the two initial sweeps: what most runs so far got by with (at most 8: the loop control's window)
-            const int ra = std::max(2, std::min(8, libc_init_usual(e, 0, 90))), rb = std::max(2, std::min(8, libc_init_usual(e, 1, 70)));
+            // (95 %: a start that needs more costs a whole batch and a second start from the host here, not one more wait)
+            const int ra = std::max(2, std::min(8, libc_init_usual(e, 0, 95))), rb = std::max(2, std::min(8, libc_init_usual(e, 1, 95)));
             if (ra != e->libc_ra || rb != e->libc_rb) { e->libc_ra = ra; e->libc_rb = rb; drop_graphs(e); }
         }
         if ((r = ensure_draw_window(e, e->draws, draw_need(e)))) return r;      // (may drop the graphs)
