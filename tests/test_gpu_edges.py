@@ -358,3 +358,34 @@ def test_the_starts_beta_sweep_gets_two_rounds_once_that_was_enough_and_three_ag
     eng.configure(**cfg)
     same_run(eng.run(), want, "ncem")
     eng.close()
+
+
+def test_one_engine_through_many_different_starts(gpu_lib, oracle):
+    """One engine, sixty runs in a row that differ in parameters, field strength, tie rule and iteration cap: what the engine
+    learns from a run about the rounds to enqueue (a start's beta sweep, the tie stream's two initial sweeps, the first
+    iterations' third round) is only ever a guess about the next one -- every run must equal the oracle's whatever the
+    guess was."""
+    from pangenomenem_amd.engine import NemEngine
+    n, d = 4000, 24
+    x, _ = synth.bernoulli_pa_matrix(n, d, 9, p=(0.9, 0.5, 0.1))
+    nei = synth.contiguity_graph(n, 9)
+    eng = NemEngine(n, d, 3)
+    eng.set_matrix(x); eng.set_graph(nei)
+    rng = np.random.default_rng(4)
+    prop0, center0, disp0 = synth.default_init(d)
+    for rep in range(60):
+        easy = rep % 5 != 4
+        if easy:
+            prop, center, disp = prop0, center0, disp0
+        else:                                                  # two classes alike, poor dispersions: ties and long sweeps
+            prop = np.array([0.3, 0.3, 0.4], np.float32)
+            center = (rng.random((3, d)) < 0.5).astype(np.float32); center[1] = center[0]
+            disp = np.full((3, d), np.float32(rng.choice([0.2, 0.45])), np.float32)
+        cfg = dict(algo="ncem", beta=float(rng.choice([0.0, 0.5, 1.0, 2.5])), disper=str(rng.choice(["sk_", "skd"])), propor="pk",
+                   it_max=int(rng.choice([0, 1, 5, 30])), tie=str(rng.choice(["hash", "libc", "first"])), seed=int(rng.integers(0, 99)))
+        eng.set_params(prop, center, disp)
+        eng.configure(**cfg)
+        got = eng.run()
+        want = oracle.run(x, nei, 3, prop, center, disp, **cfg)
+        same_run(got, want, "ncem")
+    eng.close()
